@@ -1,0 +1,20 @@
+"""singa_amd: an MI355X-native deep-learning framework with the public API of
+Apache SINGA (tensor, device, autograd, layer, model, opt, sonnx, ...).
+
+Compute path: PyTorch-ROCm supplies memory and streams, every hot op is a
+hand-written HIP kernel for gfx950 (``singa_amd/csrc/hip``), collectives run
+on RCCL through ``torch.distributed`` and steady-state training steps replay
+as hipGraphs.  The runtime around it (graph scheduler, record files,
+snapshot, logging) is C++ (``singa_amd/csrc/runtime``).
+"""
+__version__ = "0.1.0"
+
+from . import singa_wrap  # noqa: F401
+from . import device  # noqa: F401
+from . import tensor  # noqa: F401
+from . import autograd  # noqa: F401
+from . import layer  # noqa: F401
+from . import model  # noqa: F401
+from . import opt  # noqa: F401
+from . import initializer  # noqa: F401
+from . import utils  # noqa: F401

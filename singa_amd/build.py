@@ -1,0 +1,123 @@
+"""In-tree build of the native extensions.
+
+Two shared objects are produced next to this file:
+
+* ``_rt``  – C++17 runtime (graph scheduler, blocks, record files, snapshot,
+  logging, channel, timer), no GPU dependency, compiled with g++.
+* ``_hip`` – every HIP kernel under ``csrc/hip`` compiled by hipcc for gfx950
+  plus a pybind11 binding file that passes raw device pointers and a stream.
+
+Run ``python -m singa_amd.build`` (add ``--force`` to rebuild everything).
+"""
+import os
+import subprocess
+import sys
+import sysconfig
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "_obj")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+ARCH = "gfx950"
+EXT_SUFFIX = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+
+
+def _py_includes():
+    import pybind11
+    return ["-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"]]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _headers(*dirs):
+    out = []
+    for d in dirs:
+        for root, _, files in os.walk(d):
+            out += [os.path.join(root, f) for f in files
+                    if f.endswith((".h", ".hpp", ".cuh"))]
+    return out
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def _compile_many(jobs, workers):
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        for out in ex.map(_run, jobs):
+            if out.strip():
+                sys.stderr.write(out)
+
+
+def build_rt(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    rt = os.path.join(CSRC, "runtime")
+    srcs = [os.path.join(rt, f) for f in sorted(os.listdir(rt)) if f.endswith(".cc")]
+    srcs.append(os.path.join(CSRC, "bindings", "rt_bind.cc"))
+    hdrs = _headers(rt)
+    target = os.path.join(HERE, "_rt" + EXT_SUFFIX)
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(OBJ, "rt_" + os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                         "-Wall", "-c", s, "-o", o] + _py_includes())
+    if jobs and verbose:
+        print("[singa_amd.build] compiling %d runtime sources" % len(jobs))
+    _compile_many(jobs, 8)
+    if jobs or not os.path.exists(target):
+        _run(["g++", "-shared", "-o", target] + objs + ["-lpthread"])
+    return target
+
+
+def build_hip(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hd = os.path.join(CSRC, "hip")
+    srcs = [os.path.join(hd, f) for f in sorted(os.listdir(hd)) if f.endswith(".hip")]
+    hdrs = _headers(hd)
+    target = os.path.join(HERE, "_hip" + EXT_SUFFIX)
+    hipcc = os.path.join(ROCM, "bin", "hipcc")
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(OBJ, "hip_" + os.path.basename(s) + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17",
+                         "-fPIC", "-ffast-math", "-fno-gpu-rdc",
+                         "-Wno-unused-result", "-c", s, "-o", o])
+    bind = os.path.join(CSRC, "bindings", "hip_bind.cc")
+    bo = os.path.join(OBJ, "hip_bind.o")
+    objs.append(bo)
+    if force or _newer(bo, [bind] + hdrs):
+        jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+                     "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
+                     "-I" + hd, "-c", bind, "-o", bo] + _py_includes())
+    if jobs and verbose:
+        print("[singa_amd.build] compiling %d HIP sources for %s" % (len(jobs), ARCH))
+    _compile_many(jobs, 8)
+    if jobs or not os.path.exists(target):
+        _run(["g++", "-shared", "-o", target] + objs +
+             ["-L" + os.path.join(ROCM, "lib"), "-lamdhip64",
+              "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+    return target
+
+
+def build_all(force=False, verbose=True):
+    return [build_rt(force, verbose), build_hip(force, verbose)]
+
+
+if __name__ == "__main__":
+    outs = build_all(force="--force" in sys.argv)
+    for o in outs:
+        print("built", o)

@@ -1,0 +1,254 @@
+"""Convolution, batch-norm and pooling handles plus their forward / backward
+functions.  One implementation serves both devices: the op body asks the
+device's math backend (torch on the host, the hand-written MFMA / LDS kernels
+on the GPU), so ``Cpu*`` and ``Gpu*`` names are aliases of the same function.
+
+Behaviour parity: reference src/model/operation/{convolution,batchnorm,
+pooling}.{h,cc}; binding names from src/api/model_operation.i:37-191.
+"""
+from . import dtypes
+from .tensor_core import Tensor, _submit, Contiguous
+
+
+def _pair(v):
+    if isinstance(v, (list, tuple)):
+        return int(v[0]), int(v[1])
+    return int(v), int(v)
+
+
+class ConvHandle(object):
+    """Geometry of one 2-d convolution (NCHW, cross-correlation, dilation 1,
+    optional groups).  reference convolution.cc:29-70."""
+
+    def __init__(self, x, kernel_size, stride, padding, in_channels,
+                 out_channels, bias, groups=1,
+                 workspace_byte_limit=1024 * 1024 * 1024, prefer="fastest"):
+        self.kernel_h, self.kernel_w = _pair(kernel_size)
+        self.pad_h, self.pad_w = _pair(padding)
+        self.stride_h, self.stride_w = _pair(stride)
+        self.channels = int(in_channels)
+        self.num_filters = int(out_channels)
+        self.group = int(groups)
+        self.bias_term = bool(bias)
+        self.batchsize = x.shape(0)
+        assert x.shape(1) == self.channels, (
+            "the number of input channels mismatched: %d vs %d" %
+            (x.shape(1), self.channels))
+        self.height = x.shape(2)
+        self.width = x.shape(3)
+        self.conv_height = 1
+        if self.stride_h > 0:
+            self.conv_height = (self.height + 2 * self.pad_h -
+                                self.kernel_h) // self.stride_h + 1
+        self.conv_width = (self.width + 2 * self.pad_w -
+                           self.kernel_w) // self.stride_w + 1
+        self.col_height = self.channels * self.kernel_w * self.kernel_h
+        self.col_width = self.conv_height * self.conv_width
+        self.imagesize = x.Size() // self.batchsize
+        self.workspace_byte_limit = workspace_byte_limit
+        self.prefer = prefer
+
+    def out_shape(self, batch):
+        return [batch, self.num_filters, self.conv_height, self.conv_width]
+
+
+CudnnConvHandle = ConvHandle
+
+
+def _check_conv_input(x, ch):
+    assert x.nDim() == 4 and x.shape(1) == ch.channels and \
+        x.shape(2) == ch.height and x.shape(3) == ch.width, "input sample not match"
+
+
+def ConvForward(x, W, b, ch):
+    _check_conv_input(x, ch)
+    xs = x if x.is_contiguous() else Contiguous(x)
+    y = Tensor(ch.out_shape(x.shape(0)), x.device(), x.data_type())
+    st, pd, g = (ch.stride_h, ch.stride_w), (ch.pad_h, ch.pad_w), ch.group
+    if ch.bias_term and b is not None and b.Size() > 0:
+        _submit(x.device(), "ConvForward",
+                lambda a, w, bb, o: a._dev.math.conv_fwd(
+                    a.view(), w.view(), bb.view(), o.view(), st, pd, g),
+                [xs, W, b], [y])
+    else:
+        _submit(x.device(), "ConvForward",
+                lambda a, w, o: a._dev.math.conv_fwd(
+                    a.view(), w.view(), None, o.view(), st, pd, g),
+                [xs, W], [y])
+    return y
+
+
+def ConvBackwardx(dy, W, x, ch):
+    d = dy if dy.is_contiguous() else Contiguous(dy)
+    dx = Tensor(x.shape(), x.device(), x.data_type())
+    st, pd, g = (ch.stride_h, ch.stride_w), (ch.pad_h, ch.pad_w), ch.group
+    _submit(x.device(), "ConvBackwardx",
+            lambda a, w, o: a._dev.math.conv_bwd_data(
+                a.view(), w.view(), o.view(), st, pd, g),
+            [d, W], [dx])
+    return dx
+
+
+def ConvBackwardW(dy, x, W, ch):
+    d = dy if dy.is_contiguous() else Contiguous(dy)
+    xs = x if x.is_contiguous() else Contiguous(x)
+    dW = Tensor(W.shape(), W.device(), W.data_type())
+    st, pd, g = (ch.stride_h, ch.stride_w), (ch.pad_h, ch.pad_w), ch.group
+    _submit(x.device(), "ConvBackwardW",
+            lambda a, xx, o: a._dev.math.conv_bwd_weight(
+                a.view(), xx.view(), o.view(), st, pd, g),
+            [d, xs], [dW])
+    return dW
+
+
+def ConvBackwardb(dy, b, ch):
+    d = dy if dy.is_contiguous() else Contiguous(dy)
+    db = Tensor(b.shape(), b.device(), b.data_type())
+    _submit(dy.device(), "ConvBackwardb",
+            lambda a, o: a._dev.math.conv_bwd_bias(a.view(), o.view()),
+            [d], [db])
+    return db
+
+
+CpuConvForward = GpuConvForward = ConvForward
+CpuConvBackwardx = GpuConvBackwardx = ConvBackwardx
+CpuConvBackwardW = GpuConvBackwardW = ConvBackwardW
+CpuConvBackwardb = GpuConvBackwardb = ConvBackwardb
+
+
+class BatchNormHandle(object):
+    """``factor`` is the weight of the *batch* statistics in the running
+    average (running = (1 - factor) * running + factor * batch), i.e. the
+    constructor argument is used verbatim, and the variance that enters the
+    running average is the unbiased one.  reference batchnorm.cc:27-60 and
+    test/python/test_api.py:31-54."""
+
+    eps = 1e-5
+
+    def __init__(self, momentum, x):
+        self.factor = float(momentum)
+        self.batchsize = x.shape(0)
+        self.channels = x.shape(1)
+        if x.nDim() == 4:
+            self.height, self.width, self.is_2d = x.shape(2), x.shape(3), False
+        elif x.nDim() == 2:
+            self.height, self.width, self.is_2d = 1, 1, True
+        else:
+            raise ValueError("Expecting input tensor to be of dimension 2 or 4")
+
+
+CudnnBatchNormHandle = BatchNormHandle
+
+
+def BatchNormForwardTraining(bnh, x, scale, bias, running_mean, running_var):
+    """Returns [y, batch_mean, batch_inv_std]; updates the running statistics
+    in place."""
+    xs = x if x.is_contiguous() else Contiguous(x)
+    dev = x.device()
+    y = Tensor(x.shape(), dev, x.data_type())
+    mean = Tensor([bnh.channels], dev, dtypes.kFloat32)
+    invstd = Tensor([bnh.channels], dev, dtypes.kFloat32)
+    f, eps = bnh.factor, bnh.eps
+
+    def body(a, s, b, rm_in, rv_in, o, m, iv, rm, rv):
+        a._dev.math.bn_fwd_train(a.view(), s.view(), b.view(), rm.view(),
+                                 rv.view(), f, eps, o.view(), m.view(),
+                                 iv.view())
+    _submit(dev, "BatchNormForwardTraining", body,
+            [xs, scale, bias, running_mean, running_var],
+            [y, mean, invstd, running_mean, running_var])
+    return [y, mean, invstd]
+
+
+def BatchNormForwardInference(bnh, x, scale, bias, running_mean, running_var):
+    xs = x if x.is_contiguous() else Contiguous(x)
+    dev = x.device()
+    y = Tensor(x.shape(), dev, x.data_type())
+    eps = bnh.eps
+    _submit(dev, "BatchNormForwardInference",
+            lambda a, s, b, rm, rv, o: a._dev.math.bn_fwd_infer(
+                a.view(), s.view(), b.view(), rm.view(), rv.view(), eps,
+                o.view()),
+            [xs, scale, bias, running_mean, running_var], [y])
+    return y
+
+
+def BatchNormBackward(bnh, dy, x, scale, mean, invstd):
+    """Returns [dx, dscale, dbias]."""
+    d = dy if dy.is_contiguous() else Contiguous(dy)
+    xs = x if x.is_contiguous() else Contiguous(x)
+    dev = x.device()
+    dx = Tensor(x.shape(), dev, x.data_type())
+    dscale = Tensor(scale.shape(), dev, scale.data_type())
+    dbias = Tensor(scale.shape(), dev, scale.data_type())
+    _submit(dev, "BatchNormBackward",
+            lambda a, xx, s, m, iv, o, ds, db: a._dev.math.bn_bwd(
+                a.view(), xx.view(), s.view(), m.view(), iv.view(), o.view(),
+                ds.view(), db.view()),
+            [d, xs, scale, mean, invstd], [dx, dscale, dbias])
+    return [dx, dscale, dbias]
+
+
+GpuBatchNormForwardTraining = CpuBatchNormForwardTraining = BatchNormForwardTraining
+GpuBatchNormForwardInference = CpuBatchNormForwardInference = BatchNormForwardInference
+GpuBatchNormBackward = BatchNormBackward
+
+
+def CpuBatchNormBackwardx(bnh, y, dy, x, scale, bias, mean, var):
+    return BatchNormBackward(bnh, dy, x, scale, mean, var)
+
+
+class PoolingHandle(object):
+    """2-d max / average pooling; average excludes the padding from the
+    divisor and the output size is rounded down.  reference pooling.cc:27-60."""
+
+    def __init__(self, x, kernel_size, stride, padding, is_max=True):
+        self.kernel_h, self.kernel_w = _pair(kernel_size)
+        self.pad_h, self.pad_w = _pair(padding)
+        self.stride_h, self.stride_w = _pair(stride)
+        self.batchsize = x.shape(0)
+        self.channels = x.shape(1)
+        self.height = x.shape(2)
+        self.width = x.shape(3)
+        self.pooled_height = 1
+        if self.stride_h > 0:
+            self.pooled_height = (self.height + 2 * self.pad_h -
+                                  self.kernel_h) // self.stride_h + 1
+        self.pooled_width = (self.width + 2 * self.pad_w -
+                             self.kernel_w) // self.stride_w + 1
+        self.is_max_pooling = bool(is_max)
+
+    def _args(self):
+        sh = self.stride_h if self.stride_h > 0 else 1
+        return ((self.kernel_h, self.kernel_w), (sh, self.stride_w),
+                (self.pad_h, self.pad_w), self.is_max_pooling)
+
+
+CudnnPoolingHandle = PoolingHandle
+
+
+def PoolingForward(ph, x):
+    xs = x if x.is_contiguous() else Contiguous(x)
+    y = Tensor([x.shape(0), x.shape(1), ph.pooled_height, ph.pooled_width],
+               x.device(), x.data_type())
+    k, s, p, mx = ph._args()
+    _submit(x.device(), "PoolingForward",
+            lambda a, o: a._dev.math.pool_fwd(a.view(), o.view(), k, s, p, mx),
+            [xs], [y])
+    return y
+
+
+def PoolingBackward(ph, dy, x, y):
+    d = dy if dy.is_contiguous() else Contiguous(dy)
+    xs = x if x.is_contiguous() else Contiguous(x)
+    dx = Tensor(x.shape(), x.device(), x.data_type())
+    k, s, p, mx = ph._args()
+    _submit(x.device(), "PoolingBackward",
+            lambda a, xx, yy, o: a._dev.math.pool_bwd(
+                a.view(), xx.view(), yy.view(), o.view(), k, s, p, mx),
+            [d, xs, y], [dx])
+    return dx
+
+
+GpuPoolingForward = CpuPoolingForward = PoolingForward
+GpuPoolingBackward = CpuPoolingBackward = PoolingBackward

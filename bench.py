@@ -1,0 +1,130 @@
+"""Headline benchmark: ResNet-50 training throughput (images / second).
+
+Workload = reference examples/cnn/benchmark.py:33-92: ResNet-50, 1000 classes,
+synthetic 224 x 224 images copied to the device once, batch 32 per GPU (weak
+scaling), SGD(lr 0.1, momentum 0.9, weight_decay 1e-5), float32, graph mode;
+with more than one GPU the optimizer is wrapped in DistOpt (RCCL all-reduce,
+fused buckets, overlapped with backward), one process per GPU.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+BASELINE_IMG_S = {1: 45.0, 2: 88.0, 4: 173.0, 8: 332.0}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--verbosity", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from singa_amd import device, opt, tensor
+    from singa_amd.models import resnet
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world),
+                  file=sys.stderr)
+
+    sgd = opt.SGD(lr=0.1, momentum=0.9, weight_decay=1e-5)
+    if world > 1:
+        sgd = opt.DistOpt(sgd)
+        local_rank = sgd.local_rank
+    dev = device.create_cuda_gpu_on(local_rank)
+    dev.SetVerbosity(args.verbosity)
+    dev.SetSkipIteration(5)
+
+    B, S = args.batch, 224
+    rs = np.random.RandomState(1234 + rank)
+    x = rs.randn(B, 3, S, S).astype(np.float32)
+    y = rs.randint(0, 1000, B).astype(np.int32)
+    dt = tensor.float32 if args.dtype == "fp32" else tensor.float16
+    tx = tensor.Tensor((B, 3, S, S), dev, dt)
+    ty = tensor.Tensor((B,), dev, tensor.int32)
+    tx.copy_from_numpy(x.astype(np.float16) if dt == tensor.float16 else x)
+    ty.copy_from_numpy(y)
+
+    model = getattr(resnet, args.model)(num_channels=3, num_classes=1000)
+    model.train()
+    model.set_optimizer(sgd)
+    model.compile([tx], is_train=True, use_graph=not args.no_graph,
+                  sequential=world > 1)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        _, loss = model(tx, ty, 'plain', None)
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        _, loss = model(tx, ty, 'plain', None)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev.torch_device,
+                         dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_val = float(tensor.to_numpy(loss).reshape(-1)[0])
+    if rank == 0:
+        value = args.steps * B * world / elapsed
+        base = BASELINE_IMG_S.get(world)
+        print(json.dumps({
+            "metric": "images/sec (whole node) ResNet-50 DistOpt training",
+            "value": round(value, 2),
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": round(value / base, 2) if base else None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "final_loss": loss_val,
+            "config": {
+                "model": args.model,
+                "global_batch": B * world,
+                "per_gpu_batch": B,
+                "image_size": S,
+                "optimizer": "SGD(lr=0.1, momentum=0.9, weight_decay=1e-5)",
+                "parallelism": "dp%d" % world,
+                "graph": not args.no_graph,
+            },
+        }), flush=True)
+        if args.verbosity > 0:
+            dev.PrintTimeProfiling()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,554 @@
+"""MI355X math backend: every primitive launches a hand-written HIP kernel from
+``singa_amd._hip`` on the current torch stream.
+
+Operands arrive as torch views (carrying shape, strides and storage offset of
+the tensor); the methods translate them into raw pointers plus collapsed
+stride descriptors, so transposed / broadcast views are consumed in place.
+Temporary workspaces come from torch's caching allocator, which makes every
+method safe to call while a hipGraph is being captured (allocations land in
+the graph's private pool).
+
+Contract parity: reference src/core/tensor/tensor_math.h:86-485 and
+tensor_math_cuda.h (the CUDA specialisations this backend stands in for).
+"""
+import torch
+
+from . import dtypes
+
+_U = {n: i for i, n in enumerate([
+    "copy", "abs", "exp", "log", "sqrt", "square", "sign", "ceil", "floor",
+    "round", "rounde", "sigmoid", "tanh", "relu", "erf", "cos", "cosh", "acos",
+    "acosh", "sin", "sinh", "asin", "asinh", "tan", "atan", "atanh", "softplus",
+    "softsign", "clamp", "add_s", "sub_s", "mul_s", "div_s", "pow_s", "rdiv_s",
+    "lt_s", "le_s", "gt_s", "ge_s", "eq_s", "max_s", "min_s"])}
+_B = {n: i for i, n in enumerate([
+    "add", "sub", "mul", "div", "pow", "lt", "le", "gt", "ge", "eq", "max",
+    "min", "relu_bwd"])}
+_R = {"sum": 0, "mean": 1, "max": 2, "min": 3, "asum": 4, "sumsq": 5}
+
+_CODE = {torch.float32: 0, torch.float16: 1, torch.int32: 2,
+         torch.bfloat16: 7}
+
+
+def _code(t):
+    try:
+        return _CODE[t.dtype]
+    except KeyError:
+        raise TypeError("dtype %s has no HIP kernels" % t.dtype)
+
+
+def _collapse(shape, strides_list):
+    """Drop size-1 dims and merge neighbouring dims that are contiguous for
+    every operand.  Returns (shape, [strides...])."""
+    dims = [(s, tuple(st[i] for st in strides_list))
+            for i, s in enumerate(shape) if s != 1]
+    if not dims:
+        return [1], [[0] for _ in strides_list]
+    out = [dims[0]]
+    for s, st in dims[1:]:
+        ps, pst = out[-1]
+        if all(a == b * s for a, b in zip(pst, st)):
+            out[-1] = (ps * s, st)
+        else:
+            out.append((s, st))
+    shp = [d[0] for d in out]
+    sts = [[d[1][k] for d in out] for k in range(len(strides_list))]
+    return shp, sts
+
+
+def _is_linear(shp, st):
+    return len(shp) == 1 and st[0] == 1
+
+
+class HipMath(object):
+    name = "hip"
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.k = dev.kernels
+
+    # ---- plumbing -----------------------------------------------------------
+    def _s(self):
+        return torch.cuda.current_stream(self.dev.torch_device).cuda_stream
+
+    def _tmp(self, n, dtype=torch.float32):
+        return torch.empty(n, dtype=dtype, device=self.dev.torch_device)
+
+    def _unary(self, op, x, out, a=0.0, b=0.0):
+        n = out.numel()
+        if n == 0:
+            return
+        if tuple(x.shape) != tuple(out.shape):
+            x = x.expand(out.shape)
+        shp, (sx, so) = _collapse(list(out.shape),
+                                  [list(x.stride()), list(out.stride())])
+        ci, co = _code(x), _code(out)
+        if _is_linear(shp, sx) and _is_linear(shp, so):
+            self.k.unary_contig(op, ci, co, x.data_ptr(), out.data_ptr(), n,
+                                float(a), float(b), self._s())
+        else:
+            if len(shp) > 8:
+                x = x.contiguous()
+                return self._unary(op, x, out, a, b)
+            self.k.unary_strided(op, ci, co, x.data_ptr(), out.data_ptr(), shp,
+                                 sx, so, n, float(a), float(b), self._s())
+
+    # ---- element-wise ----------------------------------------------------------
+    def fill(self, out, value):
+        if out.is_contiguous():
+            self.k.fill(_code(out), out.data_ptr(), out.numel(), float(value),
+                        self._s())
+        else:
+            # x * 0 + value over the strided view
+            self._unary(_U["mul_s"], out, out, 0.0)
+            self._unary(_U["add_s"], out, out, float(value))
+
+    def copy(self, src, dst):
+        if src.dtype not in _CODE or dst.dtype not in _CODE:
+            dst.copy_(src)  # 8-bit / 64-bit types: data movement only
+            return
+        self._unary(_U["copy"], src, dst)
+
+    def unary(self, op, x, out):
+        self._unary(_U[op], x, out)
+
+    def clamp(self, x, lo, hi, out):
+        self._unary(_U["clamp"], x, out, lo, hi)
+
+    def binary(self, op, a, b, out):
+        n = out.numel()
+        if n == 0:
+            return
+        if a.dtype != out.dtype:
+            a = self._cast(a, out.dtype)
+        if b.dtype != out.dtype:
+            b = self._cast(b, out.dtype)
+        if tuple(a.shape) != tuple(out.shape):
+            a = a.expand(out.shape)
+        if tuple(b.shape) != tuple(out.shape):
+            b = b.expand(out.shape)
+        shp, (sa, sb, so) = _collapse(
+            list(out.shape),
+            [list(a.stride()), list(b.stride()), list(out.stride())])
+        code = _code(out)
+        if _is_linear(shp, sa) and _is_linear(shp, sb) and _is_linear(shp, so):
+            self.k.binary_contig(_B[op], code, a.data_ptr(), b.data_ptr(),
+                                 out.data_ptr(), n, self._s())
+        else:
+            if len(shp) > 8:
+                return self.binary(op, a.contiguous(), b.contiguous(), out)
+            self.k.binary_strided(_B[op], code, a.data_ptr(), b.data_ptr(),
+                                  out.data_ptr(), shp, sa, sb, so, n,
+                                  self._s())
+
+    def _cast(self, x, tdtype):
+        out = torch.empty(x.shape, dtype=tdtype, device=x.device)
+        self._unary(_U["copy"], x, out)
+        return out
+
+    def binary_scalar(self, op, x, s, out):
+        self._unary(_U[op + "_s"], x, out, float(s))
+
+    def axpy(self, alpha, x, y):
+        if (x.is_contiguous() and y.is_contiguous() and x.dtype == y.dtype and
+                x.data_ptr() % 16 == 0 and y.data_ptr() % 16 == 0 and
+                x.dtype != torch.int32):
+            if torch.is_tensor(alpha):
+                if alpha.dtype != torch.float32:
+                    alpha = self._cast(alpha, torch.float32)
+                self.k.axpy(_code(y), alpha.data_ptr(), 0.0, x.data_ptr(),
+                            y.data_ptr(), y.numel(), self._s())
+            else:
+                self.k.axpy(_code(y), 0, float(alpha), x.data_ptr(),
+                            y.data_ptr(), y.numel(), self._s())
+            return
+        if torch.is_tensor(alpha):
+            tmp = torch.empty(x.shape, dtype=y.dtype, device=y.device)
+            self.binary("mul", x, alpha.reshape([1] * x.dim()), tmp)
+        else:
+            tmp = torch.empty(x.shape, dtype=y.dtype, device=y.device)
+            self._unary(_U["mul_s"], x, tmp, float(alpha))
+        self.binary("add", y, tmp, y)
+
+    # ---- random -------------------------------------------------------------------
+    def _rng(self, fn, out, a, b=None):
+        tgt = out if out.is_contiguous() and out.dtype != torch.int32 else \
+            torch.empty(out.shape, dtype=torch.float32, device=out.device)
+        st = self.dev.rng_state.data_ptr()
+        if b is None:
+            fn(_code(tgt), tgt.data_ptr(), tgt.numel(), float(a), st, self._s())
+        else:
+            fn(_code(tgt), tgt.data_ptr(), tgt.numel(), float(a), float(b), st,
+               self._s())
+        if tgt is not out:
+            self.copy(tgt, out)
+
+    def uniform(self, out, low, high):
+        self._rng(self.k.rng_uniform, out, low, high)
+
+    def gaussian(self, out, mean, std):
+        self._rng(self.k.rng_normal, out, mean, std)
+
+    def bernoulli(self, out, p):
+        self._rng(self.k.rng_bernoulli, out, p)
+
+    # ---- reductions -------------------------------------------------------------------
+    def _f32c(self, x):
+        """contiguous float32 version of x (no copy when already so)"""
+        if x.dtype == torch.float32 and x.is_contiguous():
+            return x
+        out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+        self._unary(_U["copy"], x, out)
+        return out
+
+    def _reduce_all(self, op, x):
+        xf = self._f32c(x)
+        acc = self._tmp(1)
+        self.k.reduce_all(_R[op], 0, xf.data_ptr(), acc.data_ptr(),
+                          xf.numel(), self._s())
+        return acc
+
+    def sum_all(self, x, out):
+        acc = self._reduce_all("sum", x)
+        self.copy(acc.reshape(out.shape), out)
+
+    def asum(self, x):
+        return float(self._reduce_all("asum", x).item())
+
+    def nrm2(self, x):
+        return float(self._reduce_all("sumsq", x).item()) ** 0.5
+
+    def sum_float(self, x):
+        return float(self._reduce_all("sum", x).item())
+
+    def _rows(self, op, x2d, out_flat):
+        """reduce each row of a contiguous 2-d tensor"""
+        rows, cols = x2d.shape
+        if out_flat.dtype != x2d.dtype or not out_flat.is_contiguous():
+            tmp = torch.empty(rows, dtype=x2d.dtype, device=x2d.device)
+            self.k.reduce_rows(_R[op], _code(x2d), x2d.data_ptr(),
+                               tmp.data_ptr(), rows, cols, self._s())
+            self.copy(tmp, out_flat)
+        else:
+            self.k.reduce_rows(_R[op], _code(x2d), x2d.data_ptr(),
+                               out_flat.data_ptr(), rows, cols, self._s())
+
+    def _contig(self, x):
+        if x.is_contiguous():
+            return x
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+        self._unary(_U["copy"], x, out)
+        return out
+
+    def sum_axis(self, x, axis, out):
+        x = self._contig(x)
+        rows, cols = x.shape
+        o = out.reshape(-1)
+        if axis == 1:
+            self._rows("sum", x, o)
+            return
+        xf = self._f32c(x)
+        if o.dtype == torch.float32 and o.is_contiguous():
+            self.k.reduce_cols(0, xf.data_ptr(), o.data_ptr(), rows, cols,
+                               self._s())
+        else:
+            tmp = self._tmp(cols)
+            self.k.reduce_cols(0, xf.data_ptr(), tmp.data_ptr(), rows, cols,
+                               self._s())
+            self.copy(tmp, o)
+
+    def row_max(self, x, out):
+        self._rows("max", self._contig(x), out.reshape(-1))
+
+    def reduce(self, op, x, axes, out_flat):
+        nd = x.dim()
+        axes = sorted(axes)
+        kept = [i for i in range(nd) if i not in axes]
+        rows = 1
+        for i in kept:
+            rows *= x.shape[i]
+        cols = 1
+        for i in axes:
+            cols *= x.shape[i]
+        o = out_flat[:rows]
+        if axes == list(range(nd - len(axes), nd)):
+            x2 = self._contig(x).reshape(rows, cols)
+            self._rows(op, x2, o)
+        elif op in ("sum", "mean") and axes == list(range(len(axes))):
+            # leading axes: column sums of the (cols, rows) matrix
+            x2 = self._f32c(x).reshape(cols, rows)
+            tmp = o if (o.dtype == torch.float32 and o.is_contiguous()) \
+                else self._tmp(rows)
+            self.k.reduce_cols(0, x2.data_ptr(), tmp.data_ptr(), cols, rows,
+                               self._s())
+            if op == "mean":
+                self._unary(_U["mul_s"], tmp, tmp, 1.0 / cols)
+            if tmp is not o:
+                self.copy(tmp, o)
+        else:
+            xp = x.permute(kept + axes)
+            x2 = torch.empty(xp.shape, dtype=x.dtype, device=x.device)
+            self._unary(_U["copy"], xp, x2)
+            self._rows(op, x2.reshape(rows, cols), o)
+
+    # ---- linear algebra -------------------------------------------------------------------
+    def _mat(self, t):
+        """2-d / 3-d view usable by the GEMM kernel (unit stride in one of
+        the two matrix dims is not required; anything goes)."""
+        return t
+
+    def gemm(self, alpha, a, b, beta, c, bias=None, act=0):
+        if a.dim() == 2:
+            M, K = a.shape
+            N = b.shape[1]
+            batch = 1
+            a_bs = b_bs = c_bs = 0
+            a_rs, a_cs = a.stride()
+            b_rs, b_cs = b.stride()
+        else:
+            batch, M, K = a.shape
+            N = b.shape[2]
+            if b.shape[0] != batch:
+                b = b.expand(batch, b.shape[1], b.shape[2])
+            a_bs, a_rs, a_cs = a.stride()
+            b_bs, b_rs, b_cs = b.stride()
+            if not c.is_contiguous():
+                raise ValueError("GEMM output must be contiguous")
+            c_bs = c.stride()[0]
+        if c.stride()[-1] != 1:
+            raise ValueError("GEMM output must be row-major")
+        ldc = c.stride()[-2] if c.dim() >= 2 else N
+        self.k.gemm(_code(c), M, N, K, float(alpha), a.data_ptr(), a_rs, a_cs,
+                    a_bs, b.data_ptr(), b_rs, b_cs, b_bs, float(beta),
+                    c.data_ptr(), ldc, c_bs, batch,
+                    bias.data_ptr() if bias is not None else 0, act, self._s())
+
+    def gemv(self, alpha, a, v, beta, out):
+        self.gemm(alpha, a, v.reshape(-1, 1), beta, out.reshape(-1, 1))
+
+    def dgmm_rows(self, m, v, out):
+        self.binary("mul", m, v.reshape(1, -1), out)
+
+    def dgmm_cols(self, m, v, out):
+        self.binary("mul", m, v.reshape(-1, 1), out)
+
+    # ---- softmax / losses ---------------------------------------------------------------------
+    def softmax(self, x, out):
+        x = self._contig(x)
+        self.k.softmax_fwd(_code(x), x.data_ptr(), out.data_ptr(), x.shape[0],
+                           x.shape[1], self._s())
+
+    def softmax_bwd(self, dy, y, dx):
+        dy, y = self._contig(dy), self._contig(y)
+        self.k.softmax_bwd(_code(y), dy.data_ptr(), y.data_ptr(),
+                           dx.data_ptr(), y.shape[0], y.shape[1], self._s())
+
+    def _target(self, t, batch):
+        t = self._contig(t)
+        is_int = 1 if t.numel() == batch else 0
+        return t, is_int, _code(t)
+
+    def cross_entropy_fwd(self, p, t, loss):
+        p = self._contig(p)
+        t, is_int, tc = self._target(t, p.shape[0])
+        self.k.cross_entropy_fwd(_code(p), p.data_ptr(), t.data_ptr(), is_int,
+                                 tc, loss.data_ptr(), p.shape[0], p.shape[1],
+                                 self._s())
+
+    def softmax_ce_bwd(self, p, t):
+        t, is_int, tc = self._target(t, p.shape[0])
+        self.k.softmax_ce_bwd(_code(p), p.data_ptr(), t.data_ptr(), is_int, tc,
+                              p.shape[0], p.shape[1], self._s())
+
+    def softmax_ce_fused_fwd(self, x, t, p, loss):
+        x = self._contig(x)
+        t, is_int, tc = self._target(t, x.shape[0])
+        if x.dtype == torch.float32:
+            self.k.softmax_ce_fused_fwd(0, x.data_ptr(), t.data_ptr(), is_int,
+                                        tc, p.data_ptr(), loss.data_ptr(),
+                                        x.shape[0], x.shape[1], self._s())
+            return
+        # 16-bit logits: soft-max in the tensor dtype, loss reduced in float32
+        self.softmax(x, p)
+        per = torch.empty(x.shape[0], dtype=x.dtype, device=x.device)
+        self.cross_entropy_fwd(p, t, per)
+        acc = self._reduce_all("sum", per)
+        self._unary(_U["mul_s"], acc, loss.reshape(1), 1.0 / x.shape[0])
+
+    def softmax_ce_fused_bwd(self, p, t, dx):
+        t, is_int, tc = self._target(t, p.shape[0])
+        self.k.softmax_ce_fused_bwd(_code(p), p.data_ptr(), t.data_ptr(),
+                                    is_int, tc, dx.data_ptr(), p.shape[0],
+                                    p.shape[1], self._s())
+
+    # ---- convolution ---------------------------------------------------------------------------
+    def _geom(self, xshape, wshape, yshape, stride, pad, groups):
+        N, C, H, W = xshape
+        K, _, R, S = wshape
+        return self.k.ConvGeom(N, C, H, W, K, R, S, yshape[2], yshape[3],
+                               stride[0], stride[1], pad[0], pad[1], groups)
+
+    def conv_fwd(self, x, w, b, y, stride, pad, groups):
+        g = self._geom(x.shape, w.shape, y.shape, stride, pad, groups)
+        w = self._contig(w)
+        self.k.conv_fwd(_code(x), g, x.data_ptr(), w.data_ptr(),
+                        b.data_ptr() if b is not None else 0, y.data_ptr(),
+                        self._s())
+
+    def conv_bwd_data(self, dy, w, dx, stride, pad, groups):
+        g = self._geom(dx.shape, w.shape, dy.shape, stride, pad, groups)
+        w = self._contig(w)
+        self.k.conv_bwd_data(_code(dx), g, dy.data_ptr(), w.data_ptr(),
+                             dx.data_ptr(), self._s())
+
+    def conv_bwd_weight(self, dy, x, dw, stride, pad, groups):
+        g = self._geom(x.shape, dw.shape, dy.shape, stride, pad, groups)
+        if dw.dtype == torch.float32:
+            self.k.conv_bwd_weight(0, g, dy.data_ptr(), x.data_ptr(),
+                                   dw.data_ptr(), self._s())
+        else:
+            acc = torch.empty(dw.shape, dtype=torch.float32, device=dw.device)
+            self.k.conv_bwd_weight(0, g, self._f32c(dy).data_ptr(),
+                                   self._f32c(x).data_ptr(), acc.data_ptr(),
+                                   self._s())
+            self.copy(acc, dw)
+
+    def conv_bwd_bias(self, dy, db):
+        N, K = dy.shape[0], dy.shape[1]
+        PQ = dy.shape[2] * dy.shape[3]
+        self.k.conv_bwd_bias(_code(dy), dy.data_ptr(), db.data_ptr(), N, K, PQ,
+                             self._s())
+
+    # ---- batch norm ---------------------------------------------------------------------------------
+    @staticmethod
+    def _nchw(x):
+        N, C = x.shape[0], x.shape[1]
+        HW = 1
+        for s in x.shape[2:]:
+            HW *= s
+        return N, C, HW
+
+    def _f32(self, t):
+        return t if t.dtype == torch.float32 else self._cast(t, torch.float32)
+
+    def bn_fwd_train(self, x, scale, bias, rmean, rvar, factor, eps, y, mean,
+                     invstd):
+        N, C, HW = self._nchw(x)
+        work = self._tmp(self.k.bn_workspace(N, C, HW))
+        sc, bi = self._f32(scale), self._f32(bias)
+        rm, rv = self._f32(rmean), self._f32(rvar)
+        self.k.bn_fwd_train(_code(x), x.data_ptr(), sc.data_ptr(),
+                            bi.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                            float(factor), float(eps), y.data_ptr(),
+                            mean.data_ptr(), invstd.data_ptr(), N, C, HW,
+                            work.data_ptr(), self._s())
+        if rm is not rmean:
+            self.copy(rm, rmean)
+            self.copy(rv, rvar)
+
+    def bn_fwd_infer(self, x, scale, bias, rmean, rvar, eps, y):
+        N, C, HW = self._nchw(x)
+        self.k.bn_fwd_infer(_code(x), x.data_ptr(),
+                            self._f32(scale).data_ptr(),
+                            self._f32(bias).data_ptr(),
+                            self._f32(rmean).data_ptr(),
+                            self._f32(rvar).data_ptr(), float(eps),
+                            y.data_ptr(), N, C, HW, self._s())
+
+    def bn_bwd(self, dy, x, scale, mean, invstd, dx, dscale, dbias):
+        N, C, HW = self._nchw(x)
+        work = self._tmp(self.k.bn_workspace(N, C, HW))
+        ds = dscale if dscale.dtype == torch.float32 else self._tmp(C)
+        db = dbias if dbias.dtype == torch.float32 else self._tmp(C)
+        self.k.bn_bwd(_code(x), dy.data_ptr(), x.data_ptr(),
+                      self._f32(scale).data_ptr(), mean.data_ptr(),
+                      invstd.data_ptr(), dx.data_ptr(), ds.data_ptr(),
+                      db.data_ptr(), N, C, HW, work.data_ptr(), self._s())
+        if ds is not dscale:
+            self.copy(ds, dscale)
+            self.copy(db, dbias)
+
+    # ---- pooling ---------------------------------------------------------------------------------------
+    def _pgeom(self, x, y, kernel, stride, pad, is_max):
+        return self.k.PoolGeom(x.shape[0], x.shape[1], x.shape[2], x.shape[3],
+                               y.shape[2], y.shape[3], kernel[0], kernel[1],
+                               stride[0], stride[1], pad[0], pad[1],
+                               1 if is_max else 0)
+
+    def pool_fwd(self, x, y, kernel, stride, pad, is_max):
+        g = self._pgeom(x, y, kernel, stride, pad, is_max)
+        self.k.pool_fwd(_code(x), g, x.data_ptr(), y.data_ptr(), self._s())
+
+    def pool_bwd(self, dy, x, y, dx, kernel, stride, pad, is_max):
+        g = self._pgeom(x, y, kernel, stride, pad, is_max)
+        y = self._contig(y)
+        self.k.pool_bwd(_code(x), g, dy.data_ptr(), x.data_ptr(), y.data_ptr(),
+                        dx.data_ptr(), self._s())
+
+    # ---- index / gather -------------------------------------------------------------------------------------
+    def _idx(self, idx):
+        idx = self._contig(idx.reshape(-1))
+        if idx.dtype != torch.int32:
+            idx = self._cast(idx, torch.int32)
+        return idx
+
+    def index_select(self, x, axis, idx, out):
+        idx = self._idx(idx)
+        outer = 1
+        for s in x.shape[:axis]:
+            outer *= s
+        inner = 1
+        for s in x.shape[axis + 1:]:
+            inner *= s
+        self.k.index_select(_code(x), x.data_ptr(), idx.data_ptr(),
+                            out.data_ptr(), outer, x.shape[axis], idx.numel(),
+                            inner, self._s())
+
+    def index_add(self, dy, axis, idx, out):
+        idx = self._idx(idx)
+        outer = 1
+        for s in out.shape[:axis]:
+            outer *= s
+        inner = 1
+        for s in out.shape[axis + 1:]:
+            inner *= s
+        d = self._f32c(dy)
+        tgt = out if out.dtype == torch.float32 else \
+            torch.empty(out.shape, dtype=torch.float32, device=out.device)
+        self.k.index_add(0, d.data_ptr(), idx.data_ptr(), tgt.data_ptr(), outer,
+                         out.shape[axis], idx.numel(), inner, self._s())
+        if tgt is not out:
+            self.copy(tgt, out)
+
+    def gather_rows(self, table, idx, out):
+        self.index_select(table, 0, idx, out.reshape(-1, table.shape[1]))
+
+    def scatter_add_rows(self, grad, idx, dtable):
+        self.index_add(grad.reshape(-1, dtable.shape[1]), 0, idx, dtable)
+
+    # ---- fused optimiser step -------------------------------------------------------------------------------------
+    def sgd_update(self, p, g, buf, lr, momentum, dampening, weight_decay,
+                   nesterov, scale):
+        g = self._contig(g)
+        if g.dtype != p.dtype:
+            g = self._cast(g, p.dtype)
+        self.k.sgd_update(_code(p), p.data_ptr(), g.data_ptr(),
+                          buf.data_ptr() if buf is not None else 0,
+                          self._f32(lr).data_ptr(),
+                          self._f32(momentum).data_ptr(),
+                          self._f32(dampening).data_ptr(),
+                          self._f32(weight_decay).data_ptr(),
+                          1 if nesterov else 0, float(scale), p.numel(),
+                          self._s())
+
+    # ---- recurrent cells ---------------------------------------------------------------------------------------------
+    def lstm_cell_fwd(self, gates, c_prev, c, h, acts):
+        self.k.lstm_cell_fwd(_code(gates), gates.data_ptr(), c_prev.data_ptr(),
+                             c.data_ptr(), h.data_ptr(), acts.data_ptr(),
+                             c_prev.shape[0], c_prev.shape[1], self._s())
+
+    def lstm_cell_bwd(self, dh, dc_next, acts, c_prev, c, dgates, dc_prev):
+        self.k.lstm_cell_bwd(_code(acts), dh.data_ptr(), dc_next.data_ptr(),
+                             acts.data_ptr(), c_prev.data_ptr(), c.data_ptr(),
+                             dgates.data_ptr(), dc_prev.data_ptr(),
+                             c_prev.shape[0], c_prev.shape[1], self._s())

@@ -976,17 +976,26 @@ def _repeat(t, repeats, axis):
             else int(sum(repeats))
         src = t
     out = Tensor(shape, t._dev, t._dtype)
-    reps = repeats[0] if len(repeats) == 1 else list(repeats)
+    if len(repeats) == 1:
+        reps = int(repeats[0])
 
-    def body(s, o):
-        v = s.view()
-        if isinstance(reps, int):
-            r = torch.repeat_interleave(v, reps, dim=ax)
-        else:
-            r = torch.repeat_interleave(
-                v, torch.tensor(reps, device=v.device), dim=ax)
-        o._dev.math.copy(r, o.view())
-    _submit(t._dev, "Repeat", body, [src], [out])
+        def body(s, o):
+            # out[..., i * reps + j, ...] = src[..., i, ...]: one strided copy
+            v = s.view()
+            shp = list(v.shape)
+            ov = o.view().view(shp[:ax] + [shp[ax], reps] + shp[ax + 1:])
+            o._dev.math.copy(v.unsqueeze(ax + 1).expand(ov.shape), ov)
+        _submit(t._dev, "Repeat", body, [src], [out])
+        return out
+    # per-element repeat counts: gather through a host-built index map
+    idx_np = np.repeat(np.arange(src._shape[ax], dtype=np.int32),
+                       np.asarray(repeats, dtype=np.int64))
+    idx = Tensor([idx_np.size], t._dev, kInt)
+    idx.CopyIntDataFromHostPtr(idx_np)
+    _submit(t._dev, "Repeat",
+            lambda s, ix, o: s._dev.math.index_select(
+                s.view(), ax, ix.view(), o.view()),
+            [src if src.is_contiguous() else Contiguous(src), idx], [out])
     return out
 
 

@@ -1,0 +1,324 @@
+// pybind11 surface of the HIP kernels.  Device buffers arrive as integer
+// addresses (torch ``data_ptr()``), the stream as the integer handle of the
+// current torch HIP stream.  Every wrapper checks the launcher's status code
+// and raises, so an unsupported dtype can never silently do nothing.
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace py = pybind11;
+using sa::Desc;
+
+namespace {
+
+inline void *P(uintptr_t p) { return reinterpret_cast<void *>(p); }
+inline const void *CP(uintptr_t p) { return reinterpret_cast<const void *>(p); }
+inline hipStream_t S(uintptr_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+void check(int rc, const char *what) {
+  if (rc != 0)
+    throw std::runtime_error(std::string(what) + ": launcher returned " +
+                             std::to_string(rc) +
+                             " (-1 dtype, -2 alignment/size, -3 needs float32)");
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess)
+    throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+Desc make_desc(const std::vector<int64_t> &shape,
+               const std::vector<int64_t> &s0, const std::vector<int64_t> &s1,
+               const std::vector<int64_t> &s2) {
+  Desc d;
+  if (shape.size() > 8) throw std::runtime_error("more than 8 dimensions");
+  d.ndim = static_cast<int>(shape.size());
+  for (int i = 0; i < 8; ++i) {
+    d.shape[i] = i < d.ndim ? shape[i] : 1;
+    d.s0[i] = i < (int)s0.size() ? s0[i] : 0;
+    d.s1[i] = i < (int)s1.size() ? s1[i] : 0;
+    d.s2[i] = i < (int)s2.size() ? s2[i] : 0;
+  }
+  return d;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_hip, m) {
+  m.doc() = "singa_amd HIP kernels for gfx950";
+  m.attr("arch") = "gfx950";
+
+  // ---- element-wise -------------------------------------------------------
+  m.def("unary_contig", [](int op, int dt_in, int dt_out, uintptr_t x,
+                           uintptr_t y, int64_t n, float a, float b,
+                           uintptr_t s) {
+    check(sa_unary(op, dt_in, dt_out, CP(x), P(y), nullptr, n, a, b, S(s)),
+          "unary");
+  });
+  m.def("unary_strided", [](int op, int dt_in, int dt_out, uintptr_t x,
+                            uintptr_t y, std::vector<int64_t> shape,
+                            std::vector<int64_t> sx, std::vector<int64_t> sy,
+                            int64_t n, float a, float b, uintptr_t s) {
+    Desc d = make_desc(shape, sx, {}, sy);
+    check(sa_unary(op, dt_in, dt_out, CP(x), P(y), &d, n, a, b, S(s)),
+          "unary_strided");
+  });
+  m.def("binary_contig", [](int op, int dt, uintptr_t x, uintptr_t y,
+                            uintptr_t z, int64_t n, uintptr_t s) {
+    check(sa_binary(op, dt, CP(x), CP(y), P(z), nullptr, n, S(s)), "binary");
+  });
+  m.def("binary_strided", [](int op, int dt, uintptr_t x, uintptr_t y,
+                             uintptr_t z, std::vector<int64_t> shape,
+                             std::vector<int64_t> sx, std::vector<int64_t> sy,
+                             std::vector<int64_t> sz, int64_t n, uintptr_t s) {
+    Desc d = make_desc(shape, sx, sy, sz);
+    check(sa_binary(op, dt, CP(x), CP(y), P(z), &d, n, S(s)),
+          "binary_strided");
+  });
+  m.def("fill", [](int dt, uintptr_t y, int64_t n, float v, uintptr_t s) {
+    check(sa_fill(dt, P(y), n, v, S(s)), "fill");
+  });
+  m.def("axpy", [](int dt, uintptr_t alpha_ptr, float alpha, uintptr_t x,
+                   uintptr_t y, int64_t n, uintptr_t s) {
+    check(sa_axpy(dt, (const float *)CP(alpha_ptr), alpha, CP(x), P(y), n,
+                  S(s)),
+          "axpy");
+  });
+
+  // ---- reductions ---------------------------------------------------------
+  m.def("reduce_rows", [](int op, int dt, uintptr_t x, uintptr_t out,
+                          int64_t rows, int64_t cols, uintptr_t s) {
+    check(sa_reduce_rows(op, dt, CP(x), P(out), rows, cols, S(s)),
+          "reduce_rows");
+  });
+  m.def("reduce_cols", [](int dt, uintptr_t x, uintptr_t out, int64_t rows,
+                          int64_t cols, uintptr_t s) {
+    check(sa_reduce_cols(dt, CP(x), P(out), rows, cols, S(s)), "reduce_cols");
+  });
+  m.def("reduce_all", [](int op, int dt, uintptr_t x, uintptr_t out, int64_t n,
+                         uintptr_t s) {
+    check(sa_reduce_all(op, dt, CP(x), P(out), n, S(s)), "reduce_all");
+  });
+
+  // ---- softmax / losses -----------------------------------------------------
+  m.def("softmax_fwd", [](int dt, uintptr_t x, uintptr_t y, int64_t rows,
+                          int64_t cols, uintptr_t s) {
+    check(sa_softmax_fwd(dt, CP(x), P(y), rows, cols, S(s)), "softmax_fwd");
+  });
+  m.def("softmax_bwd", [](int dt, uintptr_t dy, uintptr_t y, uintptr_t dx,
+                          int64_t rows, int64_t cols, uintptr_t s) {
+    check(sa_softmax_bwd(dt, CP(dy), CP(y), P(dx), rows, cols, S(s)),
+          "softmax_bwd");
+  });
+  m.def("cross_entropy_fwd", [](int dt, uintptr_t p, uintptr_t t, int t_is_int,
+                                int t_dt, uintptr_t loss, int64_t rows,
+                                int64_t cols, uintptr_t s) {
+    check(sa_cross_entropy_fwd(dt, CP(p), CP(t), t_is_int, t_dt, P(loss), rows,
+                               cols, S(s)),
+          "cross_entropy_fwd");
+  });
+  m.def("softmax_ce_bwd", [](int dt, uintptr_t p, uintptr_t t, int t_is_int,
+                             int t_dt, int64_t rows, int64_t cols,
+                             uintptr_t s) {
+    check(sa_softmax_ce_bwd(dt, P(p), CP(t), t_is_int, t_dt, rows, cols, S(s)),
+          "softmax_ce_bwd");
+  });
+  m.def("softmax_ce_fused_fwd", [](int dt, uintptr_t x, uintptr_t t,
+                                   int t_is_int, int t_dt, uintptr_t p,
+                                   uintptr_t loss, int64_t rows, int64_t cols,
+                                   uintptr_t s) {
+    check(sa_softmax_ce_fused_fwd(dt, CP(x), CP(t), t_is_int, t_dt, P(p),
+                                  P(loss), rows, cols, S(s)),
+          "softmax_ce_fused_fwd");
+  });
+  m.def("softmax_ce_fused_bwd", [](int dt, uintptr_t p, uintptr_t t,
+                                   int t_is_int, int t_dt, uintptr_t dx,
+                                   int64_t rows, int64_t cols, uintptr_t s) {
+    check(sa_softmax_ce_fused_bwd(dt, CP(p), CP(t), t_is_int, t_dt, P(dx), rows,
+                                  cols, S(s)),
+          "softmax_ce_fused_bwd");
+  });
+
+  // ---- random -----------------------------------------------------------------
+  m.def("rng_uniform", [](int dt, uintptr_t y, int64_t n, float lo, float hi,
+                          uintptr_t state, uintptr_t s) {
+    check(sa_rng_uniform(dt, P(y), n, lo, hi, (int64_t *)P(state), S(s)),
+          "rng_uniform");
+  });
+  m.def("rng_normal", [](int dt, uintptr_t y, int64_t n, float mean, float sd,
+                         uintptr_t state, uintptr_t s) {
+    check(sa_rng_normal(dt, P(y), n, mean, sd, (int64_t *)P(state), S(s)),
+          "rng_normal");
+  });
+  m.def("rng_bernoulli", [](int dt, uintptr_t y, int64_t n, float p,
+                            uintptr_t state, uintptr_t s) {
+    check(sa_rng_bernoulli(dt, P(y), n, p, (int64_t *)P(state), S(s)),
+          "rng_bernoulli");
+  });
+
+  // ---- gemm ---------------------------------------------------------------------
+  m.def("gemm", [](int dt, int64_t M, int64_t N, int64_t K, float alpha,
+                   uintptr_t A, int64_t a_rs, int64_t a_cs, int64_t a_bs,
+                   uintptr_t B, int64_t b_rs, int64_t b_cs, int64_t b_bs,
+                   float beta, uintptr_t C, int64_t ldc, int64_t c_bs,
+                   int64_t batch, uintptr_t bias, int act, uintptr_t s) {
+    check(sa_gemm(dt, M, N, K, alpha, CP(A), a_rs, a_cs, a_bs, CP(B), b_rs,
+                  b_cs, b_bs, beta, P(C), ldc, c_bs, batch, CP(bias), act,
+                  S(s)),
+          "gemm");
+  });
+
+  // ---- convolution -----------------------------------------------------------------
+  py::class_<ConvGeom>(m, "ConvGeom")
+      .def(py::init([](int N, int C, int H, int W, int K, int R, int Sw, int P_,
+                       int Q, int sh, int sw, int ph, int pw, int groups) {
+        ConvGeom g{N, C, H, W, K, R, Sw, P_, Q, sh, sw, ph, pw, groups};
+        return g;
+      }))
+      .def_readwrite("N", &ConvGeom::N);
+  m.def("conv_fwd", [](int dt, const ConvGeom &g, uintptr_t x, uintptr_t w,
+                       uintptr_t bias, uintptr_t y, uintptr_t s) {
+    check(sa_conv_fwd(dt, &g, CP(x), CP(w), CP(bias), P(y), S(s)), "conv_fwd");
+  });
+  m.def("conv_bwd_data", [](int dt, const ConvGeom &g, uintptr_t dy,
+                            uintptr_t w, uintptr_t dx, uintptr_t s) {
+    check(sa_conv_bwd_data(dt, &g, CP(dy), CP(w), P(dx), S(s)),
+          "conv_bwd_data");
+  });
+  m.def("conv_bwd_weight", [](int dt, const ConvGeom &g, uintptr_t dy,
+                              uintptr_t x, uintptr_t dw, uintptr_t s) {
+    check(sa_conv_bwd_weight(dt, &g, CP(dy), CP(x), P(dw), S(s)),
+          "conv_bwd_weight");
+  });
+  m.def("conv_bwd_bias", [](int dt, uintptr_t dy, uintptr_t db, int N, int K,
+                            int PQ, uintptr_t s) {
+    check(sa_conv_bwd_bias(dt, CP(dy), P(db), N, K, PQ, S(s)),
+          "conv_bwd_bias");
+  });
+
+  // ---- batch norm ---------------------------------------------------------------------
+  m.def("bn_workspace", &sa_bn_workspace);
+  m.def("bn_fwd_train", [](int dt, uintptr_t x, uintptr_t scale, uintptr_t bias,
+                           uintptr_t rmean, uintptr_t rvar, float factor,
+                           float eps, uintptr_t y, uintptr_t mean,
+                           uintptr_t invstd, int N, int C, int HW,
+                           uintptr_t work, uintptr_t s) {
+    check(sa_bn_fwd_train(dt, CP(x), (const float *)CP(scale),
+                          (const float *)CP(bias), (float *)P(rmean),
+                          (float *)P(rvar), factor, eps, P(y), (float *)P(mean),
+                          (float *)P(invstd), N, C, HW, (float *)P(work), S(s)),
+          "bn_fwd_train");
+  });
+  m.def("bn_fwd_infer", [](int dt, uintptr_t x, uintptr_t scale, uintptr_t bias,
+                           uintptr_t rmean, uintptr_t rvar, float eps,
+                           uintptr_t y, int N, int C, int HW, uintptr_t s) {
+    check(sa_bn_fwd_infer(dt, CP(x), (const float *)CP(scale),
+                          (const float *)CP(bias), (const float *)CP(rmean),
+                          (const float *)CP(rvar), eps, P(y), N, C, HW, S(s)),
+          "bn_fwd_infer");
+  });
+  m.def("bn_bwd", [](int dt, uintptr_t dy, uintptr_t x, uintptr_t scale,
+                     uintptr_t mean, uintptr_t invstd, uintptr_t dx,
+                     uintptr_t dscale, uintptr_t dbias, int N, int C, int HW,
+                     uintptr_t work, uintptr_t s) {
+    check(sa_bn_bwd(dt, CP(dy), CP(x), (const float *)CP(scale),
+                    (const float *)CP(mean), (const float *)CP(invstd), P(dx),
+                    (float *)P(dscale), (float *)P(dbias), N, C, HW,
+                    (float *)P(work), S(s)),
+          "bn_bwd");
+  });
+
+  // ---- pooling ----------------------------------------------------------------------------
+  py::class_<PoolGeom>(m, "PoolGeom")
+      .def(py::init([](int N, int C, int H, int W, int P_, int Q, int kh,
+                       int kw, int sh, int sw, int ph, int pw, int is_max) {
+        PoolGeom g{N, C, H, W, P_, Q, kh, kw, sh, sw, ph, pw, is_max};
+        return g;
+      }));
+  m.def("pool_fwd", [](int dt, const PoolGeom &g, uintptr_t x, uintptr_t y,
+                       uintptr_t s) {
+    check(sa_pool_fwd(dt, &g, CP(x), P(y), S(s)), "pool_fwd");
+  });
+  m.def("pool_bwd", [](int dt, const PoolGeom &g, uintptr_t dy, uintptr_t x,
+                       uintptr_t y, uintptr_t dx, uintptr_t s) {
+    check(sa_pool_bwd(dt, &g, CP(dy), CP(x), CP(y), P(dx), S(s)), "pool_bwd");
+  });
+
+  // ---- optimiser ------------------------------------------------------------------------------
+  m.def("sgd_update", [](int dt, uintptr_t p, uintptr_t g, uintptr_t buf,
+                         uintptr_t lr, uintptr_t mom, uintptr_t damp,
+                         uintptr_t wd, int nesterov, float scale, int64_t n,
+                         uintptr_t s) {
+    check(sa_sgd_update(dt, P(p), CP(g), P(buf), (const float *)CP(lr),
+                        (const float *)CP(mom), (const float *)CP(damp),
+                        (const float *)CP(wd), nesterov, scale, n, S(s)),
+          "sgd_update");
+  });
+
+  // ---- index --------------------------------------------------------------------------------------
+  m.def("index_select", [](int dt, uintptr_t x, uintptr_t idx, uintptr_t out,
+                           int64_t outer, int64_t n_in, int64_t n_out,
+                           int64_t inner, uintptr_t s) {
+    check(sa_index_select(dt, CP(x), (const int *)CP(idx), P(out), outer, n_in,
+                          n_out, inner, S(s)),
+          "index_select");
+  });
+  m.def("index_add", [](int dt, uintptr_t dy, uintptr_t idx, uintptr_t out,
+                        int64_t outer, int64_t n_in, int64_t n_out,
+                        int64_t inner, uintptr_t s) {
+    check(sa_index_add(dt, CP(dy), (const int *)CP(idx), P(out), outer, n_in,
+                       n_out, inner, S(s)),
+          "index_add");
+  });
+
+  // ---- recurrent cells --------------------------------------------------------------------------------
+  m.def("lstm_cell_fwd", [](int dt, uintptr_t gates, uintptr_t c_prev,
+                            uintptr_t c, uintptr_t h, uintptr_t acts,
+                            int64_t batch, int64_t hidden, uintptr_t s) {
+    check(sa_lstm_cell_fwd(dt, CP(gates), CP(c_prev), P(c), P(h), P(acts),
+                           batch, hidden, S(s)),
+          "lstm_cell_fwd");
+  });
+  m.def("lstm_cell_bwd", [](int dt, uintptr_t dh, uintptr_t dc_next,
+                            uintptr_t acts, uintptr_t c_prev, uintptr_t c,
+                            uintptr_t dgates, uintptr_t dc_prev, int64_t batch,
+                            int64_t hidden, uintptr_t s) {
+    check(sa_lstm_cell_bwd(dt, CP(dh), CP(dc_next), CP(acts), CP(c_prev),
+                           CP(c), P(dgates), P(dc_prev), batch, hidden, S(s)),
+          "lstm_cell_bwd");
+  });
+
+  // ---- communication helpers ----------------------------------------------------------------------------
+  m.def("pack_entry_size", []() { return sizeof(PackEntry); });
+  m.def("pack", [](int src_dt, int dst_dt, uintptr_t table, int n,
+                   uintptr_t bucket, int64_t total, uintptr_t s) {
+    check(sa_pack(src_dt, dst_dt, (const PackEntry *)CP(table), n, P(bucket),
+                  total, S(s)),
+          "pack");
+  });
+  m.def("unpack", [](int src_dt, int dst_dt, uintptr_t table, int n,
+                     uintptr_t bucket, int64_t total, float scale,
+                     uintptr_t s) {
+    check(sa_unpack(src_dt, dst_dt, (const PackEntry *)CP(table), n, CP(bucket),
+                    total, scale, S(s)),
+          "unpack");
+  });
+  m.def("sparsify_threshold", [](uintptr_t x, float thr, uintptr_t vals,
+                                 uintptr_t idx, uintptr_t count, int64_t n,
+                                 int64_t cap, uintptr_t s) {
+    check(sa_sparsify_threshold((const float *)CP(x), thr, (float *)P(vals),
+                                (int *)P(idx), (int *)P(count), n, cap, S(s)),
+          "sparsify_threshold");
+  });
+  m.def("scatter_add_sparse", [](uintptr_t vals, uintptr_t idx, uintptr_t count,
+                                 int64_t max_count, uintptr_t dense, int64_t n,
+                                 uintptr_t s) {
+    check(sa_scatter_add_sparse((const float *)CP(vals), (const int *)CP(idx),
+                                (const int *)CP(count), max_count,
+                                (float *)P(dense), n, S(s)),
+          "scatter_add_sparse");
+  });
+}

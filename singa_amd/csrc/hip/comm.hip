@@ -1,0 +1,141 @@
+// Kernels around the collectives of data-parallel training.
+//
+// pack / unpack move a whole fusion bucket (dozens of gradient tensors) to and
+// from one flat buffer in a single launch, converting on the fly between the
+// parameter dtype and the wire dtype (fp32 <-> fp16 / bf16 compression) and,
+// on the way back, applying the 1 / world_size scaling.  The reference issues
+// one cudaMemcpy per tensor plus separate conversion kernels
+// (src/io/communicator.cc:225-414).  The sparsification helpers implement
+// threshold selection with stream compaction into fixed-capacity buffers and
+// the scatter-add of gathered (index, value) pairs, all without host syncs.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sa {
+
+// grid.y = tensor index, grid.x strides over that tensor's elements
+template <typename TS, typename TD>
+__global__ void pack_kernel(const PackEntry *__restrict__ table,
+                            TD *__restrict__ bucket) {
+  const PackEntry e = table[blockIdx.y];
+  const TS *src = (const TS *)e.ptr;
+  TD *dst = bucket + e.offset;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e.count;
+       i += step)
+    dst[i] = from_f<TD>(to_f<TS>(src[i]));
+}
+
+template <typename TS, typename TD>
+__global__ void unpack_kernel(const PackEntry *__restrict__ table,
+                              const TS *__restrict__ bucket, float scale) {
+  const PackEntry e = table[blockIdx.y];
+  TD *dst = (TD *)e.ptr;
+  const TS *src = bucket + e.offset;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e.count;
+       i += step)
+    dst[i] = from_f<TD>(to_f<TS>(src[i]) * scale);
+}
+
+// keeps |x| >= thr: appends (index + 1, value) pairs, count is the cursor
+__global__ void sparsify_threshold_kernel(const float *__restrict__ x,
+                                          float thr, float *__restrict__ vals,
+                                          int *__restrict__ idx,
+                                          int *__restrict__ count, int64_t n,
+                                          int64_t cap) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += step) {
+    const float v = x[i];
+    if (fabsf(v) >= thr) {
+      const int slot = atomicAdd(count, 1);
+      if (slot < cap) {
+        vals[slot] = v;
+        idx[slot] = (int)i;
+      }
+    }
+  }
+}
+
+__global__ void scatter_add_sparse_kernel(const float *__restrict__ vals,
+                                          const int *__restrict__ idx,
+                                          const int *__restrict__ count,
+                                          int64_t max_count,
+                                          float *__restrict__ dense,
+                                          int64_t n) {
+  int64_t c = count ? (int64_t)count[0] : max_count;
+  if (c > max_count) c = max_count;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < c;
+       i += step) {
+    const int j = idx[i];
+    if (j >= 0 && j < n) atomicAdd(dense + j, vals[i]);
+  }
+}
+
+template <typename TS, typename TD>
+int launch_pack(const PackEntry *table, int nt, void *bucket, int64_t total,
+                hipStream_t s) {
+  int64_t per = (total + nt - 1) / nt;
+  int gx = (int)i64min(i64max((per + 1023) / 1024, 1), 64);
+  hipLaunchKernelGGL((pack_kernel<TS, TD>), dim3(gx, nt), dim3(256), 0, s,
+                     table, (TD *)bucket);
+  return 0;
+}
+
+template <typename TS, typename TD>
+int launch_unpack(const PackEntry *table, int nt, const void *bucket,
+                  int64_t total, float scale, hipStream_t s) {
+  int64_t per = (total + nt - 1) / nt;
+  int gx = (int)i64min(i64max((per + 1023) / 1024, 1), 64);
+  hipLaunchKernelGGL((unpack_kernel<TS, TD>), dim3(gx, nt), dim3(256), 0, s,
+                     table, (const TS *)bucket, scale);
+  return 0;
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+#define PAIR_DISPATCH(FN, ...)                                              \
+  if (src_dtype == kF32 && dst_dtype == kF32) return FN<float, float>(__VA_ARGS__); \
+  if (src_dtype == kF32 && dst_dtype == kF16) return FN<float, __half>(__VA_ARGS__); \
+  if (src_dtype == kF16 && dst_dtype == kF32) return FN<__half, float>(__VA_ARGS__); \
+  if (src_dtype == kF32 && dst_dtype == kBF16) return FN<float, __hip_bfloat16>(__VA_ARGS__); \
+  if (src_dtype == kBF16 && dst_dtype == kF32) return FN<__hip_bfloat16, float>(__VA_ARGS__); \
+  if (src_dtype == kF16 && dst_dtype == kF16) return FN<__half, __half>(__VA_ARGS__); \
+  if (src_dtype == kBF16 && dst_dtype == kBF16) return FN<__hip_bfloat16, __hip_bfloat16>(__VA_ARGS__); \
+  return -1;
+
+int sa_pack(int src_dtype, int dst_dtype, const PackEntry *table,
+            int n_tensors, void *bucket, int64_t total, hipStream_t s) {
+  if (n_tensors <= 0) return 0;
+  PAIR_DISPATCH(launch_pack, table, n_tensors, bucket, total, s)
+}
+
+int sa_unpack(int src_dtype, int dst_dtype, const PackEntry *table,
+              int n_tensors, const void *bucket, int64_t total, float scale,
+              hipStream_t s) {
+  if (n_tensors <= 0) return 0;
+  PAIR_DISPATCH(launch_unpack, table, n_tensors, bucket, total, scale, s)
+}
+
+int sa_sparsify_threshold(const float *x, float thr, float *vals, int *idx,
+                          int *count, int64_t n, int64_t cap, hipStream_t s) {
+  hipMemsetAsync(count, 0, sizeof(int), s);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sparsify_threshold_kernel, dim3(grid_for(n, 256, 4)),
+                     dim3(256), 0, s, x, thr, vals, idx, count, n, cap);
+  return 0;
+}
+
+int sa_scatter_add_sparse(const float *vals, const int *idx, const int *count,
+                          int64_t max_count, float *dense, int64_t n,
+                          hipStream_t s) {
+  if (max_count <= 0) return 0;
+  hipLaunchKernelGGL(scatter_add_sparse_kernel,
+                     dim3(grid_for(max_count, 256)), dim3(256), 0, s, vals,
+                     idx, count, max_count, dense, n);
+  return 0;
+}

@@ -1,0 +1,486 @@
+// GEMM on the CDNA4 matrix cores.
+//
+//   C[b] = act(alpha * A[b] * B[b] + beta * C[b] + bias)
+//
+// float32 uses v_mfma_f32_32x32x2_f32 (exact f32 products and accumulation, the
+// only f32 matrix path on gfx950); fp16 / bf16 use v_mfma_f32_32x32x16_{f16,
+// bf16} with float accumulation.  Operands are described by element strides,
+// so transposed views produced by autograd (x^T, W^T) are consumed directly.
+//
+// Block = 256 threads = 4 waves in a 2 x 2 arrangement; tile BM x BN x BK
+// with BM, BN in {64, 128}.  A and B tiles are staged global -> registers ->
+// LDS; the loads of tile t+1 are issued before the MFMAs of tile t so their
+// latency hides under matrix work.  For f32 both LDS tiles are k-major
+// ([k][m], [k][n]) because the 32x32x2 operand layout wants lane = row index
+// for a fixed k, which makes every ds_read_b32 conflict free.  For 16-bit
+// types the tiles are [m][k] / [n][k] with k contiguous (8 values per lane).
+//
+// Replaces cublasSgemm / cublasHgemm / cublasSgemmStridedBatched / cublasSgemv
+// of the reference (tensor_math_cuda.h:1129-1272).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sa {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f16x8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+
+enum { LD_GENERIC = 0, LD_VEC_K = 1, LD_VEC_MN = 2 };
+
+struct GemmArgs {
+  int64_t M, N, K;
+  float alpha, beta;
+  const void *A;
+  int64_t a_rs, a_cs, a_bs;
+  const void *B;
+  int64_t b_rs, b_cs, b_bs;
+  void *C;
+  int64_t ldc, c_bs;
+  const void *bias;
+  int act;  // 0 none, 1 relu
+};
+
+// ---------------------------------------------------------------------------
+// float32
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int AMODE, int BMODE>
+__global__ void __launch_bounds__(256)
+gemm_f32_kernel(GemmArgs g) {
+  constexpr int BK = 16;
+  constexpr int WM = BM / 2, WN = BN / 2;  // per-wave tile
+  constexpr int TM = WM / 32, TN = WN / 32;  // 32x32 MFMA blocks per wave
+  constexpr int LDA = BM + 4, LDB = BN + 4;  // keep 16-byte row alignment
+  constexpr int A_PER = BM * BK / 256, B_PER = BN * BK / 256;
+  __shared__ __attribute__((aligned(16))) float As[BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const float *A = (const float *)g.A + (int64_t)blockIdx.z * g.a_bs;
+  const float *B = (const float *)g.B + (int64_t)blockIdx.z * g.b_bs;
+  float *C = (float *)g.C + (int64_t)blockIdx.z * g.c_bs;
+
+  float ra[A_PER], rb[B_PER];
+
+  auto load_tiles = [&](int64_t k0) {
+    // ---- A tile: BM x BK ----
+    if (AMODE == LD_VEC_K) {
+      // float4 along k; thread -> (m, k quad)
+#pragma unroll
+      for (int j = 0; j < A_PER / 4; ++j) {
+        const int e = tid + 256 * j;
+        const int m = e % BM, kq = e / BM;
+        const int64_t gm = m0 + m, gk = k0 + 4 * kq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gm < g.M && gk < g.K)
+          v = *reinterpret_cast<const float4 *>(A + gm * g.a_rs + gk);
+        ra[4 * j + 0] = v.x; ra[4 * j + 1] = v.y;
+        ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
+      }
+    } else if (AMODE == LD_VEC_MN) {
+      // float4 along m; thread -> (m quad, k)
+#pragma unroll
+      for (int j = 0; j < A_PER / 4; ++j) {
+        const int e = tid + 256 * j;
+        const int mq = e % (BM / 4), k = e / (BM / 4);
+        const int64_t gm = m0 + 4 * mq, gk = k0 + k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gm < g.M && gk < g.K)
+          v = *reinterpret_cast<const float4 *>(A + gk * g.a_cs + gm);
+        ra[4 * j + 0] = v.x; ra[4 * j + 1] = v.y;
+        ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j) {
+        const int e = tid + 256 * j;
+        const int m = e % BM, k = e / BM;
+        const int64_t gm = m0 + m, gk = k0 + k;
+        ra[j] = (gm < g.M && gk < g.K) ? A[gm * g.a_rs + gk * g.a_cs] : 0.f;
+      }
+    }
+    // ---- B tile: BK x BN ----
+    if (BMODE == LD_VEC_MN) {
+#pragma unroll
+      for (int j = 0; j < B_PER / 4; ++j) {
+        const int e = tid + 256 * j;
+        const int nq = e % (BN / 4), k = e / (BN / 4);
+        const int64_t gn = n0 + 4 * nq, gk = k0 + k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gn < g.N && gk < g.K)
+          v = *reinterpret_cast<const float4 *>(B + gk * g.b_rs + gn);
+        rb[4 * j + 0] = v.x; rb[4 * j + 1] = v.y;
+        rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w;
+      }
+    } else if (BMODE == LD_VEC_K) {
+#pragma unroll
+      for (int j = 0; j < B_PER / 4; ++j) {
+        const int e = tid + 256 * j;
+        const int n = e % BN, kq = e / BN;
+        const int64_t gn = n0 + n, gk = k0 + 4 * kq;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gn < g.N && gk < g.K)
+          v = *reinterpret_cast<const float4 *>(B + gn * g.b_cs + gk);
+        rb[4 * j + 0] = v.x; rb[4 * j + 1] = v.y;
+        rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) {
+        const int e = tid + 256 * j;
+        const int n = e % BN, k = e / BN;
+        const int64_t gn = n0 + n, gk = k0 + k;
+        rb[j] = (gn < g.N && gk < g.K) ? B[gk * g.b_rs + gn * g.b_cs] : 0.f;
+      }
+    }
+  };
+
+  auto store_tiles = [&]() {
+    if (AMODE == LD_VEC_K) {
+#pragma unroll
+      for (int j = 0; j < A_PER / 4; ++j) {
+        const int e = tid + 256 * j;
+        const int m = e % BM, kq = e / BM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) As[(4 * kq + i) * LDA + m] = ra[4 * j + i];
+      }
+    } else if (AMODE == LD_VEC_MN) {
+#pragma unroll
+      for (int j = 0; j < A_PER / 4; ++j) {
+        const int e = tid + 256 * j;
+        const int mq = e % (BM / 4), k = e / (BM / 4);
+        *reinterpret_cast<float4 *>(&As[k * LDA + 4 * mq]) =
+            make_float4(ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < A_PER; ++j) {
+        const int e = tid + 256 * j;
+        As[(e / BM) * LDA + (e % BM)] = ra[j];
+      }
+    }
+    if (BMODE == LD_VEC_MN) {
+#pragma unroll
+      for (int j = 0; j < B_PER / 4; ++j) {
+        const int e = tid + 256 * j;
+        const int nq = e % (BN / 4), k = e / (BN / 4);
+        *reinterpret_cast<float4 *>(&Bs[k * LDB + 4 * nq]) =
+            make_float4(rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]);
+      }
+    } else if (BMODE == LD_VEC_K) {
+#pragma unroll
+      for (int j = 0; j < B_PER / 4; ++j) {
+        const int e = tid + 256 * j;
+        const int n = e % BN, kq = e / BN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Bs[(4 * kq + i) * LDB + n] = rb[4 * j + i];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < B_PER; ++j) {
+        const int e = tid + 256 * j;
+        Bs[(e / BN) * LDB + (e % BN)] = rb[j];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = (int)((g.K + BK - 1) / BK);
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+  const int lrow = lane & 31, lk = lane >> 5;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) load_tiles((int64_t)(t + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = As[(ks + lk) * LDA + wm * WM + 32 * i + lrow];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = Bs[(ks + lk) * LDB + wn * WN + 32 * j + lrow];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j],
+                                                           acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (t + 1 < nt) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  // epilogue: lane holds column (lane & 31); register r holds row
+  // (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) of its 32x32 block
+  const float *bias = (const float *)g.bias;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + wn * WN + 32 * j + (lane & 31);
+      if (col >= g.N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row =
+            m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float v = g.alpha * acc[i][j][r] + bv;
+        float *cp = C + row * g.ldc + col;
+        if (g.beta != 0.f) v += g.beta * (*cp);
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        *cp = v;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fp16 / bf16 (float accumulation)
+// ---------------------------------------------------------------------------
+template <typename T> struct Half16;
+template <> struct Half16<__half> {
+  using frag = f16x8;
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Half16<__hip_bfloat16> {
+  using frag = bf16x8;
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+// A 16-bit tile is kept as [row][k] with BK = 32 values (64 bytes) per row;
+// row r's four 16-byte chunks are rotated by (r >> 1) & 3 so that the 16-byte
+// fragment reads of a wave (32 rows x 2 k-halves) spread over all LDS banks.
+template <typename T, int BM, int BN>
+__global__ void __launch_bounds__(256)
+gemm_h16_kernel(GemmArgs g) {
+  constexpr int BK = 32;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int A_PER = BM * BK / 256, B_PER = BN * BK / 256;
+  using frag = typename Half16<T>::frag;
+  __shared__ __attribute__((aligned(16))) uint16_t As[BM * BK];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * BK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const uint16_t *A = (const uint16_t *)g.A + (int64_t)blockIdx.z * g.a_bs;
+  const uint16_t *B = (const uint16_t *)g.B + (int64_t)blockIdx.z * g.b_bs;
+  T *C = (T *)g.C + (int64_t)blockIdx.z * g.c_bs;
+
+  uint16_t ra[A_PER], rb[B_PER];
+  auto swz = [](int row, int k) {
+    const int chunk = ((k >> 3) + (row >> 1)) & 3;
+    return row * BK + chunk * 8 + (k & 7);
+  };
+  auto load_tiles = [&](int64_t k0) {
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+      const int e = tid + 256 * j;
+      // lanes walk k first when A is k-contiguous, m first otherwise
+      int m, k;
+      if (g.a_cs == 1) { k = e % BK; m = e / BK; }
+      else { m = e % BM; k = e / BM; }
+      const int64_t gm = m0 + m, gk = k0 + k;
+      ra[j] = (gm < g.M && gk < g.K) ? A[gm * g.a_rs + gk * g.a_cs]
+                                     : (uint16_t)0;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+      const int e = tid + 256 * j;
+      int n, k;
+      if (g.b_rs == 1) { k = e % BK; n = e / BK; }
+      else { n = e % BN; k = e / BN; }
+      const int64_t gn = n0 + n, gk = k0 + k;
+      rb[j] = (gn < g.N && gk < g.K) ? B[gk * g.b_rs + gn * g.b_cs]
+                                     : (uint16_t)0;
+    }
+  };
+  auto store_tiles = [&]() {
+#pragma unroll
+    for (int j = 0; j < A_PER; ++j) {
+      const int e = tid + 256 * j;
+      int m, k;
+      if (g.a_cs == 1) { k = e % BK; m = e / BK; }
+      else { m = e % BM; k = e / BM; }
+      As[swz(m, k)] = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < B_PER; ++j) {
+      const int e = tid + 256 * j;
+      int n, k;
+      if (g.b_rs == 1) { k = e % BK; n = e / BK; }
+      else { n = e % BN; k = e / BN; }
+      Bs[swz(n, k)] = rb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = (int)((g.K + BK - 1) / BK);
+  load_tiles(0);
+  store_tiles();
+  __syncthreads();
+  const int lrow = lane & 31, lh = lane >> 5;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) load_tiles((int64_t)(t + 1) * BK);
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 16) {
+      frag a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = wm * WM + 32 * i + lrow;
+        a[i] = *reinterpret_cast<const frag *>(&As[swz(row, ks + 8 * lh)]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int row = wn * WN + 32 * j + lrow;
+        b[j] = *reinterpret_cast<const frag *>(&Bs[swz(row, ks + 8 * lh)]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = Half16<T>::mma(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+    if (t + 1 < nt) {
+      store_tiles();
+      __syncthreads();
+    }
+  }
+
+  const T *bias = (const T *)g.bias;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + wn * WN + 32 * j + (lane & 31);
+      if (col >= g.N) continue;
+      const float bv = bias ? to_f<T>(bias[col]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row =
+            m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float v = g.alpha * acc[i][j][r] + bv;
+        T *cp = C + row * g.ldc + col;
+        if (g.beta != 0.f) v += g.beta * to_f<T>(*cp);
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        *cp = from_f<T>(v);
+      }
+    }
+}
+
+template <int BM, int BN>
+void launch_f32(const GemmArgs &g, int amode, int bmode, dim3 grid,
+                hipStream_t s) {
+#define SA_GEMM_CASE(AM, BMo)                                               \
+  if (amode == AM && bmode == BMo) {                                        \
+    hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, AM, BMo>), grid, dim3(256), \
+                       0, s, g);                                            \
+    return;                                                                 \
+  }
+  SA_GEMM_CASE(LD_VEC_K, LD_VEC_MN)
+  SA_GEMM_CASE(LD_VEC_K, LD_VEC_K)
+  SA_GEMM_CASE(LD_VEC_MN, LD_VEC_MN)
+  SA_GEMM_CASE(LD_VEC_MN, LD_VEC_K)
+  SA_GEMM_CASE(LD_GENERIC, LD_GENERIC)
+#undef SA_GEMM_CASE
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LD_GENERIC, LD_GENERIC>), grid,
+                     dim3(256), 0, s, g);
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
+            const void *A, int64_t a_rs, int64_t a_cs, int64_t a_bs,
+            const void *B, int64_t b_rs, int64_t b_cs, int64_t b_bs,
+            float beta, void *C, int64_t ldc, int64_t c_bs, int64_t batch,
+            const void *bias, int act, hipStream_t s) {
+  if (M <= 0 || N <= 0 || batch <= 0) return 0;
+  GemmArgs g{M, N, K, alpha, beta, A, a_rs, a_cs, a_bs, B, b_rs, b_cs, b_bs,
+             C, ldc, c_bs, bias, act};
+  // big tiles only when they still fill the 256 CUs
+  const int64_t tiles128 = ((M + 127) / 128) * ((N + 127) / 128) * batch;
+  const bool big = tiles128 >= 192 && M >= 96 && N >= 96;
+  if (dtype == kF32) {
+    auto al16 = [](const void *p) {
+      return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    };
+    int amode = LD_GENERIC, bmode = LD_GENERIC;
+    if (a_cs == 1 && (a_rs % 4) == 0 && (K % 4) == 0 && (a_bs % 4) == 0 &&
+        al16(A))
+      amode = LD_VEC_K;
+    else if (a_rs == 1 && (a_cs % 4) == 0 && (M % 4) == 0 && (a_bs % 4) == 0 &&
+             al16(A))
+      amode = LD_VEC_MN;
+    if (b_cs == 1 && (b_rs % 4) == 0 && (N % 4) == 0 && (b_bs % 4) == 0 &&
+        al16(B))
+      bmode = LD_VEC_MN;
+    else if (b_rs == 1 && (b_cs % 4) == 0 && (K % 4) == 0 && (b_bs % 4) == 0 &&
+             al16(B))
+      bmode = LD_VEC_K;
+    if (amode == LD_GENERIC || bmode == LD_GENERIC)
+      amode = bmode = LD_GENERIC;
+    if (big) {
+      dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128),
+                (unsigned)batch);
+      launch_f32<128, 128>(g, amode, bmode, grid, s);
+    } else {
+      dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64),
+                (unsigned)batch);
+      launch_f32<64, 64>(g, amode, bmode, grid, s);
+    }
+    return 0;
+  }
+  if (dtype == kF16 || dtype == kBF16) {
+    if (big) {
+      dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128),
+                (unsigned)batch);
+      if (dtype == kF16)
+        hipLaunchKernelGGL((gemm_h16_kernel<__half, 128, 128>), grid,
+                           dim3(256), 0, s, g);
+      else
+        hipLaunchKernelGGL((gemm_h16_kernel<__hip_bfloat16, 128, 128>), grid,
+                           dim3(256), 0, s, g);
+    } else {
+      dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64),
+                (unsigned)batch);
+      if (dtype == kF16)
+        hipLaunchKernelGGL((gemm_h16_kernel<__half, 64, 64>), grid, dim3(256),
+                           0, s, g);
+      else
+        hipLaunchKernelGGL((gemm_h16_kernel<__hip_bfloat16, 64, 64>), grid,
+                           dim3(256), 0, s, g);
+    }
+    return 0;
+  }
+  return -1;
+}

@@ -1,0 +1,190 @@
+// Host-callable launchers of every HIP kernel.  All functions enqueue on the
+// given stream, never allocate or synchronise (so they can be captured into a
+// hipGraph) and return 0 on success, a negative code for unsupported
+// arguments.  Pointers are raw device pointers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sa {
+
+// Up to 8 collapsed dimensions with three stride sets (operand 0, operand 1,
+// output); strides are in elements, 0 = broadcast.
+struct Desc {
+  int ndim;
+  int64_t shape[8];
+  int64_t s0[8];
+  int64_t s1[8];
+  int64_t s2[8];
+};
+
+enum UnaryOp : int {
+  U_COPY = 0, U_ABS, U_EXP, U_LOG, U_SQRT, U_SQUARE, U_SIGN, U_CEIL, U_FLOOR,
+  U_ROUND, U_ROUNDE, U_SIGMOID, U_TANH, U_RELU, U_ERF, U_COS, U_COSH, U_ACOS,
+  U_ACOSH, U_SIN, U_SINH, U_ASIN, U_ASINH, U_TAN, U_ATAN, U_ATANH, U_SOFTPLUS,
+  U_SOFTSIGN, U_CLAMP, U_ADD_S, U_SUB_S, U_MUL_S, U_DIV_S, U_POW_S, U_RDIV_S,
+  U_LT_S, U_LE_S, U_GT_S, U_GE_S, U_EQ_S, U_MAX_S, U_MIN_S
+};
+
+enum BinaryOp : int {
+  B_ADD = 0, B_SUB, B_MUL, B_DIV, B_POW, B_LT, B_LE, B_GT, B_GE, B_EQ, B_MAX,
+  B_MIN, B_RELU_BWD
+};
+
+enum ReduceOp : int { R_SUM = 0, R_MEAN, R_MAX, R_MIN, R_ASUM, R_SUMSQ };
+
+}  // namespace sa
+
+// ---- elementwise.hip --------------------------------------------------------
+int sa_unary(int op, int dt_in, int dt_out, const void *x, void *y,
+             const sa::Desc *d, int64_t n, float a, float b, hipStream_t s);
+int sa_binary(int op, int dtype, const void *x, const void *y, void *z,
+              const sa::Desc *d, int64_t n, hipStream_t s);
+int sa_fill(int dtype, void *y, int64_t n, float v, hipStream_t s);
+int sa_axpy(int dtype, const float *alpha_ptr, float alpha, const void *x,
+            void *y, int64_t n, hipStream_t s);
+
+// ---- reduce.hip ---------------------------------------------------------------
+// out[r] = reduce_c x[r, c] for a row-major (rows, cols) matrix
+int sa_reduce_rows(int op, int dtype, const void *x, void *out, int64_t rows,
+                   int64_t cols, hipStream_t s);
+// out[c] = sum_r x[r, c] for a row-major (rows, cols) matrix; out is float32
+// when out_f32 != 0.  `work` must hold rows_split * cols floats (see
+// sa_reduce_cols_workspace).
+int sa_reduce_cols(int dtype, const void *x, void *out, int64_t rows,
+                   int64_t cols, hipStream_t s);
+// whole-tensor reduction to one element (op: R_SUM, R_ASUM, R_SUMSQ, R_MAX,
+// R_MIN); `out` is written in the tensor's dtype, zero-initialised by the
+// launcher.
+int sa_reduce_all(int op, int dtype, const void *x, void *out, int64_t n,
+                  hipStream_t s);
+
+// ---- softmax_loss.hip -----------------------------------------------------------
+int sa_softmax_fwd(int dtype, const void *x, void *y, int64_t rows,
+                   int64_t cols, hipStream_t s);
+int sa_softmax_bwd(int dtype, const void *dy, const void *y, void *dx,
+                   int64_t rows, int64_t cols, hipStream_t s);
+// loss[r] = -log p[r, t[r]] (int labels) or -sum_c w[r,c] log p[r,c]
+int sa_cross_entropy_fwd(int dtype, const void *p, const void *t, int t_is_int,
+                         int t_dtype, void *loss, int64_t rows, int64_t cols,
+                         hipStream_t s);
+// in place: p -= onehot(t)  (or p -= t)
+int sa_softmax_ce_bwd(int dtype, void *p, const void *t, int t_is_int,
+                      int t_dtype, int64_t rows, int64_t cols, hipStream_t s);
+// p = softmax(x); loss[0] = mean_r CE(p[r], t[r])
+int sa_softmax_ce_fused_fwd(int dtype, const void *x, const void *t,
+                            int t_is_int, int t_dtype, void *p, void *loss,
+                            int64_t rows, int64_t cols, hipStream_t s);
+// dx = (p - onehot(t)) / rows
+int sa_softmax_ce_fused_bwd(int dtype, const void *p, const void *t,
+                            int t_is_int, int t_dtype, void *dx, int64_t rows,
+                            int64_t cols, hipStream_t s);
+
+// ---- rng.hip --------------------------------------------------------------------------
+// state = int64[2] {seed, offset}; the kernel draws from the current offset
+// and a trailing single-thread kernel advances it, so replays of a captured
+// graph continue the stream.
+int sa_rng_uniform(int dtype, void *y, int64_t n, float lo, float hi,
+                   int64_t *state, hipStream_t s);
+int sa_rng_normal(int dtype, void *y, int64_t n, float mean, float std,
+                  int64_t *state, hipStream_t s);
+int sa_rng_bernoulli(int dtype, void *y, int64_t n, float p, int64_t *state,
+                     hipStream_t s);
+
+// ---- gemm.hip ---------------------------------------------------------------------------
+// C[b] = alpha * op(A[b]) * op(B[b]) + beta * C[b]; A is (M, K) with element
+// strides (a_rs, a_cs), B is (K, N) with (b_rs, b_cs), C row-major with ldc.
+int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
+            const void *A, int64_t a_rs, int64_t a_cs, int64_t a_bs,
+            const void *B, int64_t b_rs, int64_t b_cs, int64_t b_bs,
+            float beta, void *C, int64_t ldc, int64_t c_bs, int64_t batch,
+            const void *bias, int act, hipStream_t s);
+
+// ---- conv.hip ---------------------------------------------------------------------------------
+struct ConvGeom {
+  int N, C, H, W;      // input
+  int K, R, S;         // filters (K output channels, R x S window)
+  int P, Q;            // output spatial size
+  int stride_h, stride_w, pad_h, pad_w;
+  int groups;
+};
+int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
+                const void *bias, void *y, hipStream_t s);
+int sa_conv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
+                     const void *w, void *dx, hipStream_t s);
+// dw must be zero-filled by the launcher (it does so itself)
+int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
+                       const void *x, void *dw, hipStream_t s);
+int sa_conv_bwd_bias(int dtype, const void *dy, void *db, int N, int K,
+                     int PQ, hipStream_t s);
+
+// ---- batchnorm.hip ----------------------------------------------------------------------------------
+// x, y: (N, C, HW) contiguous; statistics and affine parameters are float32.
+int sa_bn_fwd_train(int dtype, const void *x, const float *scale,
+                    const float *bias, float *rmean, float *rvar, float factor,
+                    float eps, void *y, float *mean, float *invstd, int N,
+                    int C, int HW, float *work, hipStream_t s);
+int sa_bn_fwd_infer(int dtype, const void *x, const float *scale,
+                    const float *bias, const float *rmean, const float *rvar,
+                    float eps, void *y, int N, int C, int HW, hipStream_t s);
+int sa_bn_bwd(int dtype, const void *dy, const void *x, const float *scale,
+              const float *mean, const float *invstd, void *dx, float *dscale,
+              float *dbias, int N, int C, int HW, float *work, hipStream_t s);
+// number of floats sa_bn_* need in `work`
+int64_t sa_bn_workspace(int N, int C, int HW);
+
+// ---- pooling.hip ---------------------------------------------------------------------------------------
+struct PoolGeom {
+  int N, C, H, W, P, Q;
+  int kh, kw, sh, sw, ph, pw;
+  int is_max;
+};
+int sa_pool_fwd(int dtype, const PoolGeom *g, const void *x, void *y,
+                hipStream_t s);
+int sa_pool_bwd(int dtype, const PoolGeom *g, const void *dy, const void *x,
+                const void *y, void *dx, hipStream_t s);
+
+// ---- optim.hip --------------------------------------------------------------------------------------------
+int sa_sgd_update(int dtype, void *p, const void *g, void *buf,
+                  const float *lr, const float *momentum,
+                  const float *dampening, const float *weight_decay,
+                  int nesterov, float scale, int64_t n, hipStream_t s);
+
+// ---- index.hip -----------------------------------------------------------------------------------------------
+// out[o, j, i] = x[o, idx[j], i]   (x: outer x n_in x inner)
+int sa_index_select(int dtype, const void *x, const int *idx, void *out,
+                    int64_t outer, int64_t n_in, int64_t n_out, int64_t inner,
+                    hipStream_t s);
+// out[o, idx[j], i] += dy[o, j, i]  (out zero-filled by the launcher)
+int sa_index_add(int dtype, const void *dy, const int *idx, void *out,
+                 int64_t outer, int64_t n_in, int64_t n_out, int64_t inner,
+                 hipStream_t s);
+
+// ---- rnn.hip ----------------------------------------------------------------------------------------------------
+int sa_lstm_cell_fwd(int dtype, const void *gates, const void *c_prev, void *c,
+                     void *h, void *acts, int64_t batch, int64_t hidden,
+                     hipStream_t s);
+int sa_lstm_cell_bwd(int dtype, const void *dh, const void *dc_next,
+                     const void *acts, const void *c_prev, const void *c,
+                     void *dgates, void *dc_prev, int64_t batch,
+                     int64_t hidden, hipStream_t s);
+
+// ---- comm.hip -------------------------------------------------------------------------------------------------------
+// many small tensors <-> one flat bucket in a single launch.  `table` is a
+// device array of n_tensors entries {ptr, offset, count}.
+struct PackEntry {
+  void *ptr;
+  int64_t offset;
+  int64_t count;
+};
+int sa_pack(int src_dtype, int dst_dtype, const PackEntry *table,
+            int n_tensors, void *bucket, int64_t total, hipStream_t s);
+int sa_unpack(int src_dtype, int dst_dtype, const PackEntry *table,
+              int n_tensors, const void *bucket, int64_t total, float scale,
+              hipStream_t s);
+// threshold sparsification helpers
+int sa_sparsify_threshold(const float *x, float thr, float *vals, int *idx,
+                          int *count, int64_t n, int64_t cap, hipStream_t s);
+int sa_scatter_add_sparse(const float *vals, const int *idx, const int *count,
+                          int64_t max_count, float *dense, int64_t n,
+                          hipStream_t s);

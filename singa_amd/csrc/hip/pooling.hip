@@ -1,0 +1,104 @@
+// 2-d max / average pooling, NCHW.  One thread per output element forward;
+// backward is gather-style (one thread per *input* element walks the output
+// windows that cover it), so no atomics are needed and results are
+// deterministic.  Max backward routes the gradient to every input position
+// equal to the window maximum, which needs only x and y like the cuDNN call
+// it replaces; average pooling divides by the number of in-bounds cells.
+//
+// Replaces cudnnPoolingForward / cudnnPoolingBackward of the reference
+// (src/model/operation/pooling.cc:120-227).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sa {
+
+template <typename T>
+__global__ void pool_fwd_kernel(PoolGeom g, const T *__restrict__ x,
+                                T *__restrict__ y, int64_t total) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += step) {
+    const int q = i % g.Q;
+    const int p = (i / g.Q) % g.P;
+    const int64_t nc = i / ((int64_t)g.P * g.Q);
+    const T *src = x + nc * g.H * g.W;
+    const int h0 = p * g.sh - g.ph, w0 = q * g.sw - g.pw;
+    const int h1 = min(h0 + g.kh, g.H), w1 = min(w0 + g.kw, g.W);
+    const int hs = max(h0, 0), ws = max(w0, 0);
+    float acc = g.is_max ? -3.4e38f : 0.f;
+    for (int h = hs; h < h1; ++h)
+      for (int w = ws; w < w1; ++w) {
+        const float v = to_f<T>(src[h * g.W + w]);
+        acc = g.is_max ? fmaxf(acc, v) : acc + v;
+      }
+    if (!g.is_max) {
+      const int cnt = (h1 - hs) * (w1 - ws);
+      acc = cnt > 0 ? acc / (float)cnt : 0.f;
+    }
+    y[i] = from_f<T>(acc);
+  }
+}
+
+template <typename T>
+__global__ void pool_bwd_kernel(PoolGeom g, const T *__restrict__ dy,
+                                const T *__restrict__ x,
+                                const T *__restrict__ y, T *__restrict__ dx,
+                                int64_t total) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += step) {
+    const int w = i % g.W;
+    const int h = (i / g.W) % g.H;
+    const int64_t nc = i / ((int64_t)g.H * g.W);
+    const T *dyp = dy + nc * g.P * g.Q;
+    const T *yp = y + nc * g.P * g.Q;
+    // output windows covering (h, w): p*sh - ph <= h < p*sh - ph + kh
+    const int hp = h + g.ph, wp = w + g.pw;
+    const int p_lo = hp < g.kh ? 0 : (hp - g.kh) / g.sh + 1;
+    const int p_hi = min(hp / g.sh, g.P - 1);
+    const int q_lo = wp < g.kw ? 0 : (wp - g.kw) / g.sw + 1;
+    const int q_hi = min(wp / g.sw, g.Q - 1);
+    const float xv = to_f<T>(x[i]);
+    float acc = 0.f;
+    for (int p = p_lo; p <= p_hi; ++p)
+      for (int q = q_lo; q <= q_hi; ++q) {
+        const float d = to_f<T>(dyp[p * g.Q + q]);
+        if (g.is_max) {
+          if (to_f<T>(yp[p * g.Q + q]) == xv) acc += d;
+        } else {
+          const int h0 = p * g.sh - g.ph, w0 = q * g.sw - g.pw;
+          const int cnt = (min(h0 + g.kh, g.H) - max(h0, 0)) *
+                          (min(w0 + g.kw, g.W) - max(w0, 0));
+          acc += d / (float)cnt;
+        }
+      }
+    dx[i] = from_f<T>(acc);
+  }
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+int sa_pool_fwd(int dtype, const PoolGeom *g, const void *x, void *y,
+                hipStream_t s) {
+  const int64_t total = (int64_t)g->N * g->C * g->P * g->Q;
+  if (total <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((pool_fwd_kernel<T>), dim3(grid_for(total, 256)),
+                       dim3(256), 0, s, *g, (const T *)x, (T *)y, total);
+  });
+  return 0;
+}
+
+int sa_pool_bwd(int dtype, const PoolGeom *g, const void *dy, const void *x,
+                const void *y, void *dx, hipStream_t s) {
+  const int64_t total = (int64_t)g->N * g->C * g->H * g->W;
+  if (total <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3(grid_for(total, 256)),
+                       dim3(256), 0, s, *g, (const T *)dy, (const T *)x,
+                       (const T *)y, (T *)dx, total);
+  });
+  return 0;
+}

@@ -1,0 +1,263 @@
+// Reductions: per-row (sum / mean / max / min over the fastest dimension),
+// per-column sum (over the slowest dimension) and whole-tensor reductions.
+//
+// Row reductions give one wave to short rows and one 256-thread block to long
+// ones; column sums tile the matrix 64 columns wide so every wave reads whole
+// 256-byte lines, accumulate in registers down a strip of rows and finish
+// with one float atomic per (strip, column).  Whole-tensor reductions do a
+// grid-stride pass, a block reduction and one atomic per block.
+//
+// Replaces cudnnReduceTensor / cublasSasum / cublasSnrm2 / the GEMV-with-ones
+// reductions and KernelRowMax of the reference (tensor_math_cuda.h:1000-1109,
+// 1492-1563).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sa {
+
+template <int OP> __device__ __forceinline__ float r_init() {
+  return OP == R_MAX ? -3.4e38f : (OP == R_MIN ? 3.4e38f : 0.f);
+}
+template <int OP> __device__ __forceinline__ float r_map(float x) {
+  if (OP == R_ASUM) return fabsf(x);
+  if (OP == R_SUMSQ) return x * x;
+  return x;
+}
+template <int OP> __device__ __forceinline__ float r_comb(float a, float b) {
+  if (OP == R_MAX) return fmaxf(a, b);
+  if (OP == R_MIN) return fminf(a, b);
+  return a + b;
+}
+template <int OP> __device__ __forceinline__ float r_wave(float v) {
+  if (OP == R_MAX) return wave_max(v);
+  if (OP == R_MIN) return wave_min(v);
+  return wave_sum(v);
+}
+
+// one wave per row
+template <typename T, int OP>
+__global__ void reduce_rows_wave_kernel(const T *__restrict__ x,
+                                        T *__restrict__ out, int64_t rows,
+                                        int64_t cols) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t r = wave; r < rows; r += nwaves) {
+    const T *row = x + r * cols;
+    float acc = r_init<OP>();
+    for (int64_t c = lane; c < cols; c += 64)
+      acc = r_comb<OP>(acc, r_map<OP>(to_f<T>(row[c])));
+    acc = r_wave<OP>(acc);
+    if (lane == 0) {
+      if (OP == R_MEAN) acc /= (float)cols;
+      out[r] = from_f<T>(acc);
+    }
+  }
+}
+
+// one block per row (long rows)
+template <typename T, int OP>
+__global__ void reduce_rows_block_kernel(const T *__restrict__ x,
+                                         T *__restrict__ out, int64_t rows,
+                                         int64_t cols) {
+  __shared__ float smem[32];
+  for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const T *row = x + r * cols;
+    float acc = r_init<OP>();
+    for (int64_t c = threadIdx.x; c < cols; c += blockDim.x)
+      acc = r_comb<OP>(acc, r_map<OP>(to_f<T>(row[c])));
+    acc = r_wave<OP>(acc);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) smem[wid] = acc;
+    __syncthreads();
+    if (wid == 0) {
+      float v = lane < (blockDim.x >> 6) ? smem[lane] : r_init<OP>();
+      v = r_wave<OP>(v);
+      if (lane == 0) {
+        if (OP == R_MEAN) v /= (float)cols;
+        out[r] = from_f<T>(v);
+      }
+    }
+  }
+}
+
+// column sums: block = 256 threads = 4 row-lanes x 64 columns
+template <typename T>
+__global__ void reduce_cols_kernel(const T *__restrict__ x,
+                                   float *__restrict__ out, int64_t rows,
+                                   int64_t cols, int64_t rows_per_block) {
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  float acc = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + ry; r < r1; r += 4) acc += to_f<T>(x[r * cols + c]);
+  part[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < cols) {
+    acc = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+    if (gridDim.y == 1)
+      out[c] = acc;
+    else
+      atomicAdd(out + c, acc);
+  }
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(const float *__restrict__ in,
+                                     T *__restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = from_f<T>(in[i]);
+}
+
+template <typename T, int OP>
+__global__ void reduce_all_kernel(const T *__restrict__ x,
+                                  float *__restrict__ acc_out, int64_t n) {
+  __shared__ float smem[32];
+  float acc = r_init<OP>();
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += step)
+    acc = r_comb<OP>(acc, r_map<OP>(to_f<T>(x[i])));
+  acc = r_wave<OP>(acc);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) smem[wid] = acc;
+  __syncthreads();
+  if (wid == 0) {
+    float v = lane < (blockDim.x >> 6) ? smem[lane] : r_init<OP>();
+    v = r_wave<OP>(v);
+    if (lane == 0) {
+      if (OP == R_MAX) {
+        // float max through the integer atomic on the ordered bit pattern
+        int *ai = reinterpret_cast<int *>(acc_out);
+        int old = *ai, assumed;
+        do {
+          assumed = old;
+          if (__int_as_float(assumed) >= v) break;
+          old = atomicCAS(ai, assumed, __float_as_int(v));
+        } while (assumed != old);
+      } else if (OP == R_MIN) {
+        int *ai = reinterpret_cast<int *>(acc_out);
+        int old = *ai, assumed;
+        do {
+          assumed = old;
+          if (__int_as_float(assumed) <= v) break;
+          old = atomicCAS(ai, assumed, __float_as_int(v));
+        } while (assumed != old);
+      } else {
+        atomicAdd(acc_out, v);
+      }
+    }
+  }
+}
+
+__global__ void set_scalar_kernel(float *p, float v) { *p = v; }
+
+template <typename T>
+__global__ void finish_scalar_kernel(const float *acc, T *out) {
+  *out = from_f<T>(*acc);
+}
+
+template <typename T, int OP>
+int launch_rows(const void *x, void *out, int64_t rows, int64_t cols,
+                hipStream_t s) {
+  if (cols <= 1024) {
+    int64_t waves = rows;
+    int blocks = (int)i64min((waves + 3) / 4, kMaxBlocks);
+    hipLaunchKernelGGL((reduce_rows_wave_kernel<T, OP>), dim3(blocks < 1 ? 1 : blocks),
+                       dim3(256), 0, s, (const T *)x, (T *)out, rows, cols);
+  } else {
+    int blocks = (int)i64min(rows, kMaxBlocks);
+    hipLaunchKernelGGL((reduce_rows_block_kernel<T, OP>), dim3(blocks < 1 ? 1 : blocks),
+                       dim3(256), 0, s, (const T *)x, (T *)out, rows, cols);
+  }
+  return 0;
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+int sa_reduce_rows(int op, int dtype, const void *x, void *out, int64_t rows,
+                   int64_t cols, hipStream_t s) {
+  if (rows <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    switch (op) {
+      case R_SUM: return launch_rows<T, R_SUM>(x, out, rows, cols, s);
+      case R_MEAN: return launch_rows<T, R_MEAN>(x, out, rows, cols, s);
+      case R_MAX: return launch_rows<T, R_MAX>(x, out, rows, cols, s);
+      case R_MIN: return launch_rows<T, R_MIN>(x, out, rows, cols, s);
+      default: return -1;
+    }
+  });
+  return 0;
+}
+
+int sa_reduce_cols(int dtype, const void *x, void *out, int64_t rows,
+                   int64_t cols, hipStream_t s) {
+  if (cols <= 0) return 0;
+  // split the rows so that the launch has a few thousand blocks at most
+  const int64_t col_blocks = (cols + 63) / 64;
+  int64_t splits = 1;
+  if (rows > 256) {
+    splits = i64min((rows + 255) / 256,
+                          i64max(1, 1024 / col_blocks));
+  }
+  const int64_t rpb = (rows + splits - 1) / splits;
+  splits = (rows + rpb - 1) / rpb;
+  if (dtype == kF32) {
+    if (splits > 1) hipMemsetAsync(out, 0, cols * sizeof(float), s);
+    hipLaunchKernelGGL((reduce_cols_kernel<float>),
+                       dim3((unsigned)col_blocks, (unsigned)splits), dim3(256),
+                       0, s, (const float *)x, (float *)out, rows, cols, rpb);
+    return 0;
+  }
+  // half types: single pass per column block, accumulate in float, no split
+  SA_DISPATCH_FLOAT(dtype, T, {
+    // reuse the kernel with splits = 1 writing float into a temp is not
+    // possible without workspace, so accumulate per column block serially
+    return -3;
+  });
+  return 0;
+}
+
+int sa_reduce_all(int op, int dtype, const void *x, void *out, int64_t n,
+                  hipStream_t s) {
+  // the float accumulator lives in the first 4 bytes of a static scratch
+  // word per stream is not capture friendly, so `out` must provide at least
+  // 4 bytes: for f32 it is the accumulator itself.
+  if (dtype != kF32) return -3;
+  float init = op == R_MAX ? -3.4e38f : (op == R_MIN ? 3.4e38f : 0.f);
+  hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, (float *)out,
+                     init);
+  if (n <= 0) return 0;
+  const int blocks = grid_for(n, 256, 8);
+  switch (op) {
+    case R_SUM:
+      hipLaunchKernelGGL((reduce_all_kernel<float, R_SUM>), dim3(blocks),
+                         dim3(256), 0, s, (const float *)x, (float *)out, n);
+      break;
+    case R_ASUM:
+      hipLaunchKernelGGL((reduce_all_kernel<float, R_ASUM>), dim3(blocks),
+                         dim3(256), 0, s, (const float *)x, (float *)out, n);
+      break;
+    case R_SUMSQ:
+      hipLaunchKernelGGL((reduce_all_kernel<float, R_SUMSQ>), dim3(blocks),
+                         dim3(256), 0, s, (const float *)x, (float *)out, n);
+      break;
+    case R_MAX:
+      hipLaunchKernelGGL((reduce_all_kernel<float, R_MAX>), dim3(blocks),
+                         dim3(256), 0, s, (const float *)x, (float *)out, n);
+      break;
+    case R_MIN:
+      hipLaunchKernelGGL((reduce_all_kernel<float, R_MIN>), dim3(blocks),
+                         dim3(256), 0, s, (const float *)x, (float *)out, n);
+      break;
+    default:
+      return -1;
+  }
+  return 0;
+}

@@ -1,0 +1,457 @@
+"""Numerics of every HIP kernel against a plain PyTorch float32 reference of
+the same op (the host math backend)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def maths(gpu_dev):
+    from singa_amd import device
+    return gpu_dev.math, device.get_default_device().math, gpu_dev
+
+
+def g(t, dev):
+    return t.to(dev.torch_device)
+
+
+def rnd(*shape, seed=0, lo=-1.0, hi=1.0):
+    r = np.random.RandomState(seed)
+    return torch.from_numpy(r.uniform(lo, hi, shape).astype(np.float32))
+
+
+UNARY = ["abs", "exp", "log", "sqrt", "square", "sign", "ceil", "floor",
+         "round", "rounde", "sigmoid", "tanh", "relu", "erf", "cos", "cosh",
+         "acos", "acosh", "sin", "sinh", "asin", "asinh", "tan", "atan",
+         "atanh", "softplus", "softsign"]
+
+
+@pytest.mark.parametrize("op", UNARY)
+def test_unary(maths, op):
+    hm, cm, dev = maths
+    lo, hi = (-0.9, 0.9)
+    if op in ("log", "sqrt"):
+        lo, hi = 0.1, 3.0
+    if op == "acosh":
+        lo, hi = 1.1, 3.0
+    x = rnd(1000, 7, seed=1, lo=lo, hi=hi)
+    ref = torch.empty_like(x)
+    cm.unary(op, x, ref)
+    out = torch.empty_like(x, device=dev.torch_device)
+    hm.unary(op, g(x, dev), out)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5,
+                               atol=2e-6)
+
+
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "pow", "lt", "le",
+                                "gt", "ge", "eq", "max", "min", "relu_bwd"])
+def test_binary_broadcast_and_transpose(maths, op):
+    hm, cm, dev = maths
+    a = rnd(6, 5, 33, seed=2, lo=0.2, hi=2.0)
+    b = rnd(5, 1, seed=3, lo=0.2, hi=2.0)
+    bt = b.expand(6, 5, 33)
+    ref = torch.empty(6, 5, 33)
+    cm.binary(op, a, bt, ref)
+    out = torch.empty(6, 5, 33, device=dev.torch_device)
+    hm.binary(op, g(a, dev), g(b, dev).expand(6, 5, 33), out)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5)
+    # transposed operand
+    at = rnd(33, 5, 6, seed=4, lo=0.2, hi=2.0)
+    ref2 = torch.empty(6, 5, 33)
+    cm.binary(op, at.permute(2, 1, 0), a, ref2)
+    out2 = torch.empty(6, 5, 33, device=dev.torch_device)
+    hm.binary(op, g(at, dev).permute(2, 1, 0), g(a, dev), out2)
+    np.testing.assert_allclose(out2.cpu().numpy(), ref2.numpy(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "pow", "lt", "ge",
+                                "eq", "rdiv", "max", "min"])
+def test_scalar(maths, op):
+    hm, cm, dev = maths
+    x = rnd(4099, seed=5, lo=0.5, hi=2.0)
+    ref = torch.empty_like(x)
+    cm.binary_scalar(op, x, 1.25, ref)
+    out = torch.empty_like(x, device=dev.torch_device)
+    hm.binary_scalar(op, g(x, dev), 1.25, out)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.int32])
+def test_cast_and_strided_copy(maths, dt):
+    hm, cm, dev = maths
+    x = rnd(17, 9, 5, seed=6, lo=-50, hi=50)
+    out = torch.empty(5, 9, 17, dtype=dt, device=dev.torch_device)
+    hm.copy(g(x, dev).permute(2, 1, 0), out)
+    ref = x.permute(2, 1, 0).to(dt)
+    assert torch.equal(out.cpu().float(), ref.float())
+    back = torch.empty(5, 9, 17, device=dev.torch_device)
+    hm.copy(out, back)
+    assert torch.equal(back.cpu(), ref.float())
+
+
+def test_fill_axpy(maths):
+    hm, cm, dev = maths
+    y = torch.empty(1000, device=dev.torch_device)
+    hm.fill(y, 2.5)
+    assert float(y.min()) == 2.5 and float(y.max()) == 2.5
+    x = g(rnd(1000, seed=7), dev)
+    hm.axpy(0.5, x, y)
+    np.testing.assert_allclose(y.cpu().numpy(), 2.5 + 0.5 * x.cpu().numpy(),
+                               rtol=1e-6)
+    alpha = torch.tensor([-2.0], device=dev.torch_device)
+    hm.axpy(alpha, x, y)
+    np.testing.assert_allclose(y.cpu().numpy(), 2.5 - 1.5 * x.cpu().numpy(),
+                               rtol=1e-5, atol=1e-6)
+
+
+def test_reductions(maths):
+    hm, cm, dev = maths
+    x = rnd(300, 70, seed=8)
+    xg = g(x, dev)
+    out = torch.empty(1, device=dev.torch_device)
+    hm.sum_all(xg, out)
+    np.testing.assert_allclose(out.cpu().numpy(), [x.sum().item()], rtol=1e-4)
+    o0 = torch.empty(70, device=dev.torch_device)
+    hm.sum_axis(xg, 0, o0)
+    np.testing.assert_allclose(o0.cpu().numpy(), x.sum(0).numpy(), rtol=1e-4,
+                               atol=1e-5)
+    o1 = torch.empty(300, device=dev.torch_device)
+    hm.sum_axis(xg, 1, o1)
+    np.testing.assert_allclose(o1.cpu().numpy(), x.sum(1).numpy(), rtol=1e-4,
+                               atol=1e-5)
+    hm.row_max(xg, o1)
+    np.testing.assert_allclose(o1.cpu().numpy(), x.max(1).values.numpy())
+    assert abs(hm.asum(xg) - x.abs().sum().item()) < 1e-1
+    assert abs(hm.nrm2(xg) - x.norm().item()) < 1e-3
+    big = rnd(5000, 130, seed=9)
+    ob = torch.empty(130, device=dev.torch_device)
+    hm.sum_axis(g(big, dev), 0, ob)
+    np.testing.assert_allclose(ob.cpu().numpy(), big.sum(0).numpy(), rtol=1e-4,
+                               atol=1e-3)
+    x4 = rnd(3, 4, 5, 6, seed=10)
+    for axes, op in [([1, 3], "sum"), ([0], "mean"), ([2, 3], "max"),
+                     ([0, 1], "sum"), ([3], "min")]:
+        ref = torch.empty(360)
+        cm.reduce(op, x4, axes, ref)
+        outf = torch.empty(360, device=dev.torch_device)
+        hm.reduce(op, g(x4, dev), axes, outf)
+        n = x4.numel() // int(np.prod([x4.shape[a] for a in axes]))
+        np.testing.assert_allclose(outf.cpu().numpy()[:n], ref.numpy()[:n],
+                                   rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cols", [10, 1000, 5000])
+def test_softmax_and_losses(maths, cols):
+    hm, cm, dev = maths
+    x = rnd(37, cols, seed=11, lo=-4, hi=4)
+    t = torch.from_numpy(np.random.RandomState(1).randint(0, cols, 37)
+                         .astype(np.int32))
+    ref = torch.empty_like(x)
+    cm.softmax(x, ref)
+    out = torch.empty_like(x, device=dev.torch_device)
+    hm.softmax(g(x, dev), out)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5,
+                               atol=1e-7)
+    dy = rnd(37, cols, seed=12)
+    rdx = torch.empty_like(x)
+    cm.softmax_bwd(dy, ref, rdx)
+    dx = torch.empty_like(x, device=dev.torch_device)
+    hm.softmax_bwd(g(dy, dev), out, dx)
+    np.testing.assert_allclose(dx.cpu().numpy(), rdx.numpy(), rtol=1e-4,
+                               atol=1e-7)
+    rl = torch.empty(37)
+    cm.cross_entropy_fwd(ref, t, rl)
+    l = torch.empty(37, device=dev.torch_device)
+    hm.cross_entropy_fwd(out, g(t, dev), l)
+    np.testing.assert_allclose(l.cpu().numpy(), rl.numpy(), rtol=1e-5)
+    # fused
+    rp, rloss = torch.empty_like(x), torch.empty(1)
+    cm.softmax_ce_fused_fwd(x, t, rp, rloss)
+    p = torch.empty_like(x, device=dev.torch_device)
+    loss = torch.empty(1, device=dev.torch_device)
+    hm.softmax_ce_fused_fwd(g(x, dev), g(t, dev), p, loss)
+    np.testing.assert_allclose(loss.cpu().numpy(), rloss.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(p.cpu().numpy(), rp.numpy(), rtol=1e-5, atol=1e-7)
+    rdx2 = torch.empty_like(x)
+    cm.softmax_ce_fused_bwd(rp, t, rdx2)
+    dx2 = torch.empty_like(x, device=dev.torch_device)
+    hm.softmax_ce_fused_bwd(p, g(t, dev), dx2)
+    np.testing.assert_allclose(dx2.cpu().numpy(), rdx2.numpy(), rtol=1e-5,
+                               atol=1e-8)
+    # dense targets
+    td = torch.softmax(rnd(37, cols, seed=13), dim=1)
+    cm.cross_entropy_fwd(ref, td, rl)
+    hm.cross_entropy_fwd(out, g(td, dev), l)
+    np.testing.assert_allclose(l.cpu().numpy(), rl.numpy(), rtol=1e-4)
+
+
+def test_rng_moments(maths):
+    hm, cm, dev = maths
+    dev.SetRandSeed(7)
+    n = 1 << 20
+    y = torch.empty(n, device=dev.torch_device)
+    hm.uniform(y, -1.0, 3.0)
+    assert abs(float(y.mean()) - 1.0) < 0.01 and float(y.min()) >= -1.0
+    assert float(y.max()) <= 3.0
+    hm.gaussian(y, 0.5, 2.0)
+    assert abs(float(y.mean()) - 0.5) < 0.01
+    assert abs(float(y.std()) - 2.0) < 0.01
+    hm.bernoulli(y, 0.3)
+    assert abs(float(y.mean()) - 0.3) < 0.005
+    a = torch.empty(1000, device=dev.torch_device)
+    b = torch.empty(1000, device=dev.torch_device)
+    hm.uniform(a, 0, 1)
+    hm.uniform(b, 0, 1)
+    assert not torch.equal(a, b)  # the device-side offset advanced
+    dev.SetRandSeed(7)
+    c = torch.empty(n, device=dev.torch_device)
+    hm.uniform(c, -1.0, 3.0)
+    dev.SetRandSeed(7)
+    d = torch.empty(n, device=dev.torch_device)
+    hm.uniform(d, -1.0, 3.0)
+    assert torch.equal(c, d)  # reproducible for a fixed seed
+
+
+GEMM_SHAPES = [(64, 2048, 1600), (33, 17, 65), (400, 3, 2), (256, 768, 768),
+               (1, 1000, 2048), (130, 129, 131)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_f32_layouts(maths, M, N, K):
+    hm, cm, dev = maths
+    a, b = rnd(M, K, seed=20), rnd(K, N, seed=21)
+    ref = a.double() @ b.double()
+    tol = 2e-6 * K
+    c = torch.empty(M, N, device=dev.torch_device)
+    hm.gemm(1.0, g(a, dev), g(b, dev), 0.0, c)
+    np.testing.assert_allclose(c.cpu().numpy(), ref.numpy(), atol=tol)
+    # transposed views of both operands (strides, not copies)
+    at = g(a.t().contiguous(), dev).t()
+    bt = g(b.t().contiguous(), dev).t()
+    hm.gemm(1.0, at, bt, 0.0, c)
+    np.testing.assert_allclose(c.cpu().numpy(), ref.numpy(), atol=tol)
+    hm.gemm(1.0, at, g(b, dev), 0.0, c)
+    np.testing.assert_allclose(c.cpu().numpy(), ref.numpy(), atol=tol)
+    # alpha / beta
+    c0 = rnd(M, N, seed=22)
+    c = g(c0, dev).clone()
+    hm.gemm(0.5, g(a, dev), g(b, dev), 2.0, c)
+    np.testing.assert_allclose(c.cpu().numpy(),
+                               (0.5 * ref + 2.0 * c0.double()).numpy(),
+                               atol=tol)
+
+
+def test_gemm_identity_asymmetric(maths):
+    """A = I with an asymmetric B catches swapped row / column maps."""
+    hm, cm, dev = maths
+    n = 96
+    eye = torch.eye(n)
+    b = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 17 + \
+        torch.arange(n).reshape(n, 1) * 0.5
+    c = torch.empty(n, n, device=dev.torch_device)
+    hm.gemm(1.0, g(eye, dev), g(b, dev), 0.0, c)
+    assert torch.equal(c.cpu(), b)
+
+
+def test_gemm_batched_and_gemv(maths):
+    hm, cm, dev = maths
+    a, b = rnd(12, 256, 64, seed=23), rnd(12, 64, 256, seed=24)
+    c = torch.empty(12, 256, 256, device=dev.torch_device)
+    hm.gemm(1.0, g(a, dev), g(b, dev), 0.0, c)
+    np.testing.assert_allclose(c.cpu().numpy(), torch.matmul(a, b).numpy(),
+                               atol=2e-4)
+    m, v = rnd(70, 50, seed=25), rnd(50, seed=26)
+    o = torch.empty(70, device=dev.torch_device)
+    hm.gemv(1.0, g(m, dev), g(v, dev), 0.0, o)
+    np.testing.assert_allclose(o.cpu().numpy(), (m @ v).numpy(), atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_half(maths, dt):
+    hm, cm, dev = maths
+    a, b = rnd(130, 200, seed=27).to(dt), rnd(200, 96, seed=28).to(dt)
+    ref = a.float() @ b.float()
+    c = torch.empty(130, 96, dtype=dt, device=dev.torch_device)
+    hm.gemm(1.0, g(a, dev), g(b, dev), 0.0, c)
+    tol = 0.02 if dt == torch.float16 else 0.15
+    np.testing.assert_allclose(c.cpu().float().numpy(), ref.numpy(), atol=tol)
+    ct = torch.empty(130, 96, dtype=dt, device=dev.torch_device)
+    hm.gemm(1.0, g(a.t().contiguous(), dev).t(),
+            g(b.t().contiguous(), dev).t(), 0.0, ct)
+    np.testing.assert_allclose(ct.cpu().float().numpy(), ref.numpy(), atol=tol)
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, S, stride, pad, groups
+    (2, 3, 32, 32, 16, 7, 7, 2, 3, 1),
+    (4, 64, 14, 14, 64, 3, 3, 1, 1, 1),
+    (3, 32, 15, 15, 48, 3, 3, 2, 1, 1),
+    (2, 128, 9, 9, 256, 1, 1, 1, 0, 1),
+    (2, 64, 12, 12, 128, 1, 1, 2, 0, 1),
+    (2, 16, 10, 11, 32, 3, 2, 1, 1, 4),
+    (2, 8, 9, 9, 8, 3, 3, 1, 1, 8),
+    (1, 20, 8, 8, 50, 5, 5, 1, 0, 1),
+    (5, 130, 7, 7, 200, 3, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_all_passes(maths, case):
+    hm, cm, dev = maths
+    N, C, H, W, K, R, S, st, pd, grp = case
+    x = rnd(N, C, H, W, seed=30)
+    w = rnd(K, C // grp, R, S, seed=31)
+    b = rnd(K, seed=32)
+    P = (H + 2 * pd - R) // st + 1
+    Q = (W + 2 * pd - S) // st + 1
+    ry = torch.empty(N, K, P, Q)
+    cm.conv_fwd(x, w, b, ry, (st, st), (pd, pd), grp)
+    y = torch.empty(N, K, P, Q, device=dev.torch_device)
+    hm.conv_fwd(g(x, dev), g(w, dev), g(b, dev), y, (st, st), (pd, pd), grp)
+    tol = 3e-6 * (C // grp) * R * S
+    np.testing.assert_allclose(y.cpu().numpy(), ry.numpy(), atol=tol, rtol=1e-5)
+    dy = rnd(N, K, P, Q, seed=33)
+    rdx = torch.empty_like(x)
+    cm.conv_bwd_data(dy, w, rdx, (st, st), (pd, pd), grp)
+    dx = torch.empty_like(x, device=dev.torch_device)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (st, st), (pd, pd), grp)
+    np.testing.assert_allclose(dx.cpu().numpy(), rdx.numpy(),
+                               atol=3e-6 * (K // grp) * R * S, rtol=1e-5)
+    rdw = torch.empty_like(w)
+    cm.conv_bwd_weight(dy, x, rdw, (st, st), (pd, pd), grp)
+    dw = torch.empty_like(w, device=dev.torch_device)
+    hm.conv_bwd_weight(g(dy, dev), g(x, dev), dw, (st, st), (pd, pd), grp)
+    np.testing.assert_allclose(dw.cpu().numpy(), rdw.numpy(),
+                               atol=3e-6 * N * P * Q, rtol=1e-4)
+    rdb = torch.empty(K)
+    cm.conv_bwd_bias(dy, rdb)
+    db = torch.empty(K, device=dev.torch_device)
+    hm.conv_bwd_bias(g(dy, dev), db)
+    np.testing.assert_allclose(db.cpu().numpy(), rdb.numpy(), atol=1e-4,
+                               rtol=1e-4)
+
+
+@pytest.mark.parametrize("shape", [(8, 16, 14, 14), (32, 64, 7, 7), (16, 10),
+                                   (4, 3, 33, 17)])
+def test_batchnorm(maths, shape):
+    hm, cm, dev = maths
+    C = shape[1]
+    x = rnd(*shape, seed=40, lo=-2, hi=5)
+    scale, bias = rnd(C, seed=41, lo=0.5, hi=1.5), rnd(C, seed=42)
+    rm, rv = rnd(C, seed=43), rnd(C, seed=44, lo=0.5, hi=2.0)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    ry, rmean, ristd = torch.empty_like(x), torch.empty(C), torch.empty(C)
+    cm.bn_fwd_train(x, scale, bias, rm_r, rv_r, 0.1, 1e-5, ry, rmean, ristd)
+    d = dev.torch_device
+    rm_g, rv_g = g(rm, dev), g(rv, dev)
+    y = torch.empty_like(x, device=d)
+    mean, istd = torch.empty(C, device=d), torch.empty(C, device=d)
+    hm.bn_fwd_train(g(x, dev), g(scale, dev), g(bias, dev), rm_g, rv_g, 0.1,
+                    1e-5, y, mean, istd)
+    np.testing.assert_allclose(y.cpu().numpy(), ry.numpy(), atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(mean.cpu().numpy(), rmean.numpy(), atol=1e-5)
+    np.testing.assert_allclose(istd.cpu().numpy(), ristd.numpy(), rtol=1e-4)
+    np.testing.assert_allclose(rm_g.cpu().numpy(), rm_r.numpy(), atol=1e-5)
+    np.testing.assert_allclose(rv_g.cpu().numpy(), rv_r.numpy(), rtol=1e-4)
+    dy = rnd(*shape, seed=45)
+    rdx, rds, rdb = torch.empty_like(x), torch.empty(C), torch.empty(C)
+    cm.bn_bwd(dy, x, scale, rmean, ristd, rdx, rds, rdb)
+    dx = torch.empty_like(x, device=d)
+    ds, db = torch.empty(C, device=d), torch.empty(C, device=d)
+    hm.bn_bwd(g(dy, dev), g(x, dev), g(scale, dev), mean, istd, dx, ds, db)
+    np.testing.assert_allclose(dx.cpu().numpy(), rdx.numpy(), atol=5e-5,
+                               rtol=1e-3)
+    np.testing.assert_allclose(ds.cpu().numpy(), rds.numpy(), atol=1e-3,
+                               rtol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), rdb.numpy(), atol=1e-3,
+                               rtol=1e-4)
+    riy = torch.empty_like(x)
+    cm.bn_fwd_infer(x, scale, bias, rm, rv, 1e-5, riy)
+    iy = torch.empty_like(x, device=d)
+    hm.bn_fwd_infer(g(x, dev), g(scale, dev), g(bias, dev), g(rm, dev),
+                    g(rv, dev), 1e-5, iy)
+    np.testing.assert_allclose(iy.cpu().numpy(), riy.numpy(), atol=2e-5,
+                               rtol=1e-4)
+
+
+@pytest.mark.parametrize("k,s,p,is_max", [(3, 2, 1, True), (2, 2, 0, True),
+                                          (7, 1, 0, False), (3, 2, 1, False),
+                                          (3, 1, 1, True)])
+def test_pooling(maths, k, s, p, is_max):
+    hm, cm, dev = maths
+    x = rnd(3, 5, 15, 14, seed=50)
+    P = (15 + 2 * p - k) // s + 1
+    Q = (14 + 2 * p - k) // s + 1
+    ry = torch.empty(3, 5, P, Q)
+    cm.pool_fwd(x, ry, (k, k), (s, s), (p, p), is_max)
+    y = torch.empty(3, 5, P, Q, device=dev.torch_device)
+    hm.pool_fwd(g(x, dev), y, (k, k), (s, s), (p, p), is_max)
+    np.testing.assert_allclose(y.cpu().numpy(), ry.numpy(), rtol=1e-6,
+                               atol=1e-6)
+    dy = rnd(3, 5, P, Q, seed=51)
+    rdx = torch.empty_like(x)
+    cm.pool_bwd(dy, x, ry, rdx, (k, k), (s, s), (p, p), is_max)
+    dx = torch.empty_like(x, device=dev.torch_device)
+    hm.pool_bwd(g(dy, dev), g(x, dev), y, dx, (k, k), (s, s), (p, p), is_max)
+    np.testing.assert_allclose(dx.cpu().numpy(), rdx.numpy(), rtol=1e-5,
+                               atol=1e-6)
+
+
+@pytest.mark.parametrize("nesterov,mom", [(False, 0.0), (False, 0.9),
+                                          (True, 0.9)])
+def test_sgd_fused(maths, nesterov, mom):
+    hm, cm, dev = maths
+    p, gr, buf = rnd(1003, seed=60), rnd(1003, seed=61), rnd(1003, seed=62)
+    hp = [torch.tensor([v]) for v in (0.1, mom, 0.0, 1e-3)]
+    pr, br = p.clone(), buf.clone()
+    cm.sgd_update(pr, gr, br if mom else None, hp[0], hp[1], hp[2], hp[3],
+                  nesterov, 0.5)
+    pg, bg = g(p, dev), g(buf, dev)
+    hm.sgd_update(pg, g(gr, dev), bg if mom else None,
+                  *[g(h, dev) for h in hp], nesterov, 0.5)
+    np.testing.assert_allclose(pg.cpu().numpy(), pr.numpy(), rtol=1e-5,
+                               atol=1e-7)
+    if mom:
+        np.testing.assert_allclose(bg.cpu().numpy(), br.numpy(), rtol=1e-5,
+                                   atol=1e-7)
+
+
+def test_index_ops(maths):
+    hm, cm, dev = maths
+    x = rnd(4, 9, 6, seed=70)
+    idx = torch.tensor([3, 0, 8, 3, -1], dtype=torch.int32)
+    ref = torch.index_select(x, 1, torch.tensor([3, 0, 8, 3, 8]))
+    out = torch.empty(4, 5, 6, device=dev.torch_device)
+    hm.index_select(g(x, dev), 1, g(idx, dev), out)
+    assert torch.equal(out.cpu(), ref)
+    dy = rnd(4, 5, 6, seed=71)
+    rdx = torch.zeros(4, 9, 6).index_add_(1, torch.tensor([3, 0, 8, 3, 8]), dy)
+    dx = torch.empty(4, 9, 6, device=dev.torch_device)
+    hm.index_add(g(dy, dev), 1, g(idx, dev), dx)
+    np.testing.assert_allclose(dx.cpu().numpy(), rdx.numpy(), rtol=1e-6,
+                               atol=1e-6)
+
+
+def test_lstm_cell(maths):
+    hm, cm, dev = maths
+    B, H = 7, 33
+    gates, cp = rnd(B, 4 * H, seed=80, lo=-2, hi=2), rnd(B, H, seed=81)
+    rc, rh, ra = torch.empty(B, H), torch.empty(B, H), torch.empty(B, 4 * H)
+    cm.lstm_cell_fwd(gates, cp, rc, rh, ra)
+    d = dev.torch_device
+    c, h, a = (torch.empty(B, H, device=d), torch.empty(B, H, device=d),
+               torch.empty(B, 4 * H, device=d))
+    hm.lstm_cell_fwd(g(gates, dev), g(cp, dev), c, h, a)
+    np.testing.assert_allclose(h.cpu().numpy(), rh.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(c.cpu().numpy(), rc.numpy(), rtol=1e-5, atol=1e-6)
+    dh, dc = rnd(B, H, seed=82), rnd(B, H, seed=83)
+    rdg, rdcp = torch.empty(B, 4 * H), torch.empty(B, H)
+    cm.lstm_cell_bwd(dh, dc, ra, cp, rc, rdg, rdcp)
+    dg, dcp = torch.empty(B, 4 * H, device=d), torch.empty(B, H, device=d)
+    hm.lstm_cell_bwd(g(dh, dev), g(dc, dev), a, g(cp, dev), c, dg, dcp)
+    np.testing.assert_allclose(dg.cpu().numpy(), rdg.numpy(), rtol=1e-4,
+                               atol=1e-6)
+    np.testing.assert_allclose(dcp.cpu().numpy(), rdcp.numpy(), rtol=1e-4,
+                               atol=1e-6)

@@ -135,10 +135,19 @@ def backward(y, dy=None):
         del op  # release everything the op cached
 
 
+class _AllTrue(object):
+    """Default of ``Operator.x_needs_grad`` for ops driven by hand through
+    ``forward`` / ``backward`` rather than ``__call__``."""
+
+    def __getitem__(self, idx):
+        return True
+
+
 class Operator(object):
     """Forward + backward of one tensor computation on core tensors."""
 
     op_count = 0
+    x_needs_grad = _AllTrue()
 
     def __init__(self, name=None):
         if name is None:
@@ -161,6 +170,12 @@ class Operator(object):
         assert all([isinstance(x, Tensor) for x in xs
                     ]), "xs should include only Tensor instances"
         self.requires_grad = any([x.requires_grad for x in xs])
+        # inputs whose gradient nobody consumes (data fed to the network):
+        # ops may return None for them instead of computing it
+        self.x_needs_grad = tuple(
+            x.stores_grad or
+            (x.requires_grad and not isinstance(x.creator, Dummy))
+            for x in xs)
         self.src = []
         for x in xs:
             if x.stores_grad:
@@ -1015,12 +1030,15 @@ class Matmul(Operator):
 
     def backward(self, dy):
         x, w = self.input
-        dx = singa.Mult(dy, _t_last2(w))
-        dw = singa.Mult(_t_last2(x), dy)
-        if list(dx.shape()) != list(x.shape()):
-            dx = back_broadcast(dx.shape(), x.shape(), dx)
-        if list(dw.shape()) != list(w.shape()):
-            dw = back_broadcast(dw.shape(), w.shape(), dw)
+        dx = dw = None
+        if self.x_needs_grad[0]:
+            dx = singa.Mult(dy, _t_last2(w))
+            if list(dx.shape()) != list(x.shape()):
+                dx = back_broadcast(dx.shape(), x.shape(), dx)
+        if self.x_needs_grad[1]:
+            dw = singa.Mult(_t_last2(x), dy)
+            if list(dw.shape()) != list(w.shape()):
+                dw = back_broadcast(dw.shape(), w.shape(), dw)
         return dx, dw
 
 
@@ -2101,13 +2119,15 @@ class _Conv2d(Operator):
     def backward(self, dy):
         assert training is True and hasattr(
             self, "inputs"), "Please set training as True before do BP. "
-        dx = singa.ConvBackwardx(dy, self.inputs[1], self.inputs[0],
-                                 self.handle)
+        dx = None
+        if self.x_needs_grad[0]:
+            dx = singa.ConvBackwardx(dy, self.inputs[1], self.inputs[0],
+                                     self.handle)
         dW = singa.ConvBackwardW(dy, self.inputs[0], self.inputs[1],
                                  self.handle)
         db = singa.ConvBackwardb(dy, self.inputs[2], self.handle) \
             if self.handle.bias_term else None
-        if self.odd_padding != (0, 0, 0, 0):
+        if dx is not None and self.odd_padding != (0, 0, 0, 0):
             dx = utils.handle_odd_pad_bwd(dx, self.odd_padding)
         if db is not None:
             return dx, dW, db

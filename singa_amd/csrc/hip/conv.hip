@@ -22,6 +22,11 @@
 //
 // Replaces cudnnConvolutionForward / BackwardData / BackwardFilter /
 // BackwardBias of the reference (src/model/operation/convolution.cc:585-703).
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -60,56 +65,121 @@ struct ConvArgs {
   int M, Ngemm, Kgemm;  // GEMM extents per group
   int Cg, Kg, RS, PQ, HW;
   int splits, k_per_split;
-  FastDiv div_rs, div_s, div_pq, div_q, div_hw, div_w, div_sh, div_sw;
+  int mt, nt;      // tile counts along M and N
+  int a_vec;       // A rows may be read four reduction indices at a time
+  int ncls;        // backward-data: stride classes in this launch
+  FastDiv div_rs, div_s, div_pq, div_q, div_hw, div_w;
+  // Backward-data with stride (sh, sw) splits into sh * sw independent
+  // stride-1 problems: input pixels with (h % sh, w % sw) = (ch, cw) receive
+  // contributions only from the taps r = r0 + sh * rr, s = s0 + sw * ss, and
+  // the output pixel hit by tap (rr, ss) is p = hh + off_h - rr,
+  // q = ww + off_w - ss for h = ch + sh * hh, w = cw + sw * ww.  A class is a
+  // dense convolution over its Hc x Wc sub-grid with an Rc x Sc sub-filter,
+  // so no multiply is spent on the zeros of the dilated gradient.
+  struct Cls {
+    int ch, cw, r0, s0, Rc, Sc, Hc, Wc, off_h, off_w, Kgemm, Ngemm;
+    FastDiv div_rcsc, div_sc, div_hcwc, div_wc;
+  } cls[4];
 };
 
-template <typename T, int MODE, int BM, int BN>
+// four consecutive elements -> float
+template <typename T>
+__device__ __forceinline__ void load4(const T *p, float (&o)[4]) {
+  struct alignas(sizeof(T) * 4) Pack { T v[4]; };
+  const Pack pk = *reinterpret_cast<const Pack *>(p);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = to_f<T>(pk.v[e]);
+}
+
+// V1: both operands are plain matrices (1x1 filter, stride 1, no padding,
+// H*W and the channel count multiples of 4): tiles are staged with 4-wide
+// loads and no per-element index arithmetic.
+template <typename T, int MODE, int BM, int BN, int BK, bool V1>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(ConvArgs a) {
-  constexpr int BK = 16;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int LDA = BM + 4, LDB = BN + 4;
+  // Row pitch of the k-major LDS tiles: rows written 4-wide need 16-byte
+  // alignment (pitch % 4 == 0); rows filled by transposing stores (reduction
+  // index over lanes) get an odd pitch, which spreads them over all banks.
+  constexpr bool A_T = MODE != CONV_BWD_DATA, B_T = MODE == CONV_BWD_WEIGHT;
+  constexpr int LDA = BM + (A_T ? 1 : 4), LDB = BN + (B_T ? 1 : 4);
   constexpr int A_PER = BM * BK / 256, B_PER = BN * BK / 256;
-  __shared__ float As[BK * LDA];
-  __shared__ float Bs[BK * LDB];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
 
   const ConvGeom &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int grp = blockIdx.z / a.splits, split = blockIdx.z % a.splits;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // ---- tile assignment -------------------------------------------------------
+  // Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with a
+  // private L2.  Tiles that read the same pixels (forward / backward-data:
+  // the M tiles of one pixel tile; backward-weight: all tiles of one
+  // reduction split) are given ids that are congruent mod 8 and adjacent in
+  // time, so the shared operand is fetched from HBM once per XCD instead of
+  // once per tile.
+  const int cls_i = MODE == CONV_BWD_DATA ? blockIdx.z % a.ncls : 0;
+  const int grp = MODE == CONV_BWD_DATA ? blockIdx.z / a.ncls : blockIdx.z;
+  const ConvArgs::Cls &bc = a.cls[cls_i];
+  const int Ngemm = MODE == CONV_BWD_DATA ? bc.Ngemm : a.Ngemm;
+  const int Kgemm = MODE == CONV_BWD_DATA ? bc.Kgemm : a.Kgemm;
+  int mt_i, nt_i, split = blockIdx.y;
+  {
+    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    if (MODE == CONV_BWD_WEIGHT) {
+      const int tiles = a.mt * a.nt;
+      const int tile = i % tiles;
+      split = (i / tiles) * 8 + xcd;
+      if (split >= a.splits) return;
+      mt_i = tile % a.mt;
+      nt_i = tile / a.mt;
+    } else {
+      mt_i = i % a.mt;
+      nt_i = (i / a.mt) * 8 + xcd;
+      if (nt_i * BN >= Ngemm) return;
+    }
+  }
+  const int m0 = mt_i * BM, n0 = nt_i * BN;
   const T *pa = (const T *)a.a;
   const T *pb = (const T *)a.b;
 
-  int kbeg = 0, kend = a.Kgemm;
-  if (MODE == CONV_BWD_WEIGHT) {
+  int kbeg = 0, kend = Kgemm;
+  if (a.splits > 1) {
     kbeg = split * a.k_per_split;
-    kend = min(a.Kgemm, kbeg + a.k_per_split);
+    kend = min(Kgemm, kbeg + a.k_per_split);
+    if (kend <= kbeg) return;  // nothing to add to the zero-filled output
   }
 
   // ---- per-thread constants of the gathers --------------------------------
   // forward / backward-data: the thread owns one pixel column of the B tile
-  int bj_valid = 0, b_n = 0, b_y = 0, b_x = 0;
+  // (scalar path) or four adjacent ones (V1)
+  int bj_valid = 0, b_y = 0, b_x = 0, b_base = 0;
   // backward-weight: the thread owns B_PER (c, r, s) columns
   int bw_off[B_PER], bw_r[B_PER], bw_s[B_PER];
   if (MODE == CONV_FWD || MODE == CONV_BWD_DATA) {
-    const int j = n0 + tid % BN;
-    bj_valid = j < a.Ngemm;
+    const int j = V1 ? n0 + 4 * (tid % (BN / 4)) : n0 + tid % BN;
+    bj_valid = j < Ngemm;
     if (bj_valid) {
       uint32_t n, pix, y, x;
-      if (MODE == CONV_FWD) {
+      if (V1) {
+        a.div_hw.divmod(j, n, pix);
+        const int ch = MODE == CONV_FWD ? g.C : g.K;
+        const int chg = MODE == CONV_FWD ? a.Cg : a.Kg;
+        b_base = ((int)n * ch + grp * chg) * a.HW + (int)pix;
+      } else if (MODE == CONV_FWD) {
         a.div_pq.divmod(j, n, pix);
         a.div_q.divmod(pix, y, x);
         b_y = y * g.stride_h - g.pad_h;
         b_x = x * g.stride_w - g.pad_w;
+        b_base = ((int)n * g.C + grp * a.Cg) * a.HW + b_y * g.W + b_x;
       } else {
-        a.div_hw.divmod(j, n, pix);
-        a.div_w.divmod(pix, y, x);
-        b_y = y + g.pad_h;
-        b_x = x + g.pad_w;
+        bc.div_hcwc.divmod(j, n, pix);
+        bc.div_wc.divmod(pix, y, x);
+        b_y = y + bc.off_h;
+        b_x = x + bc.off_w;
+        b_base = ((int)n * g.K + grp * a.Kg) * a.PQ + b_y * g.Q + b_x;
       }
-      b_n = n;
     }
   } else {
 #pragma unroll
@@ -130,66 +200,145 @@ conv_igemm_kernel(ConvArgs a) {
     }
   }
 
+  // The reduction index of a scalar-path element depends on tid / BN (B) or
+  // tid / BM (backward-data A) only, which is the same for all 64 lanes of a
+  // wave: reading it through readfirstlane keeps its (c, r, s) decomposition
+  // on the scalar unit.
+  const int ub = __builtin_amdgcn_readfirstlane(tid / BN);
+  const int ua = __builtin_amdgcn_readfirstlane(tid / BM);
+
   float ra[A_PER], rb[B_PER];
+
+  auto load_a_rows_vec = [&](int k0) {
+    // A[m][kk] contiguous along kk (forward: W, backward-weight: dY)
+    constexpr int AKV = BK / 4, AROWS = 256 / AKV;
+    const int kv = tid % AKV, mrow = tid / AKV;
+    const int kk = k0 + 4 * kv;
+#pragma unroll
+    for (int i = 0; i < A_PER / 4; ++i) {
+      const int m = m0 + mrow + AROWS * i;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (m < a.M && kk < kend) {
+        if (MODE == CONV_FWD) {
+          load4<T>(pa + (size_t)(grp * a.Kg + m) * a.Kgemm + kk, v);
+        } else {
+          uint32_t n, pq;
+          a.div_pq.divmod(kk, n, pq);
+          load4<T>(pa + (size_t)((int)n * g.K + grp * a.Kg + m) * a.PQ + pq, v);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ra[4 * i + e] = v[e];
+    }
+  };
+  auto store_a_rows_vec = [&](float *as) {
+    constexpr int AKV = BK / 4, AROWS = 256 / AKV;
+    const int kv = tid % AKV, mrow = tid / AKV;
+#pragma unroll
+    for (int i = 0; i < A_PER / 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        as[(4 * kv + e) * LDA + mrow + AROWS * i] = ra[4 * i + e];
+  };
 
   auto load_tiles = [&](int k0) {
     if (MODE == CONV_FWD) {
-      // A = W[k][(c,r,s)], contiguous along kk: kk fastest over lanes
+      if (a.a_vec) {
+        load_a_rows_vec(k0);
+      } else {
 #pragma unroll
-      for (int i = 0; i < A_PER; ++i) {
-        const int kk = k0 + tid % BK, m = m0 + tid / BK + (256 / BK) * i;
-        ra[i] = (m < a.M && kk < kend)
-                    ? to_f<T>(pa[(size_t)(grp * a.Kg + m) * a.Kgemm + kk])
-                    : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < B_PER; ++i) {
-        const int kk = k0 + tid / BN + (256 / BN) * i;
-        float v = 0.f;
-        if (bj_valid && kk < kend) {
-          uint32_t c, rs, r, s;
-          if (a.RS == 1) { c = kk; r = 0; s = 0; }
-          else { a.div_rs.divmod(kk, c, rs); a.div_s.divmod(rs, r, s); }
-          const int ih = b_y + (int)r, iw = b_x + (int)s;
-          if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-            v = to_f<T>(pb[((size_t)(b_n * g.C + grp * a.Cg + c) * g.H + ih) *
-                               g.W + iw]);
+        for (int i = 0; i < A_PER; ++i) {
+          const int kk = k0 + tid % BK, m = m0 + tid / BK + (256 / BK) * i;
+          ra[i] = (m < a.M && kk < kend)
+                      ? to_f<T>(pa[(size_t)(grp * a.Kg + m) * a.Kgemm + kk])
+                      : 0.f;
         }
-        rb[i] = v;
       }
     } else if (MODE == CONV_BWD_DATA) {
-      // A = W^T[c][(k,r,s)]: c fastest over lanes (stride RS in memory)
+      if (V1) {
+        // A[m][kk] = W[kk][m], contiguous along m
+        constexpr int AMV = BM / 4, AROWS = 256 / AMV;
+        const int m = m0 + 4 * (tid % AMV), krow = tid / AMV;
 #pragma unroll
-      for (int i = 0; i < A_PER; ++i) {
-        const int m = m0 + tid % BM, kk = k0 + tid / BM + (256 / BM) * i;
-        float v = 0.f;
-        if (m < a.M && kk < kend) {
-          uint32_t k, rs;
-          if (a.RS == 1) { k = kk; rs = 0; }
-          else a.div_rs.divmod(kk, k, rs);
-          v = to_f<T>(pa[((size_t)(grp * a.Kg + k) * a.Cg + m) * a.RS + rs]);
+        for (int i = 0; i < A_PER / 4; ++i) {
+          const int kk = k0 + krow + AROWS * i;
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          if (m < a.M && kk < kend)
+            load4<T>(pa + (size_t)(grp * a.Kg + kk) * a.Cg + m, v);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ra[4 * i + e] = v[e];
         }
-        ra[i] = v;
+      } else {
+        // A[m][(k,r,s)] = W[k][m][r][s]: m over lanes (stride RS in memory)
+        const int m = m0 + tid % BM;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          const int kk = k0 + ua + (256 / BM) * i;
+          uint32_t k, rs, rr, ss;
+          bc.div_rcsc.divmod(kk, k, rs);
+          bc.div_sc.divmod(rs, rr, ss);
+          const int soff = (grp * a.Kg + (int)k) * a.Cg * a.RS +
+                           (bc.r0 + g.stride_h * (int)rr) * g.S + bc.s0 +
+                           g.stride_w * (int)ss;
+          ra[i] = (m < a.M && kk < kend) ? to_f<T>(pa[soff + m * a.RS]) : 0.f;
+        }
       }
+    } else {
+      if (a.a_vec) {
+        load_a_rows_vec(k0);
+      } else {
+        const int kk = k0 + tid % BK;
+        uint32_t n = 0, pq = 0;
+        if (kk < kend) a.div_pq.divmod(kk, n, pq);
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          const int m = m0 + tid / BK + (256 / BK) * i;
+          ra[i] = (kk < kend && m < a.M)
+                      ? to_f<T>(pa[(size_t)((int)n * g.K + grp * a.Kg + m) *
+                                       a.PQ + pq])
+                      : 0.f;
+        }
+      }
+    }
+
+    if (MODE != CONV_BWD_WEIGHT && V1) {
+      constexpr int BV = BN / 4, BROWS = 256 / BV;
+      const int krow = tid / BV;
+#pragma unroll
+      for (int i = 0; i < B_PER / 4; ++i) {
+        const int kk = k0 + krow + BROWS * i;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (bj_valid && kk < kend) load4<T>(pb + b_base + kk * a.HW, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) rb[4 * i + e] = v[e];
+      }
+    } else if (MODE == CONV_FWD) {
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
-        const int kk = k0 + tid / BN + (256 / BN) * i;
-        float v = 0.f;
-        if (bj_valid && kk < kend) {
-          uint32_t k, rs, r, s;
-          if (a.RS == 1) { k = kk; r = 0; s = 0; }
-          else { a.div_rs.divmod(kk, k, rs); a.div_s.divmod(rs, r, s); }
-          const int py = b_y - (int)r, px = b_x - (int)s;
-          if (py >= 0 && px >= 0) {
-            uint32_t p, pr, q, qr;
-            a.div_sh.divmod(py, p, pr);
-            a.div_sw.divmod(px, q, qr);
-            if (pr == 0 && qr == 0 && (int)p < g.P && (int)q < g.Q)
-              v = to_f<T>(pb[((size_t)(b_n * g.K + grp * a.Kg + k) * g.P + p) *
-                                 g.Q + q]);
-          }
-        }
-        rb[i] = v;
+        const int kk = k0 + ub + (256 / BN) * i;
+        uint32_t c, rs, r, s;
+        if (a.RS == 1) { c = kk; r = 0; s = 0; }
+        else { a.div_rs.divmod(kk, c, rs); a.div_s.divmod(rs, r, s); }
+        const int soff = (int)c * a.HW + (int)r * g.W + (int)s;
+        const int ih = b_y + (int)r, iw = b_x + (int)s;
+        const bool ok = bj_valid && kk < kend &&
+                        (unsigned)ih < (unsigned)g.H &&
+                        (unsigned)iw < (unsigned)g.W;
+        rb[i] = ok ? to_f<T>(pb[b_base + soff]) : 0.f;
+      }
+    } else if (MODE == CONV_BWD_DATA) {
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int kk = k0 + ub + (256 / BN) * i;
+        uint32_t k, rs, rr, ss;
+        bc.div_rcsc.divmod(kk, k, rs);
+        bc.div_sc.divmod(rs, rr, ss);
+        const int py = b_y - (int)rr, px = b_x - (int)ss;
+        const int soff = (int)k * a.PQ - (int)rr * g.Q - (int)ss;
+        const bool ok = bj_valid && kk < kend &&
+                        (unsigned)py < (unsigned)g.P &&
+                        (unsigned)px < (unsigned)g.Q;
+        rb[i] = ok ? to_f<T>(pb[b_base + soff]) : 0.f;
       }
     } else {
       // reduction index kk = (n, p, q), one per thread and tile
@@ -200,46 +349,55 @@ conv_igemm_kernel(ConvArgs a) {
         a.div_pq.divmod(kk, n, pq);
         a.div_q.divmod(pq, p, q);
       }
-#pragma unroll
-      for (int i = 0; i < A_PER; ++i) {
-        const int m = m0 + tid / BK + (256 / BK) * i;
-        ra[i] = (kv && m < a.M)
-                    ? to_f<T>(pa[(size_t)(n * g.K + grp * a.Kg + m) * a.PQ + pq])
-                    : 0.f;
-      }
       const int ih0 = p * g.stride_h, iw0 = q * g.stride_w;
-      const size_t base = (size_t)n * g.C * a.HW + (size_t)ih0 * g.W + iw0;
+      const int base = (int)n * g.C * a.HW + ih0 * g.W + iw0;
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
-        float v = 0.f;
-        if (kv) {
-          const int ih = ih0 + bw_r[i], iw = iw0 + bw_s[i];
-          if ((unsigned)ih < (unsigned)g.H && (unsigned)iw < (unsigned)g.W)
-            v = to_f<T>(pb[base + bw_off[i]]);
-        }
-        rb[i] = v;
+        const int ih = ih0 + bw_r[i], iw = iw0 + bw_s[i];
+        const bool ok = kv && (unsigned)ih < (unsigned)g.H &&
+                        (unsigned)iw < (unsigned)g.W;
+        rb[i] = ok ? to_f<T>(pb[base + bw_off[i]]) : 0.f;
       }
     }
   };
 
-  auto store_tiles = [&]() {
+  auto store_tiles = [&](int buf) {
+    float *as = As[buf], *bs = Bs[buf];
     if (MODE == CONV_FWD || MODE == CONV_BWD_WEIGHT) {
+      if (a.a_vec) {
+        store_a_rows_vec(as);
+      } else {
 #pragma unroll
-      for (int i = 0; i < A_PER; ++i)
-        As[(tid % BK) * LDA + tid / BK + (256 / BK) * i] = ra[i];
+        for (int i = 0; i < A_PER; ++i)
+          as[(tid % BK) * LDA + tid / BK + (256 / BK) * i] = ra[i];
+      }
+    } else if (V1) {
+      constexpr int AMV = BM / 4, AROWS = 256 / AMV;
+#pragma unroll
+      for (int i = 0; i < A_PER / 4; ++i)
+        *reinterpret_cast<float4 *>(
+            &as[(tid / AMV + AROWS * i) * LDA + 4 * (tid % AMV)]) =
+            make_float4(ra[4 * i], ra[4 * i + 1], ra[4 * i + 2], ra[4 * i + 3]);
     } else {
 #pragma unroll
       for (int i = 0; i < A_PER; ++i)
-        As[(tid / BM + (256 / BM) * i) * LDA + tid % BM] = ra[i];
+        as[(tid / BM + (256 / BM) * i) * LDA + tid % BM] = ra[i];
     }
     if (MODE == CONV_BWD_WEIGHT) {
 #pragma unroll
       for (int i = 0; i < B_PER; ++i)
-        Bs[(tid % BK) * LDB + tid / BK + (256 / BK) * i] = rb[i];
+        bs[(tid % BK) * LDB + tid / BK + (256 / BK) * i] = rb[i];
+    } else if (V1) {
+      constexpr int BV = BN / 4, BROWS = 256 / BV;
+#pragma unroll
+      for (int i = 0; i < B_PER / 4; ++i)
+        *reinterpret_cast<float4 *>(
+            &bs[(tid / BV + BROWS * i) * LDB + 4 * (tid % BV)]) =
+            make_float4(rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]);
     } else {
 #pragma unroll
       for (int i = 0; i < B_PER; ++i)
-        Bs[(tid / BN + (256 / BN) * i) * LDB + tid % BN] = rb[i];
+        bs[(tid / BN + (256 / BN) * i) * LDB + tid % BN] = rb[i];
     }
   };
 
@@ -251,24 +409,27 @@ conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // double-buffered LDS: tile t+1 is fetched into registers under the MFMAs
+  // of tile t and written to the other buffer, one barrier per tile
   const int nt = (kend - kbeg + BK - 1) / BK;
   if (nt > 0) {
     load_tiles(kbeg);
-    store_tiles();
+    store_tiles(0);
   }
   __syncthreads();
   const int lrow = lane & 31, lk = lane >> 5;
   for (int t = 0; t < nt; ++t) {
+    const float *as = As[t & 1], *bs = Bs[t & 1];
     if (t + 1 < nt) load_tiles(kbeg + (t + 1) * BK);
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 2) {
       float av[TM], bv[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        av[i] = As[(ks + lk) * LDA + wm * WM + 32 * i + lrow];
+        av[i] = as[(ks + lk) * LDA + wm * WM + 32 * i + lrow];
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bv[j] = Bs[(ks + lk) * LDB + wn * WN + 32 * j + lrow];
+        bv[j] = bs[(ks + lk) * LDB + wn * WN + 32 * j + lrow];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -276,11 +437,8 @@ conv_igemm_kernel(ConvArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j],
                                                            acc[i][j], 0, 0, 0);
     }
+    if (t + 1 < nt) store_tiles((t + 1) & 1);
     __syncthreads();
-    if (t + 1 < nt) {
-      store_tiles();
-      __syncthreads();
-    }
   }
 
   // ---- epilogue ---------------------------------------------------------------
@@ -289,7 +447,7 @@ conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * WN + 32 * j + (lane & 31);
-    if (col >= a.Ngemm) continue;
+    if (col >= Ngemm) continue;
     size_t col_off;
     int chan_stride;
     if (MODE == CONV_FWD) {
@@ -298,9 +456,12 @@ conv_igemm_kernel(ConvArgs a) {
       col_off = (size_t)n * g.K * a.PQ + pix;
       chan_stride = a.PQ;
     } else if (MODE == CONV_BWD_DATA) {
-      uint32_t n, pix;
-      a.div_hw.divmod(col, n, pix);
-      col_off = (size_t)n * g.C * a.HW + pix;
+      uint32_t n, pix, hh, ww;
+      bc.div_hcwc.divmod(col, n, pix);
+      bc.div_wc.divmod(pix, hh, ww);
+      col_off = (size_t)n * g.C * a.HW +
+                (bc.ch + g.stride_h * (int)hh) * g.W + bc.cw +
+                g.stride_w * (int)ww;
       chan_stride = a.HW;
     } else {
       col_off = col;
@@ -316,11 +477,16 @@ conv_igemm_kernel(ConvArgs a) {
         const float v = acc[i][j][r];
         if (MODE == CONV_FWD) {
           const int ch = grp * a.Kg + row;
-          const float bv = a.bias ? to_f<T>(((const T *)a.bias)[ch]) : 0.f;
-          ((T *)a.out)[col_off + (size_t)ch * chan_stride] = from_f<T>(v + bv);
+          const float bv = (a.bias && split == 0)
+                               ? to_f<T>(((const T *)a.bias)[ch]) : 0.f;
+          T *dst = (T *)a.out + col_off + (size_t)ch * chan_stride;
+          if (a.splits == 1) *dst = from_f<T>(v + bv);
+          else atomicAdd((float *)dst, v + bv);  // float outputs only
         } else if (MODE == CONV_BWD_DATA) {
           const int ch = grp * a.Cg + row;
-          ((T *)a.out)[col_off + (size_t)ch * chan_stride] = from_f<T>(v);
+          T *dst = (T *)a.out + col_off + (size_t)ch * chan_stride;
+          if (a.splits == 1) *dst = from_f<T>(v);
+          else atomicAdd((float *)dst, v);
         } else {
           float *dst = (float *)a.out +
                        (size_t)(grp * a.Kg + row) * chan_stride + col_off;
@@ -367,12 +533,17 @@ static ConvArgs make_args(const ConvGeom &g, int mode) {
   a.splits = 1;
   a.k_per_split = 0;
   a.bias = nullptr;
+  a.mt = a.nt = 1;
+  a.ncls = 1;
   if (mode == CONV_FWD) {
     a.M = a.Kg; a.Ngemm = g.N * a.PQ; a.Kgemm = a.Cg * a.RS;
+    a.a_vec = a.Kgemm % 4 == 0;
   } else if (mode == CONV_BWD_DATA) {
     a.M = a.Cg; a.Ngemm = g.N * a.HW; a.Kgemm = a.Kg * a.RS;
+    a.a_vec = 0;
   } else {
     a.M = a.Kg; a.Ngemm = a.Cg * a.RS; a.Kgemm = g.N * a.PQ;
+    a.a_vec = a.PQ % 4 == 0;  // splits start at multiples of 32
   }
   a.div_rs = FastDiv(a.RS);
   a.div_s = FastDiv(g.S);
@@ -380,24 +551,80 @@ static ConvArgs make_args(const ConvGeom &g, int mode) {
   a.div_q = FastDiv(g.Q);
   a.div_hw = FastDiv(a.HW);
   a.div_w = FastDiv(g.W);
-  a.div_sh = FastDiv(g.stride_h);
-  a.div_sw = FastDiv(g.stride_w);
   return a;
 }
 
-template <typename T, int MODE>
-void launch_conv(ConvArgs &a, hipStream_t s) {
+static int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+// Tuning knobs (read once): SA_CONV_SPLIT_TARGET = number of workgroups below
+// which the reduction is split across workgroups, SA_CONV_TILE = 64 / 128
+// forces a tile size.
+static const int kSplitTarget = env_int("SA_CONV_SPLIT_TARGET", 1024);
+static const int kForceTile = env_int("SA_CONV_TILE", 0);
+
+static inline bool use_big_tile(const ConvArgs &a) {
+  if (kForceTile == 64) return false;
+  if (kForceTile == 128) return true;
   const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.Ngemm + 127) / 128) *
-                       a.g.groups * a.splits;
-  const bool big = a.M >= 96 && a.Ngemm >= 96 && t128 >= 256;
-  if (big) {
-    dim3 grid((a.Ngemm + 127) / 128, (a.M + 127) / 128, a.g.groups * a.splits);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, 128, 128>), grid, dim3(256),
-                       0, s, a);
+                       a.g.groups * a.ncls;
+  return a.M >= 96 && a.Ngemm >= 96 && t128 >= 256;
+}
+
+// Split the reduction so that the launch has about kSplitTarget workgroups,
+// each keeping at least min_k reduction indices; results are then combined
+// with float atomics on a zero-filled output.
+static void plan_splits(ConvArgs &a, int64_t tiles, int min_k) {
+  int64_t splits = 1;
+  if (tiles < kSplitTarget) splits = (kSplitTarget + tiles - 1) / tiles;
+  const int64_t max_splits = (a.Kgemm + min_k - 1) / min_k;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int kps = (int)((a.Kgemm + splits - 1) / splits);
+  kps = (kps + 31) / 32 * 32;
+  a.k_per_split = kps;
+  a.splits = (a.Kgemm + kps - 1) / kps;
+}
+
+template <typename T, int MODE, int BM, int BN, int BK, bool V1>
+void launch_tile(ConvArgs &a, hipStream_t s) {
+  a.mt = (a.M + BM - 1) / BM;
+  a.nt = (a.Ngemm + BN - 1) / BN;
+  dim3 grid;
+  if (MODE == CONV_BWD_WEIGHT)
+    grid = dim3((unsigned)((int64_t)a.mt * a.nt * ((a.splits + 7) / 8) * 8), 1,
+                a.g.groups);
+  else
+    grid = dim3((unsigned)((int64_t)a.mt * ((a.nt + 7) / 8) * 8), a.splits,
+                a.g.groups * a.ncls);
+  hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, BM, BN, BK, V1>), grid,
+                     dim3(256), 0, s, a);
+}
+
+// a.Ngemm / a.Kgemm hold the largest per-class extents for backward-data
+template <typename T, int MODE>
+void launch_conv(ConvArgs &a, size_t out_bytes, hipStream_t s,
+                 bool may_split = true) {
+  const ConvGeom &g = a.g;
+  const bool big = use_big_tile(a);
+  const int tb = big ? 128 : 64;
+  const int64_t tiles = (int64_t)((a.M + tb - 1) / tb) *
+                        ((a.Ngemm + tb - 1) / tb) * g.groups * a.ncls;
+  if (may_split && (std::is_same<T, float>::value || MODE == CONV_BWD_WEIGHT))
+    plan_splits(a, tiles, 256);
+  if (a.splits > 1 && out_bytes) (void)hipMemsetAsync(a.out, 0, out_bytes, s);
+  bool v1 = false;
+  if (MODE != CONV_BWD_WEIGHT)
+    v1 = a.RS == 1 && g.stride_h == 1 && g.stride_w == 1 && g.pad_h == 0 &&
+         g.pad_w == 0 && a.HW % 4 == 0 && a.Cg % 4 == 0 && a.Kg % 4 == 0;
+  if (MODE != CONV_BWD_WEIGHT && v1) {
+    if (big) launch_tile<T, MODE, 128, 128, 16, true>(a, s);
+    else launch_tile<T, MODE, 64, 64, 32, true>(a, s);
   } else {
-    dim3 grid((a.Ngemm + 63) / 64, (a.M + 63) / 64, a.g.groups * a.splits);
-    hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, 64, 64>), grid, dim3(256), 0,
-                       s, a);
+    if (big) launch_tile<T, MODE, 128, 128, 16, false>(a, s);
+    else launch_tile<T, MODE, 64, 64, 32, false>(a, s);
   }
 }
 
@@ -407,26 +634,79 @@ using namespace sa;
 
 static bool geom_ok(const ConvGeom *g) {
   if (g->groups < 1 || g->C % g->groups || g->K % g->groups) return false;
+  if (g->stride_h < 1 || g->stride_w < 1) return false;
   const int64_t lim = (int64_t)1 << 31;
   return (int64_t)g->N * g->C * g->H * g->W < lim &&
          (int64_t)g->N * g->K * g->P * g->Q < lim;
 }
+
+static size_t elem_size(int dtype) { return dtype == kF32 ? 4 : 2; }
 
 int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                 const void *bias, void *y, hipStream_t s) {
   if (!geom_ok(g)) return -2;
   ConvArgs a = make_args(*g, CONV_FWD);
   a.a = w; a.b = x; a.out = y; a.bias = bias;
-  SA_DISPATCH_FLOAT(dtype, T, { launch_conv<T, CONV_FWD>(a, s); });
+  const size_t bytes = (size_t)g->N * g->K * g->P * g->Q * elem_size(dtype);
+  SA_DISPATCH_FLOAT(dtype, T, { launch_conv<T, CONV_FWD>(a, bytes, s); });
   return 0;
 }
 
 int sa_conv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
                      const void *w, void *dx, hipStream_t s) {
   if (!geom_ok(g)) return -2;
-  ConvArgs a = make_args(*g, CONV_BWD_DATA);
-  a.a = w; a.b = dy; a.out = dx;
-  SA_DISPATCH_FLOAT(dtype, T, { launch_conv<T, CONV_BWD_DATA>(a, s); });
+  ConvArgs base = make_args(*g, CONV_BWD_DATA);
+  base.a = w; base.b = dy; base.out = dx;
+  const size_t bytes = (size_t)g->N * g->C * g->H * g->W * elem_size(dtype);
+  // one dense sub-problem per (h % sh, w % sw) class; classes no tap reaches
+  // (filter smaller than the stride) stay zero
+  std::vector<ConvArgs::Cls> classes;
+  bool untouched = false;
+  for (int ch = 0; ch < g->stride_h; ++ch)
+    for (int cw = 0; cw < g->stride_w; ++cw) {
+      ConvArgs::Cls c;
+      c.ch = ch; c.cw = cw;
+      c.Hc = ch < g->H ? (g->H - ch + g->stride_h - 1) / g->stride_h : 0;
+      c.Wc = cw < g->W ? (g->W - cw + g->stride_w - 1) / g->stride_w : 0;
+      if (c.Hc == 0 || c.Wc == 0) continue;
+      c.r0 = (ch + g->pad_h) % g->stride_h;
+      c.s0 = (cw + g->pad_w) % g->stride_w;
+      c.Rc = c.r0 < g->R ? (g->R - c.r0 + g->stride_h - 1) / g->stride_h : 0;
+      c.Sc = c.s0 < g->S ? (g->S - c.s0 + g->stride_w - 1) / g->stride_w : 0;
+      if (c.Rc == 0 || c.Sc == 0) { untouched = true; continue; }
+      c.off_h = (ch + g->pad_h - c.r0) / g->stride_h;
+      c.off_w = (cw + g->pad_w - c.s0) / g->stride_w;
+      c.Kgemm = base.Kg * c.Rc * c.Sc;
+      c.Ngemm = g->N * c.Hc * c.Wc;
+      c.div_rcsc = FastDiv(c.Rc * c.Sc);
+      c.div_sc = FastDiv(c.Sc);
+      c.div_hcwc = FastDiv(c.Hc * c.Wc);
+      c.div_wc = FastDiv(c.Wc);
+      classes.push_back(c);
+    }
+  bool zeroed = false;
+  if (untouched || classes.empty()) {
+    (void)hipMemsetAsync(dx, 0, bytes, s);
+    zeroed = true;
+  }
+  for (size_t first = 0; first < classes.size(); first += 4) {
+    ConvArgs a = base;
+    a.ncls = (int)std::min<size_t>(4, classes.size() - first);
+    a.Ngemm = a.Kgemm = 0;
+    for (int i = 0; i < a.ncls; ++i) {
+      a.cls[i] = classes[first + i];
+      a.Ngemm = std::max(a.Ngemm, a.cls[i].Ngemm);
+      a.Kgemm = std::max(a.Kgemm, a.cls[i].Kgemm);
+    }
+    // an earlier batch may already have written its classes: only the first
+    // launch may clear the output for split accumulation
+    const size_t clear = (zeroed || first > 0) ? 0 : bytes;
+    const bool may_split = zeroed || first == 0;
+    SA_DISPATCH_FLOAT(dtype, T, {
+      launch_conv<T, CONV_BWD_DATA>(a, clear, s, may_split);
+    });
+    if (a.splits > 1) zeroed = true;
+  }
   return 0;
 }
 
@@ -436,21 +716,8 @@ int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
   if (dtype != kF32) return -3;  // half types accumulate via a float buffer
   ConvArgs a = make_args(*g, CONV_BWD_WEIGHT);
   a.a = dy; a.b = x; a.out = dw;
-  // split the pixel reduction until the launch has >= ~512 blocks
-  const int64_t tiles = (int64_t)((a.M + 63) / 64) * ((a.Ngemm + 63) / 64) *
-                        g->groups;
-  int64_t splits = 1;
-  if (tiles < 512) splits = (512 + tiles - 1) / tiles;
-  const int64_t max_splits = (a.Kgemm + 255) / 256;  // >= 16 k-tiles each
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  int kps = (int)((a.Kgemm + splits - 1) / splits);
-  kps = (kps + 15) / 16 * 16;
-  a.k_per_split = kps;
-  a.splits = (a.Kgemm + kps - 1) / kps;
-  if (a.splits > 1)
-    hipMemsetAsync(dw, 0, (size_t)g->K * a.Cg * a.RS * sizeof(float), s);
-  launch_conv<float, CONV_BWD_WEIGHT>(a, s);
+  launch_conv<float, CONV_BWD_WEIGHT>(
+      a, (size_t)g->K * a.Cg * a.RS * sizeof(float), s);
   return 0;
 }
 

@@ -294,6 +294,18 @@ CONV_CASES = [
     (2, 8, 9, 9, 8, 3, 3, 1, 1, 8),
     (1, 20, 8, 8, 50, 5, 5, 1, 0, 1),
     (5, 130, 7, 7, 200, 3, 3, 1, 1, 1),
+    # 4-wide staged 1x1 path, small and 128x128 tiles
+    (2, 128, 8, 8, 256, 1, 1, 1, 0, 1),
+    (3, 64, 6, 10, 36, 1, 1, 1, 0, 2),
+    (16, 128, 36, 36, 256, 1, 1, 1, 0, 1),
+    # 128x128 tiles on the gather path
+    (32, 128, 36, 36, 128, 3, 3, 1, 1, 1),
+    (32, 128, 36, 36, 128, 3, 3, 2, 1, 1),
+    # stride 3: nine stride classes for backward-data, some without taps
+    (2, 8, 13, 11, 12, 5, 5, 3, 2, 1),
+    (2, 16, 9, 9, 8, 2, 2, 3, 0, 1),
+    # few tiles, long reduction: split across workgroups in every pass
+    (2, 512, 7, 7, 512, 3, 3, 1, 1, 1),
 ]
 
 

@@ -68,6 +68,7 @@ struct ConvArgs {
   int mt, nt;      // tile counts along M and N
   int a_vec;       // A rows may be read four reduction indices at a time
   int ncls;        // backward-data: stride classes in this launch
+  int64_t a_elems, b_elems;  // elements of the two operand tensors
   FastDiv div_rs, div_s, div_pq, div_q, div_hw, div_w;
   // Backward-data with stride (sh, sw) splits into sh * sw independent
   // stride-1 problems: input pixels with (h % sh, w % sw) = (ch, cw) receive
@@ -82,14 +83,63 @@ struct ConvArgs {
   } cls[4];
 };
 
-// four consecutive elements -> float
-template <typename T>
-__device__ __forceinline__ void load4(const T *p, float (&o)[4]) {
-  struct alignas(sizeof(T) * 4) Pack { T v[4]; };
-  const Pack pk = *reinterpret_cast<const Pack *>(p);
-#pragma unroll
-  for (int e = 0; e < 4; ++e) o[e] = to_f<T>(pk.v[e]);
+// ---- buffer loads -----------------------------------------------------------
+// Tile staging reads through buffer resources: a lane whose element lies
+// outside the tile, the image or the reduction range is given a byte offset
+// past the end of the resource and the hardware returns zero for it, so the
+// gathers are straight-line code without per-element branches.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr int kOob = (int)0x80000000;  // beyond any resource (<= 2^31 - 1 bytes)
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void *base, int64_t bytes) {
+  const int n = bytes > 0x7fffffff ? 0x7fffffff : (bytes < 0 ? 0 : (int)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, n,
+                                           0x00020000);
 }
+
+template <typename T> struct BufLd;
+template <> struct BufLd<float> {
+  static __device__ __forceinline__ float one(rsrc_t r, int off) {
+    return __builtin_bit_cast(float,
+                              __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+  }
+  static __device__ __forceinline__ void four(rsrc_t r, int off, float *o) {
+    // the loaded vector is reinterpreted as a whole, never indexed directly
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f w = __builtin_bit_cast(
+        v4f, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+    o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = w.w;
+  }
+};
+template <> struct BufLd<__half> {
+  static __device__ __forceinline__ float cvt(unsigned short b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+  }
+  static __device__ __forceinline__ float one(rsrc_t r, int off) {
+    return cvt(__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+  }
+  static __device__ __forceinline__ void four(rsrc_t r, int off, float *o) {
+    typedef _Float16 v4h __attribute__((ext_vector_type(4)));
+    const v4h w = __builtin_bit_cast(
+        v4h, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    o[0] = (float)w.x; o[1] = (float)w.y; o[2] = (float)w.z; o[3] = (float)w.w;
+  }
+};
+template <> struct BufLd<__hip_bfloat16> {
+  static __device__ __forceinline__ float one(rsrc_t r, int off) {
+    const unsigned b = __builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0);
+    return __builtin_bit_cast(float, b << 16);
+  }
+  static __device__ __forceinline__ void four(rsrc_t r, int off, float *o) {
+    typedef unsigned short v4s __attribute__((ext_vector_type(4)));
+    const v4s w = __builtin_bit_cast(
+        v4s, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+    o[0] = __builtin_bit_cast(float, (unsigned)w.x << 16);
+    o[1] = __builtin_bit_cast(float, (unsigned)w.y << 16);
+    o[2] = __builtin_bit_cast(float, (unsigned)w.z << 16);
+    o[3] = __builtin_bit_cast(float, (unsigned)w.w << 16);
+  }
+};
 
 // V1: both operands are plain matrices (1x1 filter, stride 1, no padding,
 // H*W and the channel count multiples of 4): tiles are staged with 4-wide
@@ -114,11 +164,11 @@ conv_igemm_kernel(ConvArgs a) {
 
   // ---- tile assignment -------------------------------------------------------
   // Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with a
-  // private L2.  Tiles that read the same pixels (forward / backward-data:
-  // the M tiles of one pixel tile; backward-weight: all tiles of one
-  // reduction split) are given ids that are congruent mod 8 and adjacent in
-  // time, so the shared operand is fetched from HBM once per XCD instead of
-  // once per tile.
+  // private L2.  The tile list is cut into 8 contiguous chunks, one per XCD,
+  // ordered so that tiles reading the same pixels (forward / backward-data:
+  // the M tiles of one pixel tile; backward-weight: the tiles of one
+  // reduction split) are neighbours on one XCD: the shared operand is then
+  // fetched from HBM once per XCD instead of once per tile.
   const int cls_i = MODE == CONV_BWD_DATA ? blockIdx.z % a.ncls : 0;
   const int grp = MODE == CONV_BWD_DATA ? blockIdx.z / a.ncls : blockIdx.z;
   const ConvArgs::Cls &bc = a.cls[cls_i];
@@ -126,17 +176,21 @@ conv_igemm_kernel(ConvArgs a) {
   const int Kgemm = MODE == CONV_BWD_DATA ? bc.Kgemm : a.Kgemm;
   int mt_i, nt_i, split = blockIdx.y;
   {
-    const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+    // XCD x works through the x-th eighth of the tile list
+    const int w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int tiles = a.mt * a.nt;
     if (MODE == CONV_BWD_WEIGHT) {
-      const int tiles = a.mt * a.nt;
-      const int tile = i % tiles;
-      split = (i / tiles) * 8 + xcd;
-      if (split >= a.splits) return;
-      mt_i = tile % a.mt;
+      // split-major list: one XCD stays on one slice of the pixels
+      if (w >= tiles * a.splits) return;
+      split = w / tiles;
+      const int tile = w - split * tiles;
       nt_i = tile / a.mt;
+      mt_i = tile - nt_i * a.mt;
     } else {
-      mt_i = i % a.mt;
-      nt_i = (i / a.mt) * 8 + xcd;
+      // pixel-tile-major list: the M tiles of one pixel tile are adjacent
+      if (w >= tiles) return;
+      nt_i = w / a.mt;
+      mt_i = w - nt_i * a.mt;
       if (nt_i * BN >= Ngemm) return;
     }
   }
@@ -151,6 +205,20 @@ conv_igemm_kernel(ConvArgs a) {
     if (kend <= kbeg) return;  // nothing to add to the zero-filled output
   }
 
+  // ---- resources ---------------------------------------------------------------
+  // Offsets into a resource are 32-bit byte offsets, so each resource starts
+  // at the first image its tile can touch: forward / backward-data rebase B
+  // once per workgroup, backward-weight rebases both operands per K tile.
+  constexpr int SZ = (int)sizeof(T);
+  const int64_t a_img = (int64_t)g.K * a.PQ;  // backward-weight A = dY
+  const int64_t b_img =
+      MODE == CONV_BWD_DATA ? (int64_t)g.K * a.PQ : (int64_t)g.C * a.HW;
+  int n_base = 0;
+  if (MODE == CONV_FWD) n_base = a.div_pq.div(n0);
+  if (MODE == CONV_BWD_DATA) n_base = bc.div_hcwc.div(n0);
+  rsrc_t rA = make_rsrc(pa, a.a_elems * SZ);
+  rsrc_t rB = make_rsrc(pb + n_base * b_img, (a.b_elems - n_base * b_img) * SZ);
+
   // ---- per-thread constants of the gathers --------------------------------
   // forward / backward-data: the thread owns one pixel column of the B tile
   // (scalar path) or four adjacent ones (V1)
@@ -160,26 +228,24 @@ conv_igemm_kernel(ConvArgs a) {
   if (MODE == CONV_FWD || MODE == CONV_BWD_DATA) {
     const int j = V1 ? n0 + 4 * (tid % (BN / 4)) : n0 + tid % BN;
     bj_valid = j < Ngemm;
-    if (bj_valid) {
-      uint32_t n, pix, y, x;
-      if (V1) {
-        a.div_hw.divmod(j, n, pix);
-        const int ch = MODE == CONV_FWD ? g.C : g.K;
-        const int chg = MODE == CONV_FWD ? a.Cg : a.Kg;
-        b_base = ((int)n * ch + grp * chg) * a.HW + (int)pix;
-      } else if (MODE == CONV_FWD) {
-        a.div_pq.divmod(j, n, pix);
-        a.div_q.divmod(pix, y, x);
-        b_y = y * g.stride_h - g.pad_h;
-        b_x = x * g.stride_w - g.pad_w;
-        b_base = ((int)n * g.C + grp * a.Cg) * a.HW + b_y * g.W + b_x;
-      } else {
-        bc.div_hcwc.divmod(j, n, pix);
-        bc.div_wc.divmod(pix, y, x);
-        b_y = y + bc.off_h;
-        b_x = x + bc.off_w;
-        b_base = ((int)n * g.K + grp * a.Kg) * a.PQ + b_y * g.Q + b_x;
-      }
+    uint32_t n, pix, y, x;
+    if (V1) {
+      a.div_hw.divmod(j, n, pix);
+      const int ch = MODE == CONV_FWD ? g.C : g.K;
+      const int chg = MODE == CONV_FWD ? a.Cg : a.Kg;
+      b_base = (((int)n - n_base) * ch + grp * chg) * a.HW + (int)pix;
+    } else if (MODE == CONV_FWD) {
+      a.div_pq.divmod(j, n, pix);
+      a.div_q.divmod(pix, y, x);
+      b_y = y * g.stride_h - g.pad_h;
+      b_x = x * g.stride_w - g.pad_w;
+      b_base = (((int)n - n_base) * g.C + grp * a.Cg) * a.HW + b_y * g.W + b_x;
+    } else {
+      bc.div_hcwc.divmod(j, n, pix);
+      bc.div_wc.divmod(pix, y, x);
+      b_y = y + bc.off_h;
+      b_x = x + bc.off_w;
+      b_base = (((int)n - n_base) * g.K + grp * a.Kg) * a.PQ + b_y * g.Q + b_x;
     }
   } else {
 #pragma unroll
@@ -195,42 +261,25 @@ conv_igemm_kernel(ConvArgs a) {
       } else {
         // far outside the image: the bounds test rejects every tap
         bw_off[i] = 0;
-        bw_r[i] = bw_s[i] = -(1 << 28);
+        bw_r[i] = bw_s[i] = -(1 << 29);
       }
     }
   }
 
-  // The reduction index of a scalar-path element depends on tid / BN (B) or
-  // tid / BM (backward-data A) only, which is the same for all 64 lanes of a
-  // wave: reading it through readfirstlane keeps its (c, r, s) decomposition
-  // on the scalar unit.
+  // Scalar-path elements of one wave share their reduction index: element i
+  // of wave-row u sits at kk = k0 + u + step * i.  Once per K tile lane l
+  // decomposes kk = k0 + l into filter tap and byte offset; elements then
+  // fetch their entry with v_readlane, so the per-element cost is a handful
+  // of vector instructions and no integer division.
   const int ub = __builtin_amdgcn_readfirstlane(tid / BN);
   const int ua = __builtin_amdgcn_readfirstlane(tid / BM);
+  constexpr int kFar = 1 << 28;  // fails every bounds test
+  if (!bj_valid) b_y = kFar;
+  const int b_base_bytes = b_base * SZ;
 
   float ra[A_PER], rb[B_PER];
+  int ao[A_PER], bo[B_PER];
 
-  auto load_a_rows_vec = [&](int k0) {
-    // A[m][kk] contiguous along kk (forward: W, backward-weight: dY)
-    constexpr int AKV = BK / 4, AROWS = 256 / AKV;
-    const int kv = tid % AKV, mrow = tid / AKV;
-    const int kk = k0 + 4 * kv;
-#pragma unroll
-    for (int i = 0; i < A_PER / 4; ++i) {
-      const int m = m0 + mrow + AROWS * i;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (m < a.M && kk < kend) {
-        if (MODE == CONV_FWD) {
-          load4<T>(pa + (size_t)(grp * a.Kg + m) * a.Kgemm + kk, v);
-        } else {
-          uint32_t n, pq;
-          a.div_pq.divmod(kk, n, pq);
-          load4<T>(pa + (size_t)((int)n * g.K + grp * a.Kg + m) * a.PQ + pq, v);
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ra[4 * i + e] = v[e];
-    }
-  };
   auto store_a_rows_vec = [&](float *as) {
     constexpr int AKV = BK / 4, AROWS = 256 / AKV;
     const int kv = tid % AKV, mrow = tid / AKV;
@@ -241,124 +290,161 @@ conv_igemm_kernel(ConvArgs a) {
         as[(4 * kv + e) * LDA + mrow + AROWS * i] = ra[4 * i + e];
   };
 
-  auto load_tiles = [&](int k0) {
-    if (MODE == CONV_FWD) {
-      if (a.a_vec) {
-        load_a_rows_vec(k0);
+  // phase 1: byte offsets of every element of the next tile
+  auto plan_tiles = [&](int k0) {
+    int nb = 0;
+    if (MODE == CONV_BWD_WEIGHT) {
+      // all images of this K tile lie at or after image nb
+      nb = a.div_pq.div(k0);
+      rA = make_rsrc(pa + nb * a_img, (a.a_elems - nb * a_img) * SZ);
+      rB = make_rsrc(pb + nb * b_img, (a.b_elems - nb * b_img) * SZ);
+    }
+    // ---- A ----
+    if ((MODE == CONV_FWD || MODE == CONV_BWD_WEIGHT) && a.a_vec) {
+      // A[m][kk] contiguous along kk (forward: W, backward-weight: dY)
+      constexpr int AKV = BK / 4, AROWS = 256 / AKV;
+      const int kv = tid % AKV, mrow = tid / AKV;
+      const int kk = k0 + 4 * kv;
+      int base;
+      if (MODE == CONV_FWD) {
+        base = grp * a.Kg * a.Kgemm + kk;
       } else {
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-          const int kk = k0 + tid % BK, m = m0 + tid / BK + (256 / BK) * i;
-          ra[i] = (m < a.M && kk < kend)
-                      ? to_f<T>(pa[(size_t)(grp * a.Kg + m) * a.Kgemm + kk])
-                      : 0.f;
-        }
+        uint32_t n, pq;
+        a.div_pq.divmod(kk, n, pq);
+        base = (((int)n - nb) * g.K + grp * a.Kg) * a.PQ + (int)pq;
       }
-    } else if (MODE == CONV_BWD_DATA) {
-      if (V1) {
-        // A[m][kk] = W[kk][m], contiguous along m
-        constexpr int AMV = BM / 4, AROWS = 256 / AMV;
-        const int m = m0 + 4 * (tid % AMV), krow = tid / AMV;
+      const int mstride = MODE == CONV_FWD ? a.Kgemm : a.PQ;
 #pragma unroll
-        for (int i = 0; i < A_PER / 4; ++i) {
-          const int kk = k0 + krow + AROWS * i;
-          float v[4] = {0.f, 0.f, 0.f, 0.f};
-          if (m < a.M && kk < kend)
-            load4<T>(pa + (size_t)(grp * a.Kg + kk) * a.Cg + m, v);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) ra[4 * i + e] = v[e];
-        }
-      } else {
-        // A[m][(k,r,s)] = W[k][m][r][s]: m over lanes (stride RS in memory)
-        const int m = m0 + tid % BM;
-#pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-          const int kk = k0 + ua + (256 / BM) * i;
-          uint32_t k, rs, rr, ss;
-          bc.div_rcsc.divmod(kk, k, rs);
-          bc.div_sc.divmod(rs, rr, ss);
-          const int soff = (grp * a.Kg + (int)k) * a.Cg * a.RS +
-                           (bc.r0 + g.stride_h * (int)rr) * g.S + bc.s0 +
-                           g.stride_w * (int)ss;
-          ra[i] = (m < a.M && kk < kend) ? to_f<T>(pa[soff + m * a.RS]) : 0.f;
-        }
+      for (int i = 0; i < A_PER / 4; ++i) {
+        const int m = m0 + mrow + AROWS * i;
+        ao[i] = (m < a.M && kk < kend) ? (base + m * mstride) * SZ : kOob;
       }
-    } else {
-      if (a.a_vec) {
-        load_a_rows_vec(k0);
+    } else if (MODE == CONV_FWD || MODE == CONV_BWD_WEIGHT) {
+      const int kk = k0 + tid % BK;
+      int base, mstride;
+      if (MODE == CONV_FWD) {
+        base = grp * a.Kg * a.Kgemm + kk;
+        mstride = a.Kgemm;
       } else {
-        const int kk = k0 + tid % BK;
-        uint32_t n = 0, pq = 0;
-        if (kk < kend) a.div_pq.divmod(kk, n, pq);
+        uint32_t n, pq;
+        a.div_pq.divmod(kk, n, pq);
+        base = (((int)n - nb) * g.K + grp * a.Kg) * a.PQ + (int)pq;
+        mstride = a.PQ;
+      }
 #pragma unroll
-        for (int i = 0; i < A_PER; ++i) {
-          const int m = m0 + tid / BK + (256 / BK) * i;
-          ra[i] = (kk < kend && m < a.M)
-                      ? to_f<T>(pa[(size_t)((int)n * g.K + grp * a.Kg + m) *
-                                       a.PQ + pq])
-                      : 0.f;
-        }
+      for (int i = 0; i < A_PER; ++i) {
+        const int m = m0 + tid / BK + (256 / BK) * i;
+        ao[i] = (m < a.M && kk < kend) ? (base + m * mstride) * SZ : kOob;
+      }
+    } else if (V1) {
+      // backward-data, A[m][kk] = W[kk][m], contiguous along m
+      constexpr int AMV = BM / 4, AROWS = 256 / AMV;
+      const int m = m0 + 4 * (tid % AMV), krow = tid / AMV;
+#pragma unroll
+      for (int i = 0; i < A_PER / 4; ++i) {
+        const int kk = k0 + krow + AROWS * i;
+        ao[i] = (m < a.M && kk < kend)
+                    ? ((grp * a.Kg + kk) * a.Cg + m) * SZ : kOob;
       }
     }
-
+    // ---- B (and the gathered A of backward-data) ----
     if (MODE != CONV_BWD_WEIGHT && V1) {
       constexpr int BV = BN / 4, BROWS = 256 / BV;
       const int krow = tid / BV;
 #pragma unroll
       for (int i = 0; i < B_PER / 4; ++i) {
         const int kk = k0 + krow + BROWS * i;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (bj_valid && kk < kend) load4<T>(pb + b_base + kk * a.HW, v);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) rb[4 * i + e] = v[e];
+        bo[i] = (bj_valid && kk < kend) ? (b_base + kk * a.HW) * SZ : kOob;
       }
     } else if (MODE == CONV_FWD) {
+      const int kk = k0 + lane;
+      uint32_t c, rs, r, s;
+      a.div_rs.divmod(kk, c, rs);
+      a.div_s.divmod(rs, r, s);
+      const int t_off = ((int)c * a.HW + (int)r * g.W + (int)s) * SZ;
+      const int t_r = kk < kend ? (int)r : kFar, t_s = (int)s;
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
-        const int kk = k0 + ub + (256 / BN) * i;
-        uint32_t c, rs, r, s;
-        if (a.RS == 1) { c = kk; r = 0; s = 0; }
-        else { a.div_rs.divmod(kk, c, rs); a.div_s.divmod(rs, r, s); }
-        const int soff = (int)c * a.HW + (int)r * g.W + (int)s;
-        const int ih = b_y + (int)r, iw = b_x + (int)s;
-        const bool ok = bj_valid && kk < kend &&
-                        (unsigned)ih < (unsigned)g.H &&
+        const int src = ub + (256 / BN) * i;
+        const int ih = b_y + __builtin_amdgcn_readlane(t_r, src);
+        const int iw = b_x + __builtin_amdgcn_readlane(t_s, src);
+        const bool ok = (unsigned)ih < (unsigned)g.H &&
                         (unsigned)iw < (unsigned)g.W;
-        rb[i] = ok ? to_f<T>(pb[b_base + soff]) : 0.f;
+        bo[i] = ok ? b_base_bytes + __builtin_amdgcn_readlane(t_off, src)
+                   : kOob;
       }
     } else if (MODE == CONV_BWD_DATA) {
+      const int kk = k0 + lane;
+      uint32_t k, rs, rr, ss;
+      bc.div_rcsc.divmod(kk, k, rs);
+      bc.div_sc.divmod(rs, rr, ss);
+      const int t_off = ((int)k * a.PQ - (int)rr * g.Q - (int)ss) * SZ;
+      const int t_r = kk < kend ? -(int)rr : kFar, t_s = -(int)ss;
+      const int t_a = ((grp * a.Kg + (int)k) * a.Cg * a.RS +
+                       (bc.r0 + g.stride_h * (int)rr) * g.S + bc.s0 +
+                       g.stride_w * (int)ss) * SZ;
+      const int m = m0 + tid % BM;
+      const int moff = m * a.RS * SZ;
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) {
+        const int src = ua + (256 / BM) * i;
+        ao[i] = (m < a.M && k0 + src < kend)
+                    ? moff + __builtin_amdgcn_readlane(t_a, src) : kOob;
+      }
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
-        const int kk = k0 + ub + (256 / BN) * i;
-        uint32_t k, rs, rr, ss;
-        bc.div_rcsc.divmod(kk, k, rs);
-        bc.div_sc.divmod(rs, rr, ss);
-        const int py = b_y - (int)rr, px = b_x - (int)ss;
-        const int soff = (int)k * a.PQ - (int)rr * g.Q - (int)ss;
-        const bool ok = bj_valid && kk < kend &&
-                        (unsigned)py < (unsigned)g.P &&
+        const int src = ub + (256 / BN) * i;
+        const int py = b_y + __builtin_amdgcn_readlane(t_r, src);
+        const int px = b_x + __builtin_amdgcn_readlane(t_s, src);
+        const bool ok = (unsigned)py < (unsigned)g.P &&
                         (unsigned)px < (unsigned)g.Q;
-        rb[i] = ok ? to_f<T>(pb[b_base + soff]) : 0.f;
+        bo[i] = ok ? b_base_bytes + __builtin_amdgcn_readlane(t_off, src)
+                   : kOob;
       }
     } else {
-      // reduction index kk = (n, p, q), one per thread and tile
+      // backward-weight B: reduction index kk = (n, p, q), one per thread
       const int kk = k0 + tid % BK;
-      const bool kv = kk < kend;
-      uint32_t n = 0, pq = 0, p = 0, q = 0;
-      if (kv) {
-        a.div_pq.divmod(kk, n, pq);
-        a.div_q.divmod(pq, p, q);
-      }
-      const int ih0 = p * g.stride_h, iw0 = q * g.stride_w;
-      const int base = (int)n * g.C * a.HW + ih0 * g.W + iw0;
+      uint32_t n, pq, p, q;
+      a.div_pq.divmod(kk, n, pq);
+      a.div_q.divmod(pq, p, q);
+      const int ih0 = kk < kend ? (int)p * g.stride_h : kFar;
+      const int iw0 = q * g.stride_w;
+      const int base = ((int)n - nb) * g.C * a.HW + (int)p * g.stride_h * g.W +
+                       iw0;
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
         const int ih = ih0 + bw_r[i], iw = iw0 + bw_s[i];
-        const bool ok = kv && (unsigned)ih < (unsigned)g.H &&
+        const bool ok = (unsigned)ih < (unsigned)g.H &&
                         (unsigned)iw < (unsigned)g.W;
-        rb[i] = ok ? to_f<T>(pb[base + bw_off[i]]) : 0.f;
+        bo[i] = ok ? (base + bw_off[i]) * SZ : kOob;
       }
     }
+  };
+
+  // phase 2: all loads of the tile back to back
+  auto issue_loads = [&]() {
+    constexpr bool A4 = V1 && MODE == CONV_BWD_DATA;
+    if (A4 || (MODE != CONV_BWD_DATA && a.a_vec)) {
+#pragma unroll
+      for (int i = 0; i < A_PER / 4; ++i) BufLd<T>::four(rA, ao[i], &ra[4 * i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_PER; ++i) ra[i] = BufLd<T>::one(rA, ao[i]);
+    }
+    if (MODE != CONV_BWD_WEIGHT && V1) {
+#pragma unroll
+      for (int i = 0; i < B_PER / 4; ++i) BufLd<T>::four(rB, bo[i], &rb[4 * i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) rb[i] = BufLd<T>::one(rB, bo[i]);
+    }
+  };
+
+  auto load_tiles = [&](int k0) {
+    plan_tiles(k0);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_loads();
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   auto store_tiles = [&](int buf) {
@@ -594,10 +680,10 @@ void launch_tile(ConvArgs &a, hipStream_t s) {
   a.nt = (a.Ngemm + BN - 1) / BN;
   dim3 grid;
   if (MODE == CONV_BWD_WEIGHT)
-    grid = dim3((unsigned)((int64_t)a.mt * a.nt * ((a.splits + 7) / 8) * 8), 1,
+    grid = dim3((unsigned)(((int64_t)a.mt * a.nt * a.splits + 7) / 8 * 8), 1,
                 a.g.groups);
   else
-    grid = dim3((unsigned)((int64_t)a.mt * ((a.nt + 7) / 8) * 8), a.splits,
+    grid = dim3((unsigned)(((int64_t)a.mt * a.nt + 7) / 8 * 8), a.splits,
                 a.g.groups * a.ncls);
   hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, BM, BN, BK, V1>), grid,
                      dim3(256), 0, s, a);
@@ -642,11 +728,25 @@ static bool geom_ok(const ConvGeom *g) {
 
 static size_t elem_size(int dtype) { return dtype == kF32 ? 4 : 2; }
 
+// A tile addresses its operands with 32-bit byte offsets from the first image
+// it touches: `span` consecutive images (and the whole filter) must fit 2 GB.
+static bool window_ok(int64_t image_elems, int64_t span, int64_t filter_elems,
+                      size_t sz) {
+  const int64_t lim = ((int64_t)1 << 31) - 1;
+  return image_elems * span * (int64_t)sz < lim &&
+         filter_elems * (int64_t)sz < lim;
+}
+
 int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                 const void *bias, void *y, hipStream_t s) {
   if (!geom_ok(g)) return -2;
   ConvArgs a = make_args(*g, CONV_FWD);
   a.a = w; a.b = x; a.out = y; a.bias = bias;
+  a.a_elems = (int64_t)g->K * a.Cg * a.RS;
+  a.b_elems = (int64_t)g->N * g->C * a.HW;
+  if (!window_ok((int64_t)g->C * a.HW, 128 / a.PQ + 2, a.a_elems,
+                 elem_size(dtype)))
+    return -2;
   const size_t bytes = (size_t)g->N * g->K * g->P * g->Q * elem_size(dtype);
   SA_DISPATCH_FLOAT(dtype, T, { launch_conv<T, CONV_FWD>(a, bytes, s); });
   return 0;
@@ -657,6 +757,15 @@ int sa_conv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
   if (!geom_ok(g)) return -2;
   ConvArgs base = make_args(*g, CONV_BWD_DATA);
   base.a = w; base.b = dy; base.out = dx;
+  base.a_elems = (int64_t)g->K * base.Cg * base.RS;
+  base.b_elems = (int64_t)g->N * g->K * base.PQ;
+  {
+    const int hc = std::max(1, g->H / g->stride_h);
+    const int wc = std::max(1, g->W / g->stride_w);
+    if (!window_ok((int64_t)g->K * base.PQ, 128 / (hc * wc) + 2, base.a_elems,
+                   elem_size(dtype)))
+      return -2;
+  }
   const size_t bytes = (size_t)g->N * g->C * g->H * g->W * elem_size(dtype);
   // one dense sub-problem per (h % sh, w % sw) class; classes no tap reaches
   // (filter smaller than the stride) stay zero
@@ -716,6 +825,11 @@ int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
   if (dtype != kF32) return -3;  // half types accumulate via a float buffer
   ConvArgs a = make_args(*g, CONV_BWD_WEIGHT);
   a.a = dy; a.b = x; a.out = dw;
+  a.a_elems = (int64_t)g->N * g->K * a.PQ;
+  a.b_elems = (int64_t)g->N * g->C * a.HW;
+  if (!window_ok(std::max((int64_t)g->K * a.PQ, (int64_t)g->C * a.HW),
+                 32 / a.PQ + 2, 0, sizeof(float)))
+    return -2;
   launch_conv<float, CONV_BWD_WEIGHT>(
       a, (size_t)g->K * a.Cg * a.RS * sizeof(float), s);
   return 0;

@@ -68,6 +68,7 @@ struct ConvArgs {
   int mt, nt;      // tile counts along M and N
   int a_vec;       // A rows may be read four reduction indices at a time
   int ncls;        // backward-data: stride classes in this launch
+  int tap_mask;    // filter has <= 63 taps: bounds tests use a per-pixel mask
   int64_t a_elems, b_elems;  // elements of the two operand tensors
   FastDiv div_rs, div_s, div_pq, div_q, div_hw, div_w;
   // Backward-data with stride (sh, sw) splits into sh * sw independent
@@ -277,6 +278,26 @@ conv_igemm_kernel(ConvArgs a) {
   if (!bj_valid) b_y = kFar;
   const int b_base_bytes = b_base * SZ;
 
+  // Filters of up to 63 taps: bit t of inv_mask tells whether tap t falls
+  // outside the image for this thread's pixel (bit 63 is always set and
+  // stands for "beyond the reduction range").  The per-element bounds test
+  // is then one 64-bit shift whose bit 0 is moved into the sign of the offset.
+  uint64_t inv_mask = ~0ull;
+  if (MODE == CONV_FWD && !V1 && a.tap_mask) {
+    for (int r = 0; r < g.R; ++r)
+      for (int s2 = 0; s2 < g.S; ++s2)
+        if ((unsigned)(b_y + r) < (unsigned)g.H &&
+            (unsigned)(b_x + s2) < (unsigned)g.W)
+          inv_mask &= ~(1ull << (r * g.S + s2));
+  }
+  if (MODE == CONV_BWD_DATA && !V1 && a.tap_mask) {
+    for (int r = 0; r < bc.Rc; ++r)
+      for (int s2 = 0; s2 < bc.Sc; ++s2)
+        if ((unsigned)(b_y - r) < (unsigned)g.P &&
+            (unsigned)(b_x - s2) < (unsigned)g.Q)
+          inv_mask &= ~(1ull << (r * bc.Sc + s2));
+  }
+
   float ra[A_PER], rb[B_PER];
   int ao[A_PER], bo[B_PER];
 
@@ -363,6 +384,16 @@ conv_igemm_kernel(ConvArgs a) {
       a.div_s.divmod(rs, r, s);
       const int t_off = ((int)c * a.HW + (int)r * g.W + (int)s) * SZ;
       const int t_r = kk < kend ? (int)r : kFar, t_s = (int)s;
+      if (a.tap_mask) {
+        const int t_rs = kk < kend ? (int)rs : 63;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+          const int src = ub + (256 / BN) * i;
+          const uint64_t out = inv_mask >> __builtin_amdgcn_readlane(t_rs, src);
+          bo[i] = (b_base_bytes + __builtin_amdgcn_readlane(t_off, src)) |
+                  (int)((uint32_t)out << 31);
+        }
+      } else
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
         const int src = ub + (256 / BN) * i;
@@ -391,6 +422,16 @@ conv_igemm_kernel(ConvArgs a) {
         ao[i] = (m < a.M && k0 + src < kend)
                     ? moff + __builtin_amdgcn_readlane(t_a, src) : kOob;
       }
+      if (a.tap_mask) {
+        const int t_rs = kk < kend ? (int)rs : 63;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+          const int src = ub + (256 / BN) * i;
+          const uint64_t out = inv_mask >> __builtin_amdgcn_readlane(t_rs, src);
+          bo[i] = (b_base_bytes + __builtin_amdgcn_readlane(t_off, src)) |
+                  (int)((uint32_t)out << 31);
+        }
+      } else
 #pragma unroll
       for (int i = 0; i < B_PER; ++i) {
         const int src = ub + (256 / BN) * i;
@@ -621,6 +662,7 @@ static ConvArgs make_args(const ConvGeom &g, int mode) {
   a.bias = nullptr;
   a.mt = a.nt = 1;
   a.ncls = 1;
+  a.tap_mask = a.RS <= 63;
   if (mode == CONV_FWD) {
     a.M = a.Kg; a.Ngemm = g.N * a.PQ; a.Kgemm = a.Cg * a.RS;
     a.a_vec = a.Kgemm % 4 == 0;
@@ -659,12 +701,14 @@ static inline bool use_big_tile(const ConvArgs &a) {
   return a.M >= 96 && a.Ngemm >= 96 && t128 >= 256;
 }
 
-// Split the reduction so that the launch has about kSplitTarget workgroups,
-// each keeping at least min_k reduction indices; results are then combined
-// with float atomics on a zero-filled output.
+// Split the reduction so that the launch has close to, but not more than,
+// kSplitTarget workgroups (what fits the chip at once: a second, nearly empty
+// round of workgroups would cost as much as the first), each keeping at least
+// min_k reduction indices; results are then combined with float atomics on a
+// zero-filled output.
 static void plan_splits(ConvArgs &a, int64_t tiles, int min_k) {
   int64_t splits = 1;
-  if (tiles < kSplitTarget) splits = (kSplitTarget + tiles - 1) / tiles;
+  if (tiles < kSplitTarget) splits = kSplitTarget / tiles;
   const int64_t max_splits = (a.Kgemm + min_k - 1) / min_k;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

@@ -304,6 +304,9 @@ CONV_CASES = [
     # stride 3: nine stride classes for backward-data, some without taps
     (2, 8, 13, 11, 12, 5, 5, 3, 2, 1),
     (2, 16, 9, 9, 8, 2, 2, 3, 0, 1),
+    # more than 63 taps: compare-based bounds tests; 16 stride classes
+    (1, 4, 12, 12, 8, 9, 9, 1, 4, 1),
+    (1, 3, 35, 35, 8, 11, 11, 4, 2, 1),
     # few tiles, long reduction: split across workgroups in every pass
     (2, 512, 7, 7, 512, 3, 3, 1, 1, 1),
 ]

@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16"])
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--bucket", type=int, default=8 * 1024 * 1024,
+                    help="elements per all-reduce fusion bucket")
     ap.add_argument("--verbosity", type=int, default=0)
     args = ap.parse_args()
 
@@ -49,10 +51,11 @@ def main():
             print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world),
                   file=sys.stderr)
 
-    sgd = opt.SGD(lr=0.1, momentum=0.9, weight_decay=1e-5)
-    if world > 1:
-        sgd = opt.DistOpt(sgd)
-        local_rank = sgd.local_rank
+    # the reference benchmark always trains through DistOpt; a lone rank's
+    # all-reduce is the identity
+    sgd = opt.DistOpt(opt.SGD(lr=0.1, momentum=0.9, weight_decay=1e-5))
+    sgd.threshold = args.bucket
+    local_rank = sgd.local_rank
     dev = device.create_cuda_gpu_on(local_rank)
     dev.SetVerbosity(args.verbosity)
     dev.SetSkipIteration(5)
@@ -74,7 +77,7 @@ def main():
                   sequential=world > 1)
 
     def sync_all():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -87,7 +90,7 @@ def main():
         _, loss = model(tx, ty, 'plain', None)
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev.torch_device,
                          dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -122,7 +125,7 @@ def main():
         }), flush=True)
         if args.verbosity > 0:
             dev.PrintTimeProfiling()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -293,6 +293,44 @@ class CpuMath(object):
         dtable.index_add_(0, idx.reshape(-1).long(),
                           grad.reshape(-1, dtable.shape[1]))
 
+    # ---- collectives support (reference src/io/communicator.cc) ----------------------------
+    def pack_plan(self, views):
+        offs, off = [], 0
+        for v in views:
+            offs.append(off)
+            off += v.numel()
+        return offs
+
+    def pack(self, plan, views, bucket):
+        for off, v in zip(plan, views):
+            bucket[off:off + v.numel()].copy_(v)
+
+    def unpack(self, plan, bucket, views, scale):
+        for off, v in zip(plan, views):
+            src = bucket[off:off + v.numel()]
+            v.copy_(src if scale == 1.0 else src.to(torch.float32) * scale)
+
+    def sparsify_threshold(self, x, thr):
+        idx = torch.nonzero(x.abs() >= thr).flatten().to(torch.int32)
+        n = x.numel()
+        vals = torch.zeros(n, dtype=torch.float32)
+        full = torch.zeros(n, dtype=torch.int32)
+        vals[:idx.numel()] = x[idx.long()]
+        full[:idx.numel()] = idx
+        return vals, full, torch.tensor([idx.numel()], dtype=torch.int32)
+
+    def topk_abs(self, x, k):
+        _, idx = torch.topk(x.abs(), k)
+        return x[idx].contiguous(), idx.to(torch.int32)
+
+    def scatter_add_sparse(self, vals, idx, cnt, dense):
+        c = vals.numel() if cnt is None else min(int(cnt.item()), vals.numel())
+        dense.index_add_(0, idx[:c].long(), vals[:c])
+
+    def scatter_sub(self, vals, idx, cnt, dense):
+        c = vals.numel() if cnt is None else min(int(cnt.item()), vals.numel())
+        dense.index_add_(0, idx[:c].long(), -vals[:c])
+
     # ---- fused optimiser step --------------------------------------------------------------------------
     def sgd_update(self, p, g, buf, lr, momentum, dampening, weight_decay,
                    nesterov, scale):

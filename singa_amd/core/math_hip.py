@@ -526,6 +526,60 @@ class HipMath(object):
     def scatter_add_rows(self, grad, idx, dtable):
         self.index_add(grad.reshape(-1, dtable.shape[1]), 0, idx, dtable)
 
+    # ---- collectives support (reference src/io/communicator.cc) ----------------------------
+    def pack_plan(self, views):
+        """Device table of (pointer, offset, count) rows for the multi-tensor
+        pack / unpack kernels."""
+        rows, off = [], 0
+        for v in views:
+            rows.append([v.data_ptr(), off, v.numel()])
+            off += v.numel()
+        table = torch.tensor(rows, dtype=torch.int64).to(self.dev.torch_device)
+        return (table, len(rows), off)
+
+    def pack(self, plan, views, bucket):
+        table, n, total = plan
+        self.k.pack(_code(views[0]), _code(bucket), table.data_ptr(), n,
+                    bucket.data_ptr(), total, self._s())
+
+    def unpack(self, plan, bucket, views, scale):
+        table, n, total = plan
+        self.k.unpack(_code(bucket), _code(views[0]), table.data_ptr(), n,
+                      bucket.data_ptr(), total, float(scale), self._s())
+
+    def sparsify_threshold(self, x, thr):
+        """(values, indices, count) of the entries with |x| >= thr, compacted
+        on the device; buffers hold up to x.numel() entries."""
+        n = x.numel()
+        vals = self._tmp(n)
+        idx = self._tmp(n, torch.int32)
+        cnt = self._tmp(1, torch.int32)
+        self.k.sparsify_threshold(x.data_ptr(), float(thr), vals.data_ptr(),
+                                  idx.data_ptr(), cnt.data_ptr(), n, n,
+                                  self._s())
+        return vals, idx, cnt
+
+    def topk_abs(self, x, k):
+        """The k entries of largest magnitude.  Selection uses the tensor
+        library's radix select; gathering the signed values is ours."""
+        _, idx = torch.topk(x.abs(), k)
+        idx32 = idx.to(torch.int32)
+        vals = self._tmp(k)
+        self.k.index_select(0, x.data_ptr(), idx32.data_ptr(), vals.data_ptr(),
+                            1, x.numel(), k, 1, self._s())
+        return vals, idx32
+
+    def scatter_add_sparse(self, vals, idx, cnt, dense):
+        self.k.scatter_add_sparse(vals.data_ptr(), idx.data_ptr(),
+                                  cnt.data_ptr() if cnt is not None else 0,
+                                  vals.numel(), dense.data_ptr(), dense.numel(),
+                                  self._s())
+
+    def scatter_sub(self, vals, idx, cnt, dense):
+        neg = self._tmp(vals.numel())
+        self.binary_scalar("mul", vals, -1.0, neg)
+        self.scatter_add_sparse(neg, idx, cnt, dense)
+
     # ---- fused optimiser step -------------------------------------------------------------------------------------
     def sgd_update(self, p, g, buf, lr, momentum, dampening, weight_decay,
                    nesterov, scale):

@@ -398,9 +398,13 @@ class DistOpt(object):
         self.world_size = self.communicator.world_size
         self.local_rank = self.communicator.local_rank
         self.global_rank = self.communicator.global_rank
+        # elements per fusion bucket when the caller does not pass one; ring
+        # all-reduce over xGMI favours fewer, larger buckets than the
+        # reference's 2M-element default
+        self.threshold = 2097152
 
     def __call__(self, loss):
-        self.backward_and_update(loss)
+        self.backward_and_update(loss, self.threshold)
 
     def update(self, param, grad):
         """Average the all-reduced gradient and apply the wrapped optimizer.

@@ -1,9 +1,390 @@
-"""placeholder, replaced by the communicator milestone"""
+"""Collective communication for synchronous data-parallel training.
+
+One process drives one GPU; the collectives are RCCL's (``torch.distributed``
+backend ``"nccl"`` on ROCm) over xGMI, or gloo between CPU ranks.  The
+interface is the reference's ``Communicator`` (include/singa/io/communicator.h
+:76-152, src/io/communicator.cc) so that ``opt.DistOpt`` and user code carry
+over, but the data path is laid out for MI355X:
+
+* a fusion bucket is packed by ONE multi-tensor kernel into a flat buffer,
+  all-reduced in place, and unpacked by one kernel -- the reference issues a
+  ``cudaMemcpyAsync`` per tensor each way and needs a separate receive buffer;
+* fp16-on-the-wire converts inside the pack / unpack kernels instead of in
+  separate conversion passes;
+* pack, collective and unpack run on three side streams chained by events, so
+  a bucket's all-reduce overlaps with the rest of the backward pass on the
+  compute stream;
+* sparsified exchange selects, compacts and scatter-adds on the device with a
+  single host read (the largest non-zero count) per exchange;
+* every step is recorded on the device graph as a ``Dist_*`` node.  Under
+  hipGraph replay these nodes run eagerly between the captured segments: while
+  the graph is being captured their bodies only bind their operands.
+
+Ring collectives over xGMI are bound by the per-link rate, not by a switch:
+large buckets (tens of MB) amortise the ring's latency better than the
+reference's 8 MB default, which is why ``bench.py`` raises DistOpt's threshold.
+"""
+import math
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+
+from ..core import dtypes
+from ..core import tensor_core as tc
+
+
+def _free_port():
+    s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
 
 
 class NcclIdHolder(object):
-    pass
+    """Rendezvous token made by the parent process before it starts the ranks
+    (reference communicator.h:69-74 wraps an ``ncclUniqueId``).  Here it is
+    the TCP address the ranks meet at."""
+
+    def __init__(self, addr="127.0.0.1", port=None):
+        self.addr = addr
+        self.port = int(port) if port is not None else _free_port()
+
+    @property
+    def init_method(self):
+        return "tcp://%s:%d" % (self.addr, self.port)
+
+
+def _env_int(names, default):
+    for n in names:
+        v = os.environ.get(n)
+        if v not in (None, ""):
+            return int(v)
+    return default
 
 
 class Communicator(object):
-    pass
+    """``Communicator(buffSize)`` takes rank / world size from the launcher's
+    environment (torchrun, mpiexec, srun); ``Communicator(local_rank,
+    world_size, holder, buffSize)`` is for ranks started with
+    multiprocessing."""
+
+    def __init__(self, *args):
+        if len(args) == 1:
+            self.max_size = int(args[0])
+            self.world_size = _env_int(
+                ["WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", "PMI_SIZE",
+                 "SLURM_NTASKS"], 1)
+            self.global_rank = _env_int(
+                ["RANK", "OMPI_COMM_WORLD_RANK", "PMI_RANK", "SLURM_PROCID"], 0)
+            self.local_rank = _env_int(
+                ["LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK",
+                 "MPI_LOCALRANKID", "SLURM_LOCALID"], self.global_rank)
+            init_method = "tcp://%s:%s" % (
+                os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                os.environ.get("MASTER_PORT", "29500"))
+        elif len(args) == 4:
+            self.local_rank, self.world_size, holder, self.max_size = (
+                int(args[0]), int(args[1]), args[2], int(args[3]))
+            self.global_rank = self.local_rank
+            init_method = holder.init_method
+        else:
+            raise TypeError("Communicator(buffSize) or Communicator("
+                            "local_rank, world_size, nccl_id, buffSize)")
+        self._gpu = torch.cuda.is_available()
+        self._owns_group = False
+        # SINGA_DIST_FORCE=1 builds the process group even for a single rank
+        # (exercises the RCCL path on a one-GPU machine)
+        force = os.environ.get("SINGA_DIST_FORCE", "0") == "1"
+        if (self.world_size > 1 or force) and not dist.is_initialized():
+            if self._gpu:
+                torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(
+                backend="nccl" if self._gpu else "gloo",
+                init_method=init_method, rank=self.global_rank,
+                world_size=self.world_size)
+            self._owns_group = True
+        # without a process group a lone rank's all-reduce is the identity
+        self._active = dist.is_initialized()
+        self._dev = None          # device of the last synchronised tensors
+        self._blocks = []         # their blocks: what wait() orders against
+        self._buffers = {}        # (slot, dtype) -> flat bucket
+        self._slot = 0            # bucket index within the iteration
+        self._works = []          # outstanding gloo / RCCL work handles
+
+    # ------------------------------------------------------------------ helpers
+    def __del__(self):
+        try:
+            if self._owns_group and dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+
+    def _bucket(self, dev, slot, n, tdtype):
+        key = (slot, tdtype)
+        buf = self._buffers.get(key)
+        if buf is None or buf.numel() < n or buf.device != dev.torch_device:
+            buf = torch.empty(max(int(n), 1), dtype=tdtype,
+                              device=dev.torch_device)
+            self._buffers[key] = buf
+        return buf[:n]
+
+    def _next_slot(self):
+        s = self._slot
+        self._slot += 1
+        return s
+
+    def _remember(self, dev, tensors):
+        self._dev = dev
+        seen = set(id(b) for b in self._blocks)
+        for t in tensors:
+            if id(t.block()) not in seen:
+                self._blocks.append(t.block())
+                seen.add(id(t.block()))
+
+    def _all_reduce(self, flat):
+        if self._active:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+    def _all_gather(self, out_list, flat):
+        if self._active:
+            dist.all_gather(out_list, flat)
+        else:
+            out_list[0].copy_(flat)
+
+    @staticmethod
+    def _share(*tensors):
+        """Tell the caching allocator that temporaries made on another side
+        stream are also in use on the current one."""
+        for t in tensors:
+            if t is not None and t.is_cuda:
+                t.record_stream(torch.cuda.current_stream(t.device))
+
+    @staticmethod
+    def _streams(dev):
+        """(pack, collective, unpack) streams, or None on the host."""
+        if dev.lang() == 0:
+            return None
+        return dev.stream_pack, dev.stream_comm, dev.stream_unpack
+
+    def _run_pipeline(self, dev, stages):
+        """Run ``stages`` = [(which_stream, fn), ...] one after another, each
+        on its side stream, the first ordered after the compute stream.  The
+        last stream's completion is what ``wait`` joins."""
+        st = self._streams(dev)
+        if st is None:
+            for _, fn in stages:
+                fn()
+            return
+        names = {"pack": st[0], "comm": st[1], "unpack": st[2]}
+        main = torch.cuda.current_stream(dev.torch_device)
+        prev = main
+        for which, fn in stages:
+            s = names[which]
+            if s is not prev:
+                s.wait_stream(prev)
+            with torch.cuda.stream(s):
+                fn()
+            prev = s
+
+    # ----------------------------------------------------------------- all-reduce
+    def synch(self, t):
+        """In-place all-reduce (sum) of one tensor.  communicator.cc:304-328."""
+        dev = t.device()
+        self._remember(dev, [t])
+        if not self._active:
+            return
+
+        def body(x):
+            if dev.phase == "capture":
+                return
+            flat = x.flat()[:x.Size()]
+            self._run_pipeline(dev, [("comm", lambda: self._all_reduce(flat))])
+
+        tc._submit(dev, "Dist_s_synch_allreduce", body, [], [t])
+
+    def fusedSynch(self, tensors, send=True):
+        """All-reduce a bucket of tensors through one flat buffer.  Calls with
+        ``send=False`` only announce tensors of the bucket; the call with
+        ``send=True`` carries the whole bucket.  communicator.cc:212-302."""
+        self._fused(list(tensors), send, None, "fusedSynch")
+
+    def synchHalf(self, t):
+        """All-reduce one fp32 tensor with fp16 on the wire.
+        communicator.cc:416-467."""
+        assert t.data_type() == dtypes.kFloat32, (
+            "This function is only available for input tensor precision 32 "
+            "bit, which are converted into 16 bits before transmit")
+        self._fused([t], True, torch.float16, "synchHalf")
+
+    def fusedSynchHalf(self, tensors, send=True):
+        """Bucketed all-reduce of fp32 tensors with fp16 on the wire.
+        communicator.cc:330-414."""
+        tensors = list(tensors)
+        assert len(tensors) > 0
+        assert tensors[0].data_type() == dtypes.kFloat32, (
+            "This function is only available for input tensor precision 32 "
+            "bit, which are converted into 16 bits before transmit")
+        self._fused(tensors, send, torch.float16, "fusedSynchHalf")
+
+    def _fused(self, tensors, send, wire, tag):
+        assert len(tensors) > 0
+        dev = tensors[0].device()
+        self._remember(dev, tensors)
+        if not send or not self._active:
+            return
+        slot = self._next_slot()
+        total = sum(t.Size() for t in tensors)
+        state = {}
+
+        def body(*ts):
+            tdt = dtypes.to_torch(ts[0].data_type())
+            wdt = wire if wire is not None else tdt
+            views = [x.flat()[:x.Size()] for x in ts]
+            key = tuple(v.data_ptr() for v in views)
+            if state.get("key") != key:
+                # operand addresses are stable under graph replay: the
+                # pack table is built once
+                state["key"] = key
+                state["plan"] = dev.math.pack_plan(views)
+            if dev.phase == "capture":
+                return
+            bucket = self._bucket(dev, slot, total, wdt)
+            plan = state["plan"]
+            self._run_pipeline(dev, [
+                ("pack", lambda: dev.math.pack(plan, views, bucket)),
+                ("comm", lambda: self._all_reduce(bucket)),
+                ("unpack", lambda: dev.math.unpack(plan, bucket, views, 1.0)),
+            ])
+
+        tc._submit(dev, "Dist_c1sc2_%s" % tag, body, [], tensors)
+
+    # ------------------------------------------------------------- sparsification
+    def sparsification(self, t, *args):
+        """``sparsification(t, [accumulation,] threshold, topK)``: exchange only
+        the large entries of ``t`` (|x| >= threshold, or the ceil(threshold *
+        n) entries of largest magnitude), summing them over the ranks; with an
+        accumulation tensor the entries not sent are carried over to the next
+        call.  communicator.cc:469-530, 619-807."""
+        acc, thr, topk = self._spars_args(args)
+        self._sparse([t], acc, thr, topk, "sparsification")
+
+    def fusedSparsification(self, tensors, *args):
+        acc, thr, topk = self._spars_args(args)
+        self._sparse(list(tensors), acc, thr, topk, "fusedSparsification")
+
+    @staticmethod
+    def _spars_args(args):
+        if len(args) == 3:
+            return args[0], float(args[1]), bool(args[2])
+        if len(args) == 2:
+            return None, float(args[0]), bool(args[1])
+        raise TypeError("expected ([accumulation,] sparsThreshold, topK)")
+
+    def _sparse(self, tensors, acc, thr, topk, tag):
+        assert len(tensors) > 0
+        dev = tensors[0].device()
+        assert tensors[0].data_type() == dtypes.kFloat32, \
+            "sparsified exchange supports only fp32"
+        self._remember(dev, tensors + ([acc] if acc is not None else []))
+        slot = self._next_slot()
+        total = sum(t.Size() for t in tensors)
+        state = {}
+        W = self.world_size
+
+        def body(*ts):
+            if acc is not None:
+                a, ts = ts[-1], ts[:-1]
+            else:
+                a = None
+            views = [x.flat()[:x.Size()] for x in ts]
+            key = tuple(v.data_ptr() for v in views)
+            if state.get("key") != key:
+                state["key"] = key
+                state["plan"] = dev.math.pack_plan(views)
+            if dev.phase == "capture":
+                return
+            m = dev.math
+            plan = state["plan"]
+            send = self._bucket(dev, slot, total, torch.float32)
+            av = a.flat()[:total] if a is not None else None
+            box = {}
+
+            def select():
+                m.pack(plan, views, send)
+                if av is not None:
+                    m.axpy(1.0, av, send)          # add what was held back
+                if topk:
+                    k = int(math.ceil(thr * total))
+                    vals, idx = m.topk_abs(send, k)
+                    cnt = None
+                else:
+                    vals, idx, cnt = m.sparsify_threshold(send, thr)
+                if av is not None:
+                    # residual = everything that is not sent
+                    m.copy(send, av)
+                    m.scatter_sub(vals, idx, cnt, av)
+                box["sel"] = (vals, idx, cnt)
+
+            def exchange():
+                vals, idx, cnt = box["sel"]
+                self._share(vals, idx, cnt)
+                if cnt is None:
+                    nmax = vals.numel()
+                    counts = None
+                else:
+                    # ranks select different numbers of entries: agree on the
+                    # largest, the one host read of the exchange
+                    allc = [torch.empty_like(cnt) for _ in range(W)]
+                    self._all_gather(allc, cnt)
+                    counts = torch.cat(allc)
+                    nmax = int(min(int(counts.max().item()), total))
+                    counts = [counts[i:i + 1] for i in range(W)]
+                nmax = max(nmax, 1)
+                gi = [torch.empty(nmax, dtype=torch.int32,
+                                  device=dev.torch_device) for _ in range(W)]
+                gv = [torch.empty(nmax, dtype=torch.float32,
+                                  device=dev.torch_device) for _ in range(W)]
+                self._all_gather(gi, idx[:nmax].contiguous())
+                self._all_gather(gv, vals[:nmax].contiguous())
+                box["gathered"] = (gi, gv, counts, nmax)
+
+            def combine():
+                gi, gv, counts, nmax = box["gathered"]
+                self._share(*(gi + gv + (counts or [])))
+                m.fill(send, 0.0)
+                for r in range(W):
+                    m.scatter_add_sparse(gv[r], gi[r],
+                                         counts[r] if counts else None, send)
+                m.unpack(plan, send, views, 1.0)
+
+            self._run_pipeline(dev, [("pack", select), ("comm", exchange),
+                                     ("unpack", combine)])
+
+        ops = list(tensors) + ([acc] if acc is not None else [])
+        tc._submit(dev, "Dist_c1c2_%s" % tag, body, [], ops)
+
+    # ------------------------------------------------------------------------ wait
+    def wait(self):
+        """Order the compute stream after everything the communicator has in
+        flight.  communicator.cc:169-186."""
+        if self._dev is None:
+            return
+        dev = self._dev
+        blocks = self._blocks
+        self._blocks = []
+        self._slot = 0
+
+        def join():
+            if dev.phase == "capture":
+                return
+            st = self._streams(dev)
+            if st is None:
+                return
+            main = torch.cuda.current_stream(dev.torch_device)
+            for s in st:
+                main.wait_stream(s)
+
+        dev.Exec(join, blocks, blocks, "Dist_wait")

@@ -86,6 +86,12 @@ def backward(y, dy=None):
     else:
         dy = float(dy)
 
+    if isinstance(dy, float) and not getattr(y.creator, "takes_scalar_dy",
+                                             False):
+        # only the loss operators accept a python float as upstream gradient
+        g0 = CTensor(list(y.shape), y.device, y.dtype)
+        g0.SetFloatValue(dy)
+        dy = g0
     ready = deque([(y.creator, (dy,))])
     not_ready = {}
 
@@ -1148,6 +1154,7 @@ def softmax(x, axis=1):
 
 class BinaryCrossEntropy(Operator):
     """-mean_batch sum(t log(x + eps) + (1 - t) log(1 - x + eps))."""
+    takes_scalar_dy = True
 
     def __init__(self, t):
         super(BinaryCrossEntropy, self).__init__()
@@ -1179,6 +1186,7 @@ def binary_cross_entropy(x, t):
 
 class CrossEntropy(Operator):
     """-mean_batch sum(t * log(x)) for probabilities x and dense targets t."""
+    takes_scalar_dy = True
 
     def __init__(self, t):
         super(CrossEntropy, self).__init__()
@@ -1206,6 +1214,7 @@ def cross_entropy(x, t):
 
 class RankingLoss(Operator):
     """mean(max(0, M - pos + neg))."""
+    takes_scalar_dy = True
 
     def __init__(self, M=0.2):
         super().__init__()
@@ -1224,7 +1233,7 @@ class RankingLoss(Operator):
         gt_zero = self.inputs[0]
         dpos = singa.MultFloat(gt_zero, -1.0 / gt_zero.Size())
         dneg = singa.MultFloat(gt_zero, 1.0 / gt_zero.Size())
-        return dpos, dneg
+        return _apply_dy(dpos, dy), _apply_dy(dneg, dy)
 
 
 def ranking_loss(pos, neg, M=0.2):
@@ -1236,8 +1245,8 @@ def ranking_loss(pos, neg, M=0.2):
 class SoftMaxCrossEntropy(Operator):
     """Mean soft-max cross-entropy of logits ``x`` against integer labels or a
     dense target distribution.  One fused kernel forward (soft-max, log,
-    label pick, batch mean) and one backward ((p - t) / batch); like the
-    reference, the upstream gradient is taken to be 1."""
+    label pick, batch mean) and one backward ((p - t) / batch)."""
+    takes_scalar_dy = True
 
     def __init__(self, t):
         super(SoftMaxCrossEntropy, self).__init__()
@@ -1248,7 +1257,7 @@ class SoftMaxCrossEntropy(Operator):
         return loss
 
     def backward(self, dy=1.0):
-        return singa.SoftmaxCrossEntropyFusedBwd(self.p, self.t)
+        return _apply_dy(singa.SoftmaxCrossEntropyFusedBwd(self.p, self.t), dy)
 
 
 def softmax_cross_entropy(x, t):
@@ -1260,6 +1269,7 @@ def softmax_cross_entropy(x, t):
 
 
 class MeanSquareError(Operator):
+    takes_scalar_dy = True
 
     def __init__(self, t):
         super(MeanSquareError, self).__init__()
@@ -2202,9 +2212,10 @@ def pooling_2d(handle, x, odd_padding=(0, 0, 0, 0)):
 
 
 class Dropout(Operator):
-    """output = scale * data * mask.  ``scale`` reproduces the reference's
-    expression ``1 / 1 - ratio`` (= 1 - ratio), see reference
-    python/singa/autograd.py:3968."""
+    """output = scale * data * mask with scale = 1 / (1 - ratio), as the
+    reference documents it (python/singa/autograd.py:3939-3943; its code
+    computes ``1 / 1 - ratio``, an operator-precedence slip not repeated
+    here)."""
 
     def __init__(self, seed=0, ratio=0.5):
         super(Dropout, self).__init__()
@@ -2217,7 +2228,7 @@ class Dropout(Operator):
             x.device().SetRandSeed(self.seed)
             self.init_seed = True
         if training:
-            self.scale = 1 / 1 - self.ratio
+            self.scale = 1.0 / (1.0 - self.ratio)
             self.mask = CTensor(list(x.shape()), x.device(), x.data_type())
             singa.Bernoulli(1 - self.ratio, self.mask)
             x = singa.MultFloat(singa.__mul__(self.mask, x), self.scale)

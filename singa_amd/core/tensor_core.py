@@ -324,7 +324,7 @@ class Tensor(object):
 
     def L2(self):
         n = max(self.Size(), 1)
-        return self._dev.math.nrm2(self.view()) / float(np.sqrt(n))
+        return self._dev.math.nrm2(self.view()) / n
 
     def l2(self):
         return self.L2()
@@ -580,6 +580,10 @@ def _scalar(name, op):
         return ret
 
     def fn_new(x, s):
+        # an int tensor combined with a float scalar gives a float tensor
+        # (reference tensor.cc, GenBinaryScalarFunction)
+        if not dtypes.is_float(x._dtype):
+            x = x.AsType(kFloat32)
         return fn_ret(x, s, Tensor(x._shape, x._dev, x._dtype))
     fn_new.__name__ = name
     return fn_new, fn_ret
@@ -843,6 +847,10 @@ def MultWithRet(A, B, C):
 
 
 def Mult(A, B):
+    if B.nDim() == 1:
+        out = Tensor([A._shape[0]], A._dev, A._dtype)
+        MultWithScale(1.0, A, B, 0.0, out)
+        return out
     A_ = Broadcast(A, B._shape, 2)
     B_ = Broadcast(B, A._shape, 2)
     s = list(A_._shape)

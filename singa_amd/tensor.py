@@ -20,16 +20,24 @@ float16 = singa.kFloat16
 float32 = singa.kFloat32
 bfloat16 = singa.kBFloat16
 CTensor = singa.Tensor
+_NP2DTYPE = {np.float32: float32, np.float64: float32, np.float16: float16,
+             np.int32: int32, np.int64: int32}
 
 
 class Tensor(object):
     tensor_count = 0
 
-    def __init__(self, shape=(), device=None, dtype=float32, data=None,
+    def __init__(self, shape=(), device=None, dtype=None, data=None,
                  requires_grad=True, stores_grad=False, creator=None,
                  name=None):
         if device is None:
             device = get_default_device()
+        if dtype is None:
+            # a numpy array brings its own element type (float64 / int64 are
+            # narrowed to the 32-bit types the kernels support)
+            dtype = float32
+            if isinstance(data, np.ndarray):
+                dtype = _NP2DTYPE.get(data.dtype.type, float32)
         if isinstance(data, np.ndarray):
             self.data = CTensor(list(data.shape), device, dtype)
             copy_from_numpy(self.data, data)

@@ -25,3 +25,21 @@ def gpu_dev():
 def cpu_dev():
     from singa_amd import device
     return device.get_default_device()
+
+
+def _dev_params():
+    return ["cpu", pytest.param("gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=_dev_params())
+def dev(request):
+    """Every test taking ``dev`` runs on the host and, under ``-m gpu``, on
+    the MI355X through the HIP kernels."""
+    from singa_amd import device
+    if request.param == "cpu":
+        return device.get_default_device()
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = device.create_cuda_gpu_on(0)
+    return d

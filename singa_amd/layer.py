@@ -210,7 +210,9 @@ class Linear(Layer):
             self.bias = bias
 
     def initialize(self, x):
-        self.in_features = x.shape[1]
+        # features are the last axis (2-d input as in the reference, or a
+        # batched (..., in_features) input)
+        self.in_features = x.shape[-1]
         w_shape = (self.in_features, self.out_features)
         b_shape = (self.out_features,)
         self.W = Tensor(shape=w_shape, dtype=x.dtype, requires_grad=True,
@@ -231,9 +233,9 @@ class Linear(Layer):
         else:
             self.device_check(x, self.W)
             self.dtype_check(x, self.W)
-        assert x.shape[1] == self.W.shape[0], (
+        assert x.shape[-1] == self.W.shape[0], (
             "Linear layer expects input features size %d received %d" %
-            (self.W.shape[0], x.shape[1]))
+            (self.W.shape[0], x.shape[-1]))
         y = autograd.matmul(x, self.W)
         if self.bias:
             y = autograd.add_bias(y, self.b, axis=0)
@@ -565,7 +567,15 @@ class Pooling2d(Layer):
         self.is_max = is_max
         self.pad_mode = pad_mode
 
+    @staticmethod
+    def _as_4d(x):
+        """(N, C, L) inputs of the 1-d poolings are pooled as (N, C, 1, L)."""
+        if len(x.shape) == 3:
+            return autograd.reshape(x, (x.shape[0], x.shape[1], 1, x.shape[2]))
+        return x
+
     def initialize(self, x):
+        x = self._as_4d(x)
         if self.pad_mode in ("SAME_UPPER", "SAME_LOWER"):
             pad, self.odd_padding = utils.get_padding_shape(
                 self.pad_mode, x.shape[2:], self.kernel_size, self.stride)
@@ -579,6 +589,10 @@ class Pooling2d(Layer):
                                           self.padding, self.is_max)
 
     def forward(self, x):
+        if len(x.shape) == 3:
+            y = autograd.pooling_2d(self.handle, self._as_4d(x),
+                                    self.odd_padding)
+            return autograd.reshape(y, (y.shape[0], y.shape[1], y.shape[3]))
         return autograd.pooling_2d(self.handle, x, self.odd_padding)
 
 

@@ -224,8 +224,15 @@ PYBIND11_MODULE(_rt, m) {
   m.def("LogToStderr", &LogToStderr);
   m.def("SetStderrLogging", &SetStderrLogging);
   m.def("SetLogDestination", &SetLogDestination);
-  m.def("Log", &LogMessage, py::arg("severity"), py::arg("msg"),
-        py::arg("file") = "python", py::arg("line") = 0);
+  // severity 3 (FATAL) logs and then raises, like LOG(FATAL) in native code
+  m.def("Log",
+        [](int severity, const std::string &msg, const std::string &file,
+           int line) {
+          LogMessage(severity, msg, file, line);
+          if (severity >= 3) throw std::runtime_error(msg);
+        },
+        py::arg("severity"), py::arg("msg"), py::arg("file") = "python",
+        py::arg("line") = 0);
 
   // ---- channel ------------------------------------------------------------
   py::class_<Channel>(m, "Channel")

@@ -1,0 +1,238 @@
+"""Communicator and DistOpt with two ranks over gloo on the host (the collective
+calls are the ones RCCL serves on the GPUs).  Pattern of the reference's
+test/python/test_dist.py: every rank contributes known values and checks the
+reduced result; plus end-to-end equivalence of 2-rank data-parallel training
+with single-process training on the concatenated batch.
+"""
+import os
+import sys
+import traceback
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _spawn(fn, world=2, args=()):
+    sys.path.insert(0, ROOT)
+    from singa_amd.parallel.communicator import _free_port
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q, args))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = {}
+    for _ in range(world):
+        r, ok, payload = q.get(timeout=180)
+        assert ok, "rank %d failed:\n%s" % (r, payload)
+        results[r] = payload
+    for p in procs:
+        p.join(60)
+    return results
+
+
+def _entry(fn, rank, world, port, q, args):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["CUDA_VISIBLE_DEVICES"] = ""
+        from singa_amd import singa_wrap as singa
+        holder = singa.NcclIdHolder(port=port)
+        out = fn(rank, world, holder, *args)
+        q.put((rank, True, out))
+    except Exception:
+        q.put((rank, False, traceback.format_exc()))
+
+
+# ------------------------------------------------------------ raw collectives
+def _collectives(rank, world, holder):
+    from singa_amd import singa_wrap as singa, tensor
+    comm = singa.Communicator(rank, world, holder, 1 << 20)
+    out = {}
+    t = tensor.from_numpy(np.full((3, 4), rank + 1.0, np.float32))
+    comm.synch(t.data)
+    comm.wait()
+    out["synch"] = tensor.to_numpy(t)
+    a = tensor.from_numpy(np.arange(6, dtype=np.float32) * (rank + 1))
+    b = tensor.from_numpy(np.ones((2, 2), np.float32) * (rank + 1))
+    comm.fusedSynch([a.data], False)
+    comm.fusedSynch([b.data], False)
+    comm.fusedSynch([a.data, b.data], True)
+    comm.wait()
+    out["fused"] = (tensor.to_numpy(a), tensor.to_numpy(b))
+    c = tensor.from_numpy(np.arange(6, dtype=np.float32) * (rank + 1))
+    comm.synchHalf(c.data)
+    comm.wait()
+    out["half"] = tensor.to_numpy(c)
+    d = tensor.from_numpy(np.arange(4, dtype=np.float32) + rank)
+    e = tensor.from_numpy(np.ones(3, np.float32) * (rank + 2))
+    comm.fusedSynchHalf([d.data, e.data], True)
+    comm.wait()
+    out["fused_half"] = (tensor.to_numpy(d), tensor.to_numpy(e))
+    base = np.array([0.1, -2.0, 0.5, 3.0, -0.2, 1.0], np.float32) * (rank + 1)
+    g = tensor.from_numpy(base.copy())
+    acc = tensor.from_numpy(np.zeros(6, np.float32))
+    comm.sparsification(g.data, acc.data, 1.5, False)
+    comm.wait()
+    out["thr"] = (tensor.to_numpy(g), tensor.to_numpy(acc))
+    g = tensor.from_numpy(base.copy())
+    comm.fusedSparsification([g.data], 0.34, True)
+    comm.wait()
+    out["topk"] = tensor.to_numpy(g)
+    g1 = tensor.from_numpy(base[:2].copy())
+    g2 = tensor.from_numpy(base[2:].copy())
+    acc = tensor.from_numpy(np.zeros(6, np.float32))
+    comm.fusedSparsification([g1.data, g2.data], acc.data, 0.34, True)
+    comm.wait()
+    out["topk_acc"] = (tensor.to_numpy(g1), tensor.to_numpy(g2),
+                       tensor.to_numpy(acc))
+    return out
+
+
+def test_collectives_two_ranks():
+    res = _spawn(_collectives)
+    base = np.array([0.1, -2.0, 0.5, 3.0, -0.2, 1.0], np.float32)
+    for r in (0, 1):
+        o = res[r]
+        np.testing.assert_array_equal(o["synch"], np.full((3, 4), 3.0))
+        np.testing.assert_array_equal(o["fused"][0], np.arange(6) * 3.0)
+        np.testing.assert_array_equal(o["fused"][1], np.full((2, 2), 3.0))
+        np.testing.assert_array_equal(o["half"], np.arange(6) * 3.0)
+        np.testing.assert_array_equal(o["fused_half"][0],
+                                      2 * np.arange(4) + 1.0)
+        np.testing.assert_array_equal(o["fused_half"][1], np.full(3, 5.0))
+        # |x| >= 1.5: rank 0 sends -2, 3; rank 1 sends -4, 6, 2
+        np.testing.assert_allclose(o["thr"][0], [0, -6, 0, 9, 0, 2])
+        mine = base * (r + 1)
+        keep = np.abs(mine) >= 1.5
+        np.testing.assert_allclose(o["thr"][1], np.where(keep, 0, mine),
+                                   rtol=1e-6)
+        # top-3 of 6 by magnitude on both ranks: entries 1, 3, 5
+        np.testing.assert_allclose(o["topk"], [0, -6, 0, 9, 0, 3])
+        g1, g2, acc = o["topk_acc"]
+        np.testing.assert_allclose(np.concatenate([g1, g2]),
+                                   [0, -6, 0, 9, 0, 3])
+        np.testing.assert_allclose(acc, mine * np.array([1, 0, 1, 0, 1, 0]),
+                                   rtol=1e-6)
+
+
+# ------------------------------------------------------------ DistOpt training
+def _make_model():
+    from singa_amd import layer, model
+
+    class MLP(model.Model):
+
+        def __init__(self):
+            super(MLP, self).__init__()
+            self.fc1 = layer.Linear(8)
+            self.relu = layer.ReLU()
+            self.fc2 = layer.Linear(3)
+            self.loss = layer.SoftMaxCrossEntropy()
+
+        def forward(self, x):
+            return self.fc2(self.relu(self.fc1(x)))
+
+        def train_one_batch(self, x, y, dist_option, spars):
+            out = self.forward(x)
+            l = self.loss(out, y)
+            if dist_option == "plain":
+                self.optimizer(l)
+            elif dist_option == "half":
+                self.optimizer.backward_and_update_half(l)
+            elif dist_option == "partialUpdate":
+                self.optimizer.backward_and_partial_update(l)
+            elif dist_option == "sparseTopK":
+                self.optimizer.backward_and_sparse_update(l, topK=True,
+                                                          spars=spars)
+            elif dist_option == "sparseThreshold":
+                self.optimizer.backward_and_sparse_update(l, topK=False,
+                                                          spars=spars)
+            return out, l
+
+    return MLP()
+
+
+def _data():
+    rs = np.random.RandomState(0)
+    return (rs.randn(16, 5).astype(np.float32),
+            rs.randint(0, 3, 16).astype(np.int32))
+
+
+def _init(m):
+    from singa_amd import tensor
+    rs = np.random.RandomState(1)
+    for k, v in sorted(m.get_params().items()):
+        v.copy_from_numpy(rs.randn(*v.shape).astype(np.float32) * 0.3)
+
+
+def _dist_train(rank, world, holder, option, use_graph, spars):
+    from singa_amd import opt, tensor, device
+    dev = device.get_default_device()
+    sgd = opt.DistOpt(opt.SGD(lr=0.1, momentum=0.9), nccl_id=holder,
+                      local_rank=rank, world_size=world)
+    x, y = _data()
+    n = x.shape[0] // world
+    tx = tensor.Tensor(device=dev, data=x[rank * n:(rank + 1) * n])
+    ty = tensor.Tensor(device=dev, data=y[rank * n:(rank + 1) * n])
+    m = _make_model()
+    m.set_optimizer(sgd)
+    m.compile([tx], is_train=True, use_graph=use_graph, sequential=True)
+    _init(m)
+    for _ in range(4):
+        out, l = m(tx, ty, option, spars)
+    return {k: tensor.to_numpy(v) for k, v in m.get_params().items()}
+
+
+def _single_train():
+    sys.path.insert(0, ROOT)
+    from singa_amd import opt, tensor, device
+    dev = device.get_default_device()
+    x, y = _data()
+    tx = tensor.Tensor(device=dev, data=x)
+    ty = tensor.Tensor(device=dev, data=y)
+    m = _make_model()
+    m.set_optimizer(opt.SGD(lr=0.1, momentum=0.9))
+    m.compile([tx], is_train=True, use_graph=False, sequential=False)
+    _init(m)
+    for _ in range(4):
+        m(tx, ty, "plain", None)
+    return {k: tensor.to_numpy(v) for k, v in m.get_params().items()}
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_distopt_matches_single_process(use_graph):
+    """Mean loss over 2 x 8 samples with averaged gradients == mean loss over
+    16 samples in one process."""
+    ref = _single_train()
+    res = _spawn(_dist_train, args=("plain", use_graph, None))
+    for r in (0, 1):
+        for k in ref:
+            np.testing.assert_allclose(res[r][k], ref[k], rtol=1e-4,
+                                       atol=1e-5)
+
+
+def test_distopt_half_close_to_fp32():
+    ref = _single_train()
+    res = _spawn(_dist_train, args=("half", False, None))
+    for k in ref:
+        np.testing.assert_allclose(res[0][k], ref[k], rtol=2e-2, atol=2e-3)
+        np.testing.assert_array_equal(res[0][k], res[1][k])
+
+
+@pytest.mark.parametrize("option,spars", [("sparseTopK", 1.0),
+                                          ("sparseThreshold", 0.0)])
+def test_distopt_sparse_full_density_matches(option, spars):
+    """Sending every entry (top-100 % / threshold 0) is the dense all-reduce."""
+    ref = _single_train()
+    res = _spawn(_dist_train, args=(option, False, spars))
+    for k in ref:
+        np.testing.assert_allclose(res[0][k], ref[k], rtol=1e-4, atol=1e-5)
+
+
+def test_distopt_partial_update_runs_and_syncs():
+    res = _spawn(_dist_train, args=("partialUpdate", False, None))
+    for k in res[0]:
+        assert np.all(np.isfinite(res[0][k]))

@@ -1343,7 +1343,7 @@ class Reshape(Operator):
 
     def __init__(self, shape):
         super(Reshape, self).__init__()
-        self.shape = list(shape)
+        self.shape = list(shape) if shape is not None else None
 
     def forward(self, x):
         self._shape = x.shape()
@@ -1901,7 +1901,7 @@ class OneHot(_NoGrad):
         shape = list(indices.shape())
         rank = len(shape)
         axis = self.axis + rank + 1 if self.axis < 0 else self.axis
-        depth = int(self.depth)
+        depth = int(np.asarray(self.depth).reshape(-1)[0])
         # compare a broadcast arange against the (wrapped) indices on device
         rng = tensor.from_numpy(np.arange(depth, dtype=np.float32))
         rng.to_device(indices.device())

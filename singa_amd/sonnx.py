@@ -1,0 +1,779 @@
+"""ONNX import (``prepare`` -> ``SingaRep`` / ``SONNXModel``) and export
+(``to_onnx``), opset 11 / IR version 6.
+
+Functionally the reference's python/singa/sonnx.py (backend :1037-1948,
+``SingaRep`` :1951-2193, ``SONNXModel`` :2196-2220, frontend :60-987) with the
+``onnx`` package replaced by :mod:`singa_amd.onnx_proto` (if ``onnx`` is
+installed its ModelProto objects are accepted as well: only protobuf field
+access is used).  The importer is table driven: one row per ONNX operator
+naming the autograd operator or layer that runs it, how its attributes map
+to constructor arguments, and which of its inputs are really attributes
+(``shape`` of Reshape, ``pads`` of Pad, ...) or layer weights.
+"""
+import warnings
+from collections import OrderedDict, namedtuple
+
+import numpy as np
+
+from . import autograd, device, layer, model, tensor, utils
+from . import onnx_proto as onnx
+from .onnx_proto import (TensorProto, helper, mapping, numpy_helper)
+
+_OPSET = 11
+_IR_VERSION = 6
+
+
+def onnx_type_to_singa_type(onnx_type):
+    """numpy dtype the framework computes in for an ONNX element type (or a
+    numpy dtype): floats -> float32, everything integral -> int32."""
+    if isinstance(onnx_type, (int, np.integer)):
+        np_type = mapping.TENSOR_TYPE_TO_NP_TYPE[int(onnx_type)]
+    else:
+        np_type = np.dtype(onnx_type)
+    if np_type.kind == "f":
+        return np.dtype("float32")
+    return np.dtype("int32")
+
+
+def _singa_dtype_to_onnx(dt):
+    return {tensor.float32: TensorProto.FLOAT, tensor.float16:
+            TensorProto.FLOAT16, tensor.int32: TensorProto.INT32}.get(
+                dt, TensorProto.FLOAT)
+
+
+class OnnxAttributes(dict):
+    """Attributes of a node as a dict of python values."""
+
+    @staticmethod
+    def from_onnx(args):
+        d = OnnxAttributes()
+        for a in args:
+            d[a.name] = helper.get_attribute_value(a)
+        return d
+
+
+class OnnxNode(object):
+    """A NodeProto unpacked; ``weight_inputs`` (input name -> layer state
+    name) and ``attr_inputs`` (input name -> operator attribute name) mark
+    the inputs that do not flow through the operator call."""
+
+    def __init__(self, node):
+        self.name = str(node.name).replace(".", "_")
+        self.op_type = str(node.op_type)
+        self.attrs = OnnxAttributes.from_onnx(node.attribute)
+        self.inputs = list(node.input)
+        self.outputs = list(node.output)
+        self.weight_inputs = {}
+        self.attr_inputs = {}
+
+    def getattr(self, key, default=None):
+        return self.attrs[key] if key in self.attrs else default
+
+    def set_weight_inputs(self, key, name):
+        self.weight_inputs[key] = name
+
+    def del_weight_inputs(self, key):
+        del self.weight_inputs[key]
+
+    def set_attr_inputs(self, key, name):
+        self.attr_inputs[key] = name
+
+    def del_attr_inputs(self, key):
+        del self.attr_inputs[key]
+
+
+def _s(v):
+    return utils.force_unicode(v)
+
+
+# ---------------------------------------------------------------------------
+# import: ONNX operator -> (target, constructor arguments, attribute inputs)
+# ---------------------------------------------------------------------------
+def _plain(name):
+    return (name, None)
+
+
+class SingaBackend(object):
+    _opset_version = _OPSET
+    _ir_version = _IR_VERSION
+
+    _rename_operators = {
+        'Relu': 'ReLU', 'Sigmoid': 'Sigmoid', 'Add': 'Add', 'MatMul': 'Matmul',
+        'Sum': 'Sum', 'Cos': 'Cos', 'Cosh': 'Cosh', 'Sin': 'Sin',
+        'Sinh': 'Sinh', 'Tan': 'Tan', 'Tanh': 'Tanh', 'Acos': 'Acos',
+        'Acosh': 'Acosh', 'Asin': 'Asin', 'Asinh': 'Asinh', 'Atan': 'Atan',
+        'Atanh': 'Atanh', 'Equal': 'Equal', 'Less': 'Less', 'Sign': 'Sign',
+        'Div': 'Div', 'Sub': 'Sub', 'Sqrt': 'Sqrt', 'Log': 'Log',
+        'Greater': 'Greater', 'Identity': 'Identity', 'Softplus': 'SoftPlus',
+        'Softsign': 'SoftSign', 'Mean': 'Mean', 'Pow': 'Pow', 'PRelu': 'PRelu',
+        'Mul': 'Mul', 'Max': 'Max', 'Min': 'Min', 'Shape': 'Shape',
+        'And': 'And', 'Or': 'Or', 'Xor': 'Xor', 'Not': 'Not',
+        'Neg': 'Negative', 'Reciprocal': 'Reciprocal', 'NonZero': 'NonZero',
+        'Ceil': 'Ceil', 'Floor': 'Floor', 'Abs': 'Abs', 'Exp': 'Exp',
+        'Round': 'Rounde', 'Erf': 'Erf',
+        'Unsqueeze': 'Unsqueeze', 'ScatterElements': 'ScatterElements',
+        'Cast': 'Cast', 'Split': 'Split', 'Squeeze': 'Squeeze',
+        'GlobalAveragePool': 'GlobalAveragePool', 'LeakyRelu': 'LeakyRelu',
+        'ReduceSum': 'ReduceSum', 'ReduceMean': 'ReduceMean',
+        'Dropout': 'Dropout', 'ConstantOfShape': 'ConstantOfShape',
+        'Transpose': 'Transpose', 'HardSigmoid': 'HardSigmoid', 'Elu': 'Elu',
+        'Selu': 'SeLU', 'Concat': 'Concat', 'Softmax': 'SoftMax',
+        'Flatten': 'Flatten', 'OneHot': 'OneHot', 'Tile': 'Tile',
+        'Gather': 'Gather', 'Reshape': 'Reshape', 'Slice': 'Slice',
+        'Clip': 'Clip', 'Expand': 'Expand', 'Pad': 'Pad',
+        'Upsample': 'UpSample', 'DepthToSpace': 'DepthToSpace',
+        'SpaceToDepth': 'SpaceToDepth', 'Where': 'Where',
+        'Gemm': 'layer.Gemm', 'BatchNormalization': 'layer.BatchNorm2d',
+        'Conv': 'layer.Conv2d', 'MaxPool': 'layer.Pooling2d',
+        'AveragePool': 'layer.Pooling2d',
+    }
+
+    # ---- per-operator translators ---------------------------------------------
+    @staticmethod
+    def _attr_in(node, idx, name):
+        """Treat input ``idx`` (if present and non-empty) as attribute."""
+        if len(node.inputs) > idx and node.inputs[idx] != '':
+            node.set_attr_inputs(node.inputs[idx], name)
+
+    @classmethod
+    def _create(cls, n, op):
+        """Instance of operator class ``op`` for node ``n``."""
+        t = n.op_type
+        g = n.getattr
+        if t in ('DepthToSpace', 'SpaceToDepth'):
+            return op(g("blocksize"), _s(g("mode", "DCR")))
+        if t == 'Where':
+            n.set_attr_inputs(n.inputs[0], 'condition')
+            return op(None)
+        if t == 'Pad':
+            cls._attr_in(n, 1, 'pads')
+            cls._attr_in(n, 2, 'constant')
+            return op(_s(g("mode", "constant")), None, None)
+        if t == 'Upsample':
+            cls._attr_in(n, 1, 'scales')
+            return op(_s(g("mode", None)), None)
+        if t == 'Expand':
+            cls._attr_in(n, 1, 'shape')
+            return op(None)
+        if t == 'Cast':
+            to = onnx_type_to_singa_type(g("to"))
+            return op(tensor.float32 if to == np.dtype('float32')
+                      else tensor.int32)
+        if t == 'Split':
+            return op(g("axis", 0), g("split", None), len(n.outputs))
+        if t in ('Squeeze', 'Unsqueeze'):
+            return op(g("axes"))
+        if t == 'GlobalAveragePool':
+            return op(g("data_format", 'channels_first'))
+        if t == 'LeakyRelu':
+            return op(g("alpha", 0.01))
+        if t in ('ReduceSum', 'ReduceMean'):
+            return op(g("axes", None), g("keepdims", 1))
+        if t == 'Dropout':
+            return op(g("seed", 0), g("ratio", 0))
+        if t == 'ConstantOfShape':
+            value = g("value", 0)
+            if hasattr(value, "data_type"):
+                value = numpy_helper.to_array(value).reshape(-1)[0].item()
+            return op(value)
+        if t == 'Transpose':
+            return op(g("perm"))
+        if t == 'HardSigmoid':
+            return op(g("alpha", 0.2), g("beta", 0.5))
+        if t == 'Elu':
+            return op(g("alpha", 1.))
+        if t == 'Selu':
+            return op(g("alpha", 1.67326), g("gamma", 1.0507))
+        if t == 'Concat':
+            return op(axis=g('axis'))
+        if t in ('Softmax', 'Flatten'):
+            return op(axis=g('axis', 1))
+        if t == 'Gemm':
+            n.set_weight_inputs(n.inputs[1], 'W')
+            bias = len(n.inputs) == 3
+            if bias:
+                n.set_weight_inputs(n.inputs[2], 'b')
+            return op(None, alpha=g('alpha', 1.), beta=g('beta', 1.),
+                      transA=g('transA', 0), transB=g('transB', 0), bias=bias)
+        if t == 'OneHot':
+            cls._attr_in(n, 1, 'depth')
+            cls._attr_in(n, 2, 'values')
+            return op(g("axis", -1), None, None)
+        if t == 'Tile':
+            cls._attr_in(n, 1, 'repeats')
+            return op(None)
+        if t == 'Gather':
+            cls._attr_in(n, 1, 'indices')
+            return op(g("axis", 0), None)
+        if t == 'Reshape':
+            cls._attr_in(n, 1, 'shape')
+            return op(None)
+        if t == 'Slice':
+            cls._attr_in(n, 1, 'starts')
+            cls._attr_in(n, 2, 'ends')
+            cls._attr_in(n, 3, 'axes')
+            cls._attr_in(n, 4, 'steps')
+            return op(None, None, None, None)
+        if t == 'Clip':
+            cls._attr_in(n, 1, 'min')
+            cls._attr_in(n, 2, 'max')
+            return op(None, None)
+        if t == 'BatchNormalization':
+            for i, nm in enumerate(('scale', 'bias', 'running_mean',
+                                    'running_var')):
+                n.set_weight_inputs(n.inputs[i + 1], nm)
+            return op(momentum=g('momentum', 0.9))
+        if t == 'Conv':
+            kernel = tuple(g('kernel_shape'))
+            dilation = g('dilations', 1)
+            if dilation != 1 and list(dilation) != [1] * len(kernel):
+                raise ValueError("Not implemented yet for dilation")
+            if len(kernel) > 2:
+                raise ValueError("Only implemented for 1d or 2d")
+            n.set_weight_inputs(n.inputs[1], 'W')
+            bias = len(n.inputs) == 3
+            if bias:
+                n.set_weight_inputs(n.inputs[2], 'b')
+            return op(None, kernel, stride=tuple(g('strides', (1, 1))),
+                      padding=tuple(g('pads', (0, 0))), dilation=1,
+                      group=g('group', 1), bias=bias,
+                      pad_mode=_s(g('auto_pad', 'NOTSET')))
+        if t in ('MaxPool', 'AveragePool'):
+            kernel = tuple(g('kernel_shape'))
+            if g('ceil_mode', 0) != 0 or g('count_include_pad', 0) != 0:
+                raise ValueError(
+                    "Not implemented yet for count_include_pad or ceil_mode")
+            if len(kernel) > 2:
+                raise ValueError("Only implemented for 1d or 2d")
+            return op(kernel, tuple(g('strides', (1, 1))),
+                      tuple(g('pads', (0, 0))), t == 'MaxPool',
+                      _s(g('auto_pad', 'NOTSET')))
+        if t == 'ScatterElements':
+            cls._attr_in(n, 1, 'indices')
+            cls._attr_in(n, 2, 'updates')
+            return op(None, None, g("axis", 0))
+        return op()
+
+    @classmethod
+    def _onnx_constant_to_np(cls, onnx_node):
+        return numpy_helper.to_array(onnx_node.getattr('value'))
+
+    @classmethod
+    def _onnx_node_to_singa_op(cls, onnx_node, opset_version=_OPSET):
+        t = onnx_node.op_type
+        assert t in cls._rename_operators, "not support operator: %s" % t
+        renamed = cls._rename_operators[t]
+        if renamed.startswith('layer.'):
+            op_class = getattr(layer, renamed[6:])
+        else:
+            op_class = getattr(autograd, renamed)
+        op = cls._create(onnx_node, op_class)
+        op.name = onnx_node.name
+        onnx_node.inputs = [i for i in onnx_node.inputs if i != '']
+        return op
+
+    # ---- single node (ONNX backend test protocol) ---------------------------------
+    @classmethod
+    def run_node(cls, node, inputs, device_name='CPU', opset_version=_OPSET):
+        node = OnnxNode(node)
+        valid_inputs = [x for x in node.inputs if x != ""]
+        assert len(valid_inputs) == len(inputs), (
+            "%s: expected %d inputs, but got %d." %
+            (node.op_type, len(valid_inputs), len(inputs)))
+        op = cls._onnx_node_to_singa_op(node, opset_version)
+        dev = _device_of(device_name)
+        states = {}
+        xs = []
+        for key, val in zip(valid_inputs, inputs):
+            val = np.asarray(val)
+            val = val.astype(onnx_type_to_singa_type(val.dtype))
+            if key in node.weight_inputs:
+                states[node.weight_inputs[key]] = val
+            elif key in node.attr_inputs:
+                setattr(op, node.attr_inputs[key], val)
+            else:
+                xs.append(tensor.Tensor(device=dev, data=np.atleast_1d(val)))
+        if states:
+            _init_layer(op, node, xs, states)
+        outputs = cls._run_node(op, xs)
+        return OrderedDict(zip(node.outputs, outputs))
+
+    @classmethod
+    def _run_node(cls, operator, inputs):
+        outputs = operator(*inputs)
+        if not isinstance(outputs, (list, tuple)):
+            outputs = [outputs]
+        return list(outputs)
+
+    # ---- whole graph ------------------------------------------------------------------
+    @classmethod
+    def _parse_graph_params(cls, graph):
+        params = {}
+        for tp in graph.initializer:
+            val = numpy_helper.to_array(tp)
+            params[tp.name] = val.astype(onnx_type_to_singa_type(tp.data_type))
+        return params
+
+    @classmethod
+    def _parse_graph_inputs_outputs(cls, graph, params):
+        info = namedtuple('info_tuple', ['name', 'dtype', 'shape'])
+        inputs, outputs = [], []
+        for t in graph.input:
+            if t.name not in params:
+                tt = t.type.tensor_type
+                inputs.append(info(t.name, tt.elem_type,
+                                   [d.dim_value for d in tt.shape.dim]))
+        for t in graph.output:
+            tt = t.type.tensor_type
+            outputs.append(info(t.name, tt.elem_type,
+                                [d.dim_value for d in tt.shape.dim]))
+        return inputs, outputs
+
+    @classmethod
+    def _onnx_model_to_singa_ops(cls, graph, opset_version=_OPSET):
+        params = cls._parse_graph_params(graph)
+        inputs, outputs = cls._parse_graph_inputs_outputs(graph, params)
+        operators = []
+        op_tuple = namedtuple('operator_tuple', ['node', 'operator'])
+        for node in graph.node:
+            if not node.name:
+                node.name = "%s_%d" % (str(node.op_type), len(operators))
+            n = OnnxNode(node)
+            if n.op_type == 'Constant':
+                val = cls._onnx_constant_to_np(n)
+                params[n.outputs[0]] = val.astype(
+                    onnx_type_to_singa_type(val.dtype))
+            else:
+                operators.append(op_tuple(
+                    n, cls._onnx_node_to_singa_op(n, opset_version)))
+        return params, inputs, outputs, operators
+
+    @classmethod
+    def prepare(cls, model_proto, device='CPU', **kwargs):
+        """ModelProto -> SingaRep.  ``device``: 'CPU', 'CUDA' or a Device."""
+        opset_version = None
+        for imp in model_proto.opset_import:
+            if imp.domain in ("", "ai.onnx"):
+                opset_version = imp.version
+                if imp.version > cls._opset_version:
+                    warnings.warn(
+                        "The imported opertor set verion {} is larger than "
+                        "the supported version {}.".format(
+                            imp.version, cls._opset_version))
+            else:
+                warnings.warn("Unrecognized operator set %s" % imp.domain)
+        if model_proto.ir_version > cls._ir_version:
+            warnings.warn(
+                "The imported ir verion {} is larger than the supported "
+                "version {}.".format(model_proto.ir_version, cls._ir_version))
+        params, inputs, outputs, layers = cls._onnx_model_to_singa_ops(
+            model_proto.graph, opset_version or cls._opset_version)
+        return SingaRep(params, inputs, outputs, layers, device)
+
+
+def _device_of(dev):
+    if isinstance(dev, str):
+        if dev.upper() == 'CPU':
+            return device.get_default_device()
+        return device.create_cuda_gpu()
+    return dev
+
+
+def _init_layer(op, node, inputs, states):
+    """Give a layer the geometry the ONNX weights imply, create its
+    parameters from the first inputs and load the weights."""
+    if node.op_type == "Conv":
+        op.nb_kernels = states['W'].shape[0]
+    elif node.op_type == "Gemm":
+        op.nb_kernels = states['W'].shape[0 if op.transB == 1 else -1]
+        if op.bias:
+            op.bias_shape = states['b'].shape
+    if callable(getattr(op, "initialize", None)) and not op._initialized:
+        op.initialize(*inputs)
+        op._initialized = True
+    named = {getattr(op, k).name: tensor.from_numpy(np.ascontiguousarray(v))
+             for k, v in states.items()}
+    op.set_states(named)
+
+
+class SingaRep(object):
+    """Interprets the imported graph in topological order.  ``run(x)`` takes
+    numpy arrays (or Tensors when driven by ``SONNXModel``) and returns the
+    graph outputs; ``last_layers=k`` stops after layer k (transfer learning),
+    ``aux_output`` names extra tensors to return."""
+
+    def __init__(self, params, inputs, outputs, layers, dev):
+        self.inputs = inputs
+        self.states = params
+        self.outputs = outputs
+        self.dev = _device_of(dev)
+        self.layers = layers
+        self.tensor_count = {}
+        self.has_initialized = False
+        self.is_graph = False
+
+    def initialize(self):
+        self.outputs_info = {o.name: o for o in self.outputs}
+        self._layers = []
+        for node, operator in self.layers:
+            for key, name in list(node.weight_inputs.items()):
+                if key not in self.states:
+                    # weight computed by the graph: treat as attribute input
+                    node.set_attr_inputs(key, name)
+                    node.del_weight_inputs(key)
+            self.__dict__[node.name] = operator
+            self._layers.append(node)
+
+    def init_tensor_count(self):
+        self.tensor_count = {}
+        for node, _ in self.layers:
+            for inp in (node.inputs + list(node.attr_inputs.keys()) +
+                        list(node.weight_inputs.keys())):
+                self.tensor_count[inp] = self.tensor_count.get(inp, 0) + 1
+
+    def to_input_tensor(self, x):
+        tensor_dict = {}
+        for key, val in zip(self.inputs, x):
+            if not isinstance(val, tensor.Tensor):
+                val = np.asarray(val)
+                val = np.atleast_1d(val.astype(
+                    onnx_type_to_singa_type(key.dtype)))
+                val = tensor.Tensor(device=self.dev, data=val)
+            tensor_dict[key.name] = val
+        return tensor_dict
+
+    def to_output_tensor(self, y, out_name):
+        if not self.is_graph:
+            y = tensor.to_numpy(y)
+            if out_name in self.outputs_info:
+                dt = self.outputs_info[out_name].dtype
+                if dt in mapping.TENSOR_TYPE_TO_NP_TYPE:
+                    y = y.astype(mapping.TENSOR_TYPE_TO_NP_TYPE[dt])
+        return y
+
+    def get_s(self, name, node, tensor_dict):
+        if name in node.attr_inputs:
+            return tensor_dict[name]
+        return self.states[name]
+
+    def run(self, x, **kwargs):
+        if not self.has_initialized:
+            self.initialize()
+            if isinstance(x[0], tensor.Tensor):
+                self.dev = x[0].device
+        outputs_dict = OrderedDict()
+        last = kwargs.get('last_layers', len(self._layers) - 1)
+        if last < 0:
+            last = (last + 1) % len(self._layers)
+        if last != len(self._layers) - 1:
+            for o in self._layers[last].outputs:
+                outputs_dict[o] = None
+        else:
+            for o in self.outputs:
+                outputs_dict[o.name] = None
+        for o in kwargs.get('aux_output', ()):
+            outputs_dict[o] = None
+
+        tensor_dict = self.to_input_tensor(x)
+        self.init_tensor_count()
+        for node in self._layers[:last + 1]:
+            op = self.__dict__[node.name]
+            inputs = []
+            for inp in node.inputs:
+                if inp in node.weight_inputs or inp in node.attr_inputs:
+                    continue
+                if inp in tensor_dict:
+                    inputs.append(tensor_dict[inp])
+                elif inp in self.states:
+                    val = np.atleast_1d(self.states[inp])
+                    inputs.append(tensor.Tensor(device=self.dev, data=val))
+                else:
+                    raise KeyError("Not found the input %s for operation %s" %
+                                   (inp, node.name))
+            # attributes delivered as inputs
+            for key, name in node.attr_inputs.items():
+                ts = tensor_dict[key] if key in tensor_dict \
+                    else self.states[key]
+                if isinstance(ts, tensor.Tensor):
+                    ts = tensor.to_numpy(ts)
+                if name in ('W', 'b', 'scale', 'bias', 'running_mean',
+                            'running_var'):
+                    continue  # handled below as layer states
+                setattr(op, name, ts)
+            # layers: create parameters on first use and load the weights
+            if callable(getattr(op, "initialize", None)) and \
+                    not op._initialized:
+                states = {name: self.states[key]
+                          for key, name in node.weight_inputs.items()}
+                for key, name in node.attr_inputs.items():
+                    if name in ('W', 'b', 'scale', 'bias', 'running_mean',
+                                'running_var'):
+                        ts = tensor_dict[key]
+                        states[name] = tensor.to_numpy(ts)
+                prev = self.dev.graph_enabled()
+                self.dev.EnableGraph(False)
+                try:
+                    _init_layer(op, node, inputs, states)
+                finally:
+                    self.dev.EnableGraph(prev)
+            outputs = SingaBackend._run_node(op, inputs)
+            for inp in node.inputs:
+                if inp in self.tensor_count:
+                    self.tensor_count[inp] -= 1
+                    if self.tensor_count[inp] == 0:
+                        tensor_dict.pop(inp, None)
+                        del self.tensor_count[inp]
+            for outp, val in zip(node.outputs, outputs):
+                tensor_dict[outp] = val
+                if outp in outputs_dict:
+                    outputs_dict[outp] = self.to_output_tensor(val, outp)
+        self.has_initialized = True
+        return list(outputs_dict.values())
+
+
+class SONNXModel(model.Model):
+    """A Model whose forward pass is an imported ONNX graph; subclass it and
+    add ``train_one_batch`` to fine-tune (reference sonnx.py:2196-2220)."""
+
+    def __init__(self, onnx_model):
+        super(SONNXModel, self).__init__()
+        self.sg_ir = prepare(onnx_model)
+        for node, operator in self.sg_ir.layers:
+            if isinstance(operator, layer.Layer):
+                # registered as sub-layer: its weights become parameters of
+                # this model (trainable, saved with the checkpoint)
+                setattr(self, node.name, operator)
+            else:
+                self.__dict__[node.name] = operator
+        self.sg_ir.is_graph = True
+
+    def forward(self, *input, aux_output=(), **kwargs):
+        return self.sg_ir.run(input, aux_output=aux_output, **kwargs)
+
+
+# ---------------------------------------------------------------------------
+# export: autograd tape -> ONNX graph
+# ---------------------------------------------------------------------------
+def _np_i64(v):
+    return np.asarray(v, dtype=np.int64).reshape(-1)
+
+
+class SingaFrontend(object):
+    _target_opset_version = _OPSET
+
+    # operator class name -> ONNX op type, for operators without attributes
+    _rename_operators = {
+        'ReLU': 'Relu', 'Sigmoid': 'Sigmoid', 'Add': 'Add', 'Matmul': 'MatMul',
+        'Sum': 'Sum', 'Cos': 'Cos', 'Cosh': 'Cosh', 'Sin': 'Sin',
+        'Sinh': 'Sinh', 'Tan': 'Tan', 'Tanh': 'Tanh', 'Acos': 'Acos',
+        'Acosh': 'Acosh', 'Asin': 'Asin', 'Asinh': 'Asinh', 'Atan': 'Atan',
+        'Atanh': 'Atanh', 'Equal': 'Equal', 'Less': 'Less', 'Sign': 'Sign',
+        'Div': 'Div', 'Sub': 'Sub', 'Sqrt': 'Sqrt', 'Log': 'Log',
+        'Greater': 'Greater', 'Identity': 'Identity', 'SoftPlus': 'Softplus',
+        'SoftSign': 'Softsign', 'Mean': 'Mean', 'Pow': 'Pow', 'PRelu': 'PRelu',
+        'Mul': 'Mul', 'Max': 'Max', 'Min': 'Min', 'Shape': 'Shape',
+        'And': 'And', 'Or': 'Or', 'Xor': 'Xor', 'Not': 'Not',
+        'Negative': 'Neg', 'Reciprocal': 'Reciprocal', 'NonZero': 'NonZero',
+        'Ceil': 'Ceil', 'Floor': 'Floor', 'Abs': 'Abs', 'Exp': 'Exp',
+        'Rounde': 'Round', 'Erf': 'Erf', 'AddBias': 'Add',
+        'GlobalAveragePool': 'GlobalAveragePool',
+    }
+
+    @classmethod
+    def _attrs_and_extra(cls, op):
+        """(onnx op type, attribute dict, [(suffix, ndarray)] extra inputs)."""
+        n = type(op).__name__
+        h = getattr(op, "handle", None)
+        if n in cls._rename_operators:
+            return cls._rename_operators[n], {}, []
+        if n == '_Conv2d':
+            odd = op.odd_padding
+            pads = [h.pad_h + odd[0], h.pad_w + odd[2], h.pad_h + odd[1],
+                    h.pad_w + odd[3]]
+            return 'Conv', dict(kernel_shape=[h.kernel_h, h.kernel_w],
+                                pads=pads, strides=[h.stride_h, h.stride_w],
+                                group=h.group), []
+        if n == '_Pooling2d':
+            odd = op.odd_padding
+            pads = [h.pad_h + odd[0], h.pad_w + odd[2], h.pad_h + odd[1],
+                    h.pad_w + odd[3]]
+            return ('MaxPool' if h.is_max_pooling else 'AveragePool'), dict(
+                kernel_shape=[h.kernel_h, h.kernel_w], pads=pads,
+                strides=[h.stride_h, h.stride_w]), []
+        if n == '_BatchNorm2d':
+            return 'BatchNormalization', dict(momentum=float(h.factor),
+                                              epsilon=1e-5), [
+                ("mean", tensor.to_numpy(tensor.from_raw_tensor(
+                    op.running_mean))),
+                ("var", tensor.to_numpy(tensor.from_raw_tensor(
+                    op.running_var)))]
+        if n == 'Gemm':
+            return 'Gemm', dict(alpha=float(op.alpha), beta=float(op.beta),
+                                transA=int(op.transA),
+                                transB=int(op.transB)), []
+        if n == 'SoftMax':
+            return 'Softmax', dict(axis=int(op.axis)), []
+        if n == 'Flatten':
+            return 'Flatten', dict(axis=int(op.axis)), []
+        if n == 'Concat':
+            return 'Concat', dict(axis=int(op.axis)), []
+        if n == 'Transpose':
+            return 'Transpose', dict(perm=[int(p) for p in op.perm]), []
+        if n in ('Squeeze', 'Unsqueeze'):
+            ax = op.axis if isinstance(op.axis, (list, tuple)) else [op.axis]
+            return n, dict(axes=[int(a) for a in ax]), []
+        if n in ('ReduceSum', 'ReduceMean'):
+            d = dict(keepdims=int(op.keepdims))
+            if op.axes is not None:
+                d['axes'] = [int(a) for a in op.axes]
+            return n, d, []
+        if n == 'LeakyRelu':
+            return 'LeakyRelu', dict(alpha=float(op.a)), []
+        if n == 'Elu':
+            return 'Elu', dict(alpha=float(op.alpha)), []
+        if n == 'SeLU':
+            return 'Selu', dict(alpha=float(op.alpha),
+                                gamma=float(op.gamma)), []
+        if n == 'HardSigmoid':
+            return 'HardSigmoid', dict(alpha=float(op.alpha),
+                                       beta=float(op.gamma)), []
+        if n == 'Dropout':
+            return 'Dropout', dict(ratio=float(op.ratio)), []
+        if n == 'Cast':
+            return 'Cast', dict(to=_singa_dtype_to_onnx(op.to)), []
+        if n == 'Split':
+            d = dict(axis=int(op.axis))
+            if op.parts is not None:
+                d['split'] = [int(p) for p in op.parts]
+            return 'Split', d, []
+        if n in ('DepthToSpace', 'SpaceToDepth'):
+            d = dict(blocksize=int(op.blocksize))
+            if n == 'DepthToSpace':
+                d['mode'] = op.mode
+            return n, d, []
+        if n == 'ConstantOfShape':
+            return n, dict(value=helper.make_tensor(
+                "value", TensorProto.FLOAT, [1], [float(op.value)])), []
+        if n == 'Reshape':
+            return n, {}, [("shape", _np_i64(op.shape))]
+        if n == 'Expand':
+            return n, {}, [("shape", _np_i64(op.shape))]
+        if n == 'Tile':
+            return n, {}, [("repeats", _np_i64(op.repeats))]
+        if n == 'Gather':
+            return n, dict(axis=int(op.axis)), [
+                ("indices", np.asarray(op.indices, dtype=np.int64))]
+        if n == 'Clip':
+            extra = []
+            for nm in ("min", "max"):
+                v = getattr(op, nm)
+                if v is not None:
+                    extra.append((nm, np.asarray(v, dtype=np.float32)))
+            return n, {}, extra
+        if n == 'Slice':
+            extra = [("starts", _np_i64(op.starts)), ("ends", _np_i64(op.ends))]
+            axes = op.axes if op.axes is not None else list(
+                range(len(op.starts)))
+            extra.append(("axes", _np_i64(axes)))
+            if op.steps is not None:
+                extra.append(("steps", _np_i64(op.steps)))
+            return n, {}, extra
+        if n == 'Pad':
+            return n, dict(mode=op.mode), [
+                ("pads", _np_i64(op.pads)),
+                ("constant", np.asarray(op.constant, dtype=np.float32))]
+        if n == 'UpSample':
+            return 'Upsample', dict(mode=op.mode), [
+                ("scales", np.asarray(op.scales, dtype=np.float32))]
+        if n == 'OneHot':
+            return n, dict(axis=int(op.axis)), [
+                ("depth", np.asarray([op.depth], dtype=np.int64)),
+                ("values", np.asarray(op.values, dtype=np.float32))]
+        if n == 'ScatterElements':
+            return n, dict(axis=int(op.axis)), [
+                ("indices", np.asarray(op.indices, dtype=np.int64)),
+                ("updates", np.asarray(
+                    tensor.to_numpy(op.updates) if isinstance(
+                        op.updates, tensor.Tensor) else op.updates,
+                    dtype=np.float32))]
+        if n == 'Where':
+            cond = op.condition
+            if isinstance(cond, tensor.CTensor):
+                cond = tensor.from_raw_tensor(cond)
+            if isinstance(cond, tensor.Tensor):
+                cond = tensor.to_numpy(cond)
+            return n, {}, [("condition", np.asarray(cond) != 0)]
+        raise NotImplementedError("operator %s has no ONNX translation" % n)
+
+    @classmethod
+    def _input_names(cls, op):
+        names = []
+        for (src_op, x_id, _, _) in op.src:
+            if type(src_op).__name__ == 'Dummy':
+                names.append(src_op.name)
+            else:
+                names.append(src_op.output_name(src_op.y_id2idx[x_id]))
+        return names
+
+    @classmethod
+    def singa_to_onnx_graph(cls, inputs, y, model_name="sonnx"):
+        """GraphProto of the computation that produced ``y`` (a Tensor or a
+        list of Tensors) from ``inputs`` (list of Tensors)."""
+        ys = y if isinstance(y, (list, tuple)) else [y]
+        nodes, initializers = [], []
+        weights, graph_inputs = OrderedDict(), OrderedDict()
+        done = set()
+        for yy in ys:
+            ops, ws, ins = utils.post_order_recursive(yy.creator, yy)
+            weights.update(ws)
+            graph_inputs.update(ins)
+            for name, op in ops.items():
+                if id(op) in done:
+                    continue
+                done.add(id(op))
+                op_type, attrs, extra = cls._attrs_and_extra(op)
+                in_names = cls._input_names(op)
+                for suffix, arr in extra:
+                    nm = "%s_%s" % (op.name, suffix)
+                    initializers.append(numpy_helper.from_array(arr, nm))
+                    if op_type == 'Where':
+                        in_names.insert(0, nm)  # condition comes first
+                    else:
+                        in_names.append(nm)
+                out_names = [op.output_name(i) for i in
+                             range(len(op.y_id2idx))]
+                nodes.append(helper.make_node(op_type, in_names, out_names,
+                                              name=op.name, **attrs))
+        for name, t in weights.items():
+            initializers.append(numpy_helper.from_array(
+                tensor.to_numpy(t), name))
+        known_inputs = {x.creator.name: x for x in inputs}
+        g_in = []
+        for x in inputs:
+            g_in.append(helper.make_tensor_value_info(
+                x.creator.name, _singa_dtype_to_onnx(x.dtype), list(x.shape)))
+        for name in graph_inputs:
+            if name not in known_inputs:
+                raise ValueError(
+                    "graph input %s is not among the given inputs" % name)
+        g_out = [helper.make_tensor_value_info(
+            yy.creator.output_name(yy.creator.y_id2idx[id(yy)]),
+            _singa_dtype_to_onnx(yy.dtype), list(yy.shape)) for yy in ys]
+        return helper.make_graph(nodes, model_name, g_in, g_out, initializers)
+
+    @classmethod
+    def singa_to_onnx_model(cls, inputs, y, model_name="sonnx"):
+        graph = cls.singa_to_onnx_graph(inputs, y, model_name)
+        return helper.make_model(
+            graph, producer_name='sonnx',
+            opset_imports=[helper.make_operatorsetid(
+                "", cls._target_opset_version)], ir_version=_IR_VERSION)
+
+
+run_node = SingaBackend.run_node
+_run_node = SingaBackend._run_node
+prepare = SingaBackend.prepare
+get_op = SingaBackend._onnx_node_to_singa_op
+to_onnx = SingaFrontend.singa_to_onnx_model
+save = onnx.save
+load = onnx.load

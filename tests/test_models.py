@@ -1,0 +1,73 @@
+"""Model zoo: every network builds, trains one step in graph mode and the
+loss is finite; small ones are trained until the loss drops (reference
+examples/cnn/train_cnn.py, examples/mlp/model.py)."""
+import numpy as np
+import pytest
+
+from singa_amd import models, opt, tensor
+
+
+def _step(dev, name, shape, classes, steps=2, graph=True, **kw):
+    rs = np.random.RandomState(0)
+    x = rs.randn(*shape).astype(np.float32)
+    y = rs.randint(0, classes, shape[0]).astype(np.int32)
+    tx = tensor.Tensor(device=dev, data=x)
+    ty = tensor.Tensor(device=dev, data=y)
+    m = models.create(name, num_classes=classes, **kw)
+    m.set_optimizer(opt.SGD(lr=0.01, momentum=0.9))
+    m.compile([tx], is_train=True, use_graph=graph, sequential=False)
+    losses = []
+    for _ in range(steps):
+        out, loss = m(tx, ty, 'plain', None)
+        losses.append(float(tensor.to_numpy(loss).reshape(-1)[0]))
+    dev.EnableGraph(False)
+    dev.ResetGraph()
+    assert out.shape == (shape[0], classes)
+    assert np.all(np.isfinite(losses))
+    return losses, m
+
+
+def test_mlp_learns(dev):
+    losses, _ = _step(dev, "mlp", (32, 10), 4, steps=30, perceptron_size=32)
+    assert losses[-1] < 0.7 * losses[0]
+
+
+def test_cnn_learns(dev):
+    losses, m = _step(dev, "cnn", (8, 1, 28, 28), 10, steps=12,
+                      num_channels=1)
+    assert losses[-1] < losses[0]
+    assert len(m.get_params()) == 8
+
+
+def test_resnet18_step(dev):
+    losses, m = _step(dev, "resnet18", (2, 3, 224, 224), 10, steps=2)
+    assert len(m.get_params()) == 62
+
+
+def test_alexnet_step(dev):
+    _step(dev, "alexnet", (2, 3, 224, 224), 10, steps=2, num_channels=3)
+
+
+@pytest.mark.gpu
+def test_xception_step(gpu_dev):
+    _step(gpu_dev, "xceptionnet", (2, 3, 299, 299), 10, steps=2)
+
+
+@pytest.mark.gpu
+def test_resnet50_step(gpu_dev):
+    _step(gpu_dev, "resnet50", (4, 3, 224, 224), 1000, steps=3)
+
+
+def test_xception_builds_and_runs_forward(cpu_dev):
+    from singa_amd import autograd
+    autograd.training = False
+    try:
+        m = models.create("xceptionnet", num_classes=5)
+        x = tensor.Tensor(device=cpu_dev, data=np.random.randn(
+            1, 3, 299, 299).astype(np.float32))
+        m.compile([x], is_train=False, use_graph=False, sequential=False)
+        out = m(x)
+        assert out.shape == (1, 5)
+        assert len(m.get_params()) > 150
+    finally:
+        autograd.training = True

@@ -1,0 +1,7 @@
+"""arcface from the ONNX model zoo; see zoo.py for options."""
+import sys
+
+import zoo
+
+if __name__ == "__main__":
+    zoo.main(["arcface"] + sys.argv[1:])

@@ -1,0 +1,7 @@
+"""densenet121 from the ONNX model zoo; see zoo.py for options."""
+import sys
+
+import zoo
+
+if __name__ == "__main__":
+    zoo.main(["densenet121"] + sys.argv[1:])

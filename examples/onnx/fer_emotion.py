@@ -1,0 +1,7 @@
+"""fer_emotion from the ONNX model zoo; see zoo.py for options."""
+import sys
+
+import zoo
+
+if __name__ == "__main__":
+    zoo.main(["fer_emotion"] + sys.argv[1:])

@@ -1,0 +1,7 @@
+"""mobilenet from the ONNX model zoo; see zoo.py for options."""
+import sys
+
+import zoo
+
+if __name__ == "__main__":
+    zoo.main(["mobilenet"] + sys.argv[1:])

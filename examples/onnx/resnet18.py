@@ -1,0 +1,7 @@
+"""resnet18 from the ONNX model zoo; see zoo.py for options."""
+import sys
+
+import zoo
+
+if __name__ == "__main__":
+    zoo.main(["resnet18"] + sys.argv[1:])

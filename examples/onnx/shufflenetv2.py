@@ -1,0 +1,7 @@
+"""shufflenetv2 from the ONNX model zoo; see zoo.py for options."""
+import sys
+
+import zoo
+
+if __name__ == "__main__":
+    zoo.main(["shufflenetv2"] + sys.argv[1:])

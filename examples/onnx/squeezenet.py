@@ -1,0 +1,7 @@
+"""squeezenet from the ONNX model zoo; see zoo.py for options."""
+import sys
+
+import zoo
+
+if __name__ == "__main__":
+    zoo.main(["squeezenet"] + sys.argv[1:])

@@ -1,0 +1,7 @@
+"""tiny_yolov2 from the ONNX model zoo; see zoo.py for options."""
+import sys
+
+import zoo
+
+if __name__ == "__main__":
+    zoo.main(["tiny_yolov2"] + sys.argv[1:])

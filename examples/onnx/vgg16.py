@@ -1,0 +1,7 @@
+"""vgg16 from the ONNX model zoo; see zoo.py for options."""
+import sys
+
+import zoo
+
+if __name__ == "__main__":
+    zoo.main(["vgg16"] + sys.argv[1:])

@@ -217,6 +217,10 @@ class PoolingHandle(object):
         self.pooled_width = (self.width + 2 * self.pad_w -
                              self.kernel_w) // self.stride_w + 1
         self.is_max_pooling = bool(is_max)
+        assert self.pooled_height > 0 and self.pooled_width > 0, (
+            "pooling window %dx%d does not fit the %dx%d input (padding "
+            "%d,%d)" % (self.kernel_h, self.kernel_w, self.height, self.width,
+                        self.pad_h, self.pad_w))
 
     def _args(self):
         sh = self.stride_h if self.stride_h > 0 else 1

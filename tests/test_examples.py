@@ -1,0 +1,104 @@
+"""Smoke tests of the example programs on tiny budgets (CPU).  They check
+that each script's public entry points run and that training moves the loss
+in the right direction; they are not accuracy benchmarks."""
+import os
+import socket
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..",
+                    "examples")
+
+
+def _import(subdir, name):
+    import importlib
+    path = os.path.join(ROOT, subdir)
+    sys.path.insert(0, path)
+    try:
+        if name in sys.modules:
+            del sys.modules[name]
+        return importlib.import_module(name)
+    finally:
+        sys.path.remove(path)
+
+
+def test_mlp_native_and_model():
+    native = _import("mlp", "native")
+    assert native.main(["-m", "201"]) < 0.5
+    model = _import("mlp", "model")
+    assert model.main(["-m", "201"]) < 0.3
+
+
+def test_train_cnn_helpers_and_epoch(capsys):
+    tc = _import("cnn", "train_cnn")
+    x = np.random.randn(6, 3, 8, 8).astype(np.float32)
+    a = tc.augmentation(x.copy())
+    assert a.shape == x.shape
+    r = tc.resize_dataset(x, 16)
+    assert r.shape == (6, 3, 16, 16)
+    np.testing.assert_allclose(tc.resize_dataset(x, 8), x)
+    from singa_amd import opt
+    hist = tc.run(0, 1, 0, 2, 16, "cnn", "mnist", opt.SGD(0.005, 0.9, 1e-5),
+                  True, 0, max_batches=12)
+    assert hist[1][0] < hist[0][0]          # loss decreases
+    assert hist[1][2] > 0.5                 # synthetic data is separable
+
+
+def test_char_rnn_runs():
+    cr = _import("rnn", "char_rnn")
+    data = cr.Data(cr.__file__, batch_size=4, seq_length=12)
+    m, dev, losses = cr.train(data, 2, hidden_size=12, seq_length=12,
+                              batch_size=4, lr=0.5, max_batches=6)
+    assert losses[1] < losses[0]
+    text = cr.sample(m, data, dev, "def ", 5)
+    assert len(text) == 9
+
+
+def test_onnx_tiny_gpt_import():
+    tm = _import("onnx", "text_models")
+    from singa_amd import device
+    assert tm.self_test(device.get_default_device()) < 1e-3
+
+
+def test_hfl_wire_and_fedavg():
+    sys.path.insert(0, os.path.join(ROOT, "hfl"))
+    try:
+        from src import wire
+        from src.server import Server
+    finally:
+        sys.path.pop(0)
+    a, b = socket.socketpair()
+    w = {"w": np.arange(6, dtype=np.float32).reshape(2, 3),
+         "step": np.array([3], np.int32)}
+    t = threading.Thread(target=wire.send_weights, args=(a, wire.GATHER, w))
+    t.start()
+    op, got = wire.receive_weights(b)
+    t.join()
+    assert op == wire.GATHER
+    np.testing.assert_array_equal(got["w"], w["w"])
+    assert got["step"].dtype == np.int32
+    s = Server(num_clients=2)
+    out = s.aggregate({"w": [w["w"], 3 * w["w"]]})
+    np.testing.assert_allclose(out["w"], 2 * w["w"])
+    s.sock.close()
+
+
+def test_gan_step():
+    sys.path.insert(0, os.path.join(ROOT, "gan"))
+    try:
+        for k in ("utils", "model", "vanilla"):
+            sys.modules.pop(k, None)
+        import vanilla
+        from singa_amd import device
+        t = vanilla.GANTrainer(device.get_default_device(), iterations=3,
+                               interval=1, hidden_size=16, batch=16,
+                               file_dir=os.path.join("/tmp", "gan_test_out"))
+        hist = t.train()
+        assert len(hist) == 3 and all(np.isfinite(h[1]) for h in hist)
+    finally:
+        sys.path.pop(0)
+        for k in ("utils", "model", "vanilla"):
+            sys.modules.pop(k, None)

@@ -113,8 +113,67 @@ def build_hip(force=False, verbose=True):
     return target
 
 
+def build_cpp(force=False, verbose=True):
+    """C++ API: ``lib/libsinga_amd_cpp.so`` (device / memory pool / tensor /
+    layers / FeedForwardNet / optimizers / IO / network over the same HIP
+    kernels) and its self-checking test program ``bin/singa_cpp_test``."""
+    build_hip(force, verbose)  # the kernel objects are linked into the library
+    os.makedirs(OBJ, exist_ok=True)
+    cpp = os.path.join(CSRC, "cpp")
+    inc = os.path.join(cpp, "include")
+    rt = os.path.join(CSRC, "runtime")
+    hd = os.path.join(CSRC, "hip")
+    hdrs = _headers(inc, rt, hd)
+    flags = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-parameter",
+             "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
+             "-I" + inc]
+    srcs = []
+    for root, _, files in os.walk(os.path.join(cpp, "src")):
+        srcs += [os.path.join(root, f) for f in sorted(files) if f.endswith(".cc")]
+    # the runtime pieces the C++ API re-exports (default symbol visibility)
+    srcs += [os.path.join(rt, f) for f in ("graph.cc", "logging.cc", "snapshot.cc")]
+    jobs, objs = [], []
+    for s in srcs:
+        o = os.path.join(OBJ, "cpp_" + os.path.relpath(s, CSRC).replace(os.sep, "_") + ".o")
+        objs.append(o)
+        if force or _newer(o, [s] + hdrs):
+            jobs.append(flags + ["-c", s, "-o", o])
+    if jobs and verbose:
+        print("[singa_amd.build] compiling %d C++ API sources" % len(jobs))
+    _compile_many(jobs, 8)
+    hip_objs = [os.path.join(OBJ, "hip_" + f + ".o")
+                for f in sorted(os.listdir(hd)) if f.endswith(".hip")]
+    libdir = os.path.join(HERE, "lib")
+    bindir = os.path.join(HERE, "bin")
+    os.makedirs(libdir, exist_ok=True)
+    os.makedirs(bindir, exist_ok=True)
+    lib = os.path.join(libdir, "libsinga_amd_cpp.so")
+    if jobs or not os.path.exists(lib) or _newer(lib, hip_objs):
+        _run(["g++", "-shared", "-o", lib] + objs + hip_objs +
+             ["-L" + os.path.join(ROCM, "lib"), "-lamdhip64",
+              "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+    outs = [lib]
+    tests = [("singa_cpp_test", os.path.join(cpp, "test", "test_main.cc"))]
+    ex = os.path.join(HERE, "..", "examples", "cpp")
+    if os.path.isdir(ex):
+        for root, _, files in os.walk(ex):
+            for f in sorted(files):
+                if f.endswith(".cc"):
+                    tests.append(("singa_" + os.path.splitext(f)[0].replace("-", "_"),
+                                  os.path.join(root, f)))
+    for name, src in tests:
+        exe = os.path.join(bindir, name)
+        if force or _newer(exe, [src, lib] + hdrs):
+            _run(flags + [src, "-o", exe, "-L" + libdir, "-lsinga_amd_cpp",
+                          "-Wl,-rpath,$ORIGIN/../lib",
+                          "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+        outs.append(exe)
+    return outs
+
+
 def build_all(force=False, verbose=True):
-    return [build_rt(force, verbose), build_hip(force, verbose)]
+    return [build_rt(force, verbose), build_hip(force, verbose)] + \
+        build_cpp(force, verbose)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,72 @@
+// Record encoders / decoders: turn (features, label) tensors into the byte
+// strings stored in record files and back.  CSV keeps one text line per
+// sample; the image codec stores 8-bit images as binary PPM / PGM with the
+// label in a comment line, so records remain viewable with ordinary tools
+// (no image library is linked; the reference's JPGEncoder/Decoder need
+// OpenCV).  API parity: reference include/singa/io/{encoder,decoder}.h.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../core/tensor.h"
+
+namespace singa {
+
+struct EncoderConf { std::string type = "csv"; std::string image_dim_order = "HWC"; };
+struct DecoderConf { std::string type = "csv"; bool has_label = true;
+                     std::string image_dim_order = "CHW"; };
+
+class Encoder {
+ public:
+  virtual ~Encoder() {}
+  virtual void Setup(const EncoderConf &conf) {}
+  /// data[0] = features, optional data[1] = one-element int label.
+  virtual std::string Encode(std::vector<Tensor> &data) = 0;
+};
+
+class Decoder {
+ public:
+  virtual ~Decoder() {}
+  virtual void Setup(const DecoderConf &conf) {}
+  virtual std::vector<Tensor> Decode(std::string value) = 0;
+};
+
+class CSVEncoder : public Encoder {
+ public:
+  std::string Encode(std::vector<Tensor> &data) override;
+};
+
+class CSVDecoder : public Decoder {
+ public:
+  void Setup(const DecoderConf &conf) override { has_label_ = conf.has_label; }
+  std::vector<Tensor> Decode(std::string value) override;
+  bool has_label() const { return has_label_; }
+
+ private:
+  bool has_label_ = true;
+};
+
+/// uint8 image tensor (HWC or CHW, 1 or 3 channels) <-> PPM/PGM bytes.
+class ImageEncoder : public Encoder {
+ public:
+  void Setup(const EncoderConf &conf) override { order_ = conf.image_dim_order; }
+  std::string Encode(std::vector<Tensor> &data) override;
+
+ private:
+  std::string order_ = "HWC";
+};
+
+class ImageDecoder : public Decoder {
+ public:
+  void Setup(const DecoderConf &conf) override { order_ = conf.image_dim_order; }
+  /// -> {float32 image in the configured order, int label (if present)}
+  std::vector<Tensor> Decode(std::string value) override;
+
+ private:
+  std::string order_ = "CHW";
+};
+
+std::shared_ptr<Encoder> CreateEncoder(const std::string &type);
+std::shared_ptr<Decoder> CreateDecoder(const std::string &type);
+
+}  // namespace singa

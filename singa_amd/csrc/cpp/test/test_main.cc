@@ -1,0 +1,767 @@
+// Self-checking test program of the C++ API (no external test framework).
+//   singa_cpp_test            host device only
+//   singa_cpp_test --gpu      every numeric test also on HipGPU 0, compared
+//                             with the host result of the same operation
+// Modelled on the reference's test/singa/test_*.cc suites (tensor math,
+// layers, optimizers, loss, metric, snapshot, feed-forward net, endpoint).
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <iostream>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "singa/singa.h"
+
+using namespace singa;
+
+static int g_failed = 0, g_checks = 0;
+static bool g_gpu = false;
+static std::shared_ptr<Device> g_dev;
+
+#define EXPECT(cond)                                                       \
+  do {                                                                     \
+    ++g_checks;                                                            \
+    if (!(cond)) {                                                         \
+      ++g_failed;                                                          \
+      std::printf("  FAILED %s:%d  %s\n", __FILE__, __LINE__, #cond);      \
+    }                                                                      \
+  } while (0)
+#define EXPECT_NEAR(a, b, tol)                                             \
+  do {                                                                     \
+    ++g_checks;                                                            \
+    double a_ = (a), b_ = (b);                                             \
+    if (!(std::fabs(a_ - b_) <= (tol) * (1.0 + std::fabs(b_)))) {          \
+      ++g_failed;                                                          \
+      std::printf("  FAILED %s:%d  %s = %g vs %s = %g\n", __FILE__,        \
+                  __LINE__, #a, a_, #b, b_);                               \
+    }                                                                      \
+  } while (0)
+
+static Tensor FromVec(const std::vector<float> &v, const Shape &s,
+                      std::shared_ptr<Device> dev) {
+  Tensor t(s, dev);
+  t.CopyDataFromHostPtr(v.data(), v.size());
+  return t;
+}
+static Tensor FromInts(const std::vector<int> &v, const Shape &s,
+                       std::shared_ptr<Device> dev) {
+  Tensor t(s, dev, kInt);
+  t.CopyDataFromHostPtr(v.data(), v.size());
+  return t;
+}
+static std::vector<float> ToVec(const Tensor &t) {
+  return t.Contiguous().Clone(defaultDevice).ToVector<float>();
+}
+static std::vector<float> Rand(size_t n, unsigned seed, float scale = 1.f) {
+  std::mt19937 g(seed);
+  std::normal_distribution<float> d(0.f, scale);
+  std::vector<float> v(n);
+  for (auto &x : v) x = d(g);
+  return v;
+}
+static void ExpectVecNear(const std::vector<float> &a,
+                          const std::vector<float> &b, double tol,
+                          const char *what) {
+  ++g_checks;
+  if (a.size() != b.size()) {
+    ++g_failed;
+    std::printf("  FAILED %s: size %zu vs %zu\n", what, a.size(), b.size());
+    return;
+  }
+  double worst = 0;
+  for (size_t i = 0; i < a.size(); ++i)
+    worst = std::max(worst, std::fabs(double(a[i]) - b[i]) / (1.0 + std::fabs(b[i])));
+  if (!(worst <= tol)) {
+    ++g_failed;
+    std::printf("  FAILED %s: max rel diff %g > %g\n", what, worst, tol);
+  }
+}
+
+// ---- tests that run per device ------------------------------------------------------
+static void TestTensorMath(std::shared_ptr<Device> dev) {
+  auto a = Rand(12, 1), b = Rand(12, 2);
+  Tensor A = FromVec(a, {3, 4}, dev), B = FromVec(b, {3, 4}, dev);
+  auto sum = ToVec(A + B), prod = ToVec(A * B);
+  for (int i = 0; i < 12; ++i) {
+    EXPECT_NEAR(sum[i], a[i] + b[i], 1e-6);
+    EXPECT_NEAR(prod[i], a[i] * b[i], 1e-6);
+  }
+  auto r = ToVec(ReLU(A));
+  auto s = ToVec(Sigmoid(A));
+  for (int i = 0; i < 12; ++i) {
+    EXPECT_NEAR(r[i], std::max(a[i], 0.f), 1e-6);
+    EXPECT_NEAR(s[i], 1.f / (1.f + std::exp(-a[i])), 1e-5);
+  }
+  auto sc = ToVec(A * 2.5f + 1.f);
+  EXPECT_NEAR(sc[5], a[5] * 2.5f + 1.f, 1e-6);
+  auto lt = ToVec(A < 0.f);
+  EXPECT_NEAR(lt[3], a[3] < 0 ? 1.f : 0.f, 0);
+  // GEMM incl. transposed views
+  Tensor C = Mult(A, B.T());  // (3,4)x(4,3)
+  auto c = ToVec(C);
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float ref = 0;
+      for (int k = 0; k < 4; ++k) ref += a[i * 4 + k] * b[j * 4 + k];
+      EXPECT_NEAR(c[i * 3 + j], ref, 1e-5);
+    }
+  Tensor D = Mult(A.T(), B);  // (4,3)x(3,4)
+  auto d = ToVec(D);
+  float ref = 0;
+  for (int k = 0; k < 3; ++k) ref += a[k * 4 + 1] * b[k * 4 + 2];
+  EXPECT_NEAR(d[1 * 4 + 2], ref, 1e-5);
+  // row / column helpers and reductions
+  Tensor v = FromVec({1, 2, 3, 4}, {4}, dev);
+  Tensor M = A.Clone();
+  AddRow(v, &M);
+  EXPECT_NEAR(ToVec(M)[6], a[6] + 3, 1e-6);
+  Tensor col = FromVec({10, 20, 30}, {3}, dev);
+  MultColumn(col, &M);
+  EXPECT_NEAR(ToVec(M)[6], (a[6] + 3) * 20, 1e-5);
+  Tensor sr(Shape{4}, dev), scol(Shape{3}, dev);
+  SumRows(A, &sr);
+  SumColumns(A, &scol);
+  EXPECT_NEAR(ToVec(sr)[1], a[1] + a[5] + a[9], 1e-5);
+  EXPECT_NEAR(ToVec(scol)[2], a[8] + a[9] + a[10] + a[11], 1e-5);
+  float total = 0, l1 = 0, l2 = 0;
+  for (float x : a) { total += x; l1 += std::fabs(x); l2 += x * x; }
+  EXPECT_NEAR(Sum<float>(A), total, 1e-5);
+  EXPECT_NEAR(A.L1(), l1 / 12, 1e-5);
+  EXPECT_NEAR(A.L2(), std::sqrt(l2) / 12, 1e-5);
+  // softmax rows sum to one; cross entropy
+  Tensor P = SoftMax(A);
+  auto p = ToVec(P);
+  EXPECT_NEAR(p[0] + p[1] + p[2] + p[3], 1.0, 1e-5);
+  Tensor t = FromInts({1, 0, 3}, {3}, dev);
+  Tensor loss(Shape{3}, dev);
+  ComputeCrossEntropy(P, t, &loss);
+  EXPECT_NEAR(ToVec(loss)[2], -std::log(p[2 * 4 + 3]), 1e-5);
+  SoftmaxCrossEntropyBwd(t, &P);
+  EXPECT_NEAR(ToVec(P)[1], p[1] - 1.f, 1e-6);
+  // layout
+  Tensor cat = ConcatenateColumns({A, B});
+  EXPECT(cat.shape(1) == 8);
+  EXPECT_NEAR(ToVec(cat)[8 + 5], b[4 + 1], 1e-6);
+  Tensor sl = SliceOn(cat, 2, 6, 1);
+  EXPECT_NEAR(ToVec(sl)[0], a[2], 1e-6);
+  EXPECT_NEAR(ToVec(sl)[2], b[0], 1e-6);
+  Tensor rows = CopyRows(A, 1, 3);
+  EXPECT_NEAR(ToVec(rows)[0], a[4], 1e-6);
+  // casts and random
+  Tensor I = A.Clone();
+  I.SetValue(3.7f);
+  I.AsType(kInt);
+  EXPECT(I.Clone(defaultDevice).ToVector<int>()[0] == 3);
+  Tensor u(Shape{4096}, dev);
+  Uniform(0.f, 1.f, &u);
+  float mean = Sum<float>(u) / 4096;
+  EXPECT(mean > 0.45 && mean < 0.55);
+  Gaussian(1.f, 2.f, &u);
+  mean = Sum<float>(u) / 4096;
+  EXPECT(mean > 0.8 && mean < 1.2);
+  Bernoulli(0.3f, &u);
+  mean = Sum<float>(u) / 4096;
+  EXPECT(mean > 0.25 && mean < 0.35);
+}
+
+struct LayerResult {
+  std::vector<float> y, dx;
+  std::vector<std::vector<float>> dp;
+};
+
+static LayerResult RunLayer(const std::string &type, const LayerConf &base,
+                            const Shape &sample, size_t batch,
+                            std::shared_ptr<Device> dev, unsigned seed) {
+  LayerConf conf = base;
+  conf.type = type;
+  conf.name = "l";
+  auto layer = CreateLayer(type);
+  layer->Setup(sample, conf);
+  layer->ToDevice(dev);
+  unsigned s = seed;
+  for (auto p : layer->param_values()) {
+    // BatchNorm's running variance must stay positive
+    bool positive = layer->layer_type() == "BatchNorm";
+    auto v = Rand(p.Size(), ++s, 0.3f);
+    if (positive) for (auto &x : v) x = std::fabs(x) + 0.5f;
+    p.CopyDataFromHostPtr(v.data(), v.size());
+  }
+  Shape xs{batch};
+  for (size_t d : sample) xs.push_back(d);
+  Tensor x = FromVec(Rand(Product(xs), seed + 100), xs, dev);
+  Tensor y = layer->Forward(kTrain, x);
+  Tensor dy = FromVec(Rand(y.Size(), seed + 200), y.shape(), dev);
+  auto ret = layer->Backward(kTrain, dy);
+  LayerResult r;
+  r.y = ToVec(y);
+  r.dx = ToVec(ret.first);
+  for (auto &g : ret.second) r.dp.push_back(ToVec(g));
+  return r;
+}
+
+// finite-difference check of dx on the host for a scalar objective sum(y*dy)
+static void GradCheck(const std::string &type, const LayerConf &base,
+                      const Shape &sample, size_t batch) {
+  LayerConf conf = base;
+  conf.type = type;
+  conf.name = "g";
+  auto layer = CreateLayer(type);
+  layer->Setup(sample, conf);
+  unsigned s = 7;
+  for (auto p : layer->param_values()) {
+    auto v = Rand(p.Size(), ++s, 0.3f);
+    if (layer->layer_type() == "BatchNorm") for (auto &x : v) x = std::fabs(x) + 0.5f;
+    p.CopyDataFromHostPtr(v.data(), v.size());
+  }
+  Shape xs{batch};
+  for (size_t d : sample) xs.push_back(d);
+  auto xv = Rand(Product(xs), 11);
+  Tensor x = FromVec(xv, xs, defaultDevice);
+  Tensor y = layer->Forward(kTrain, x);
+  auto dyv = Rand(y.Size(), 12);
+  Tensor dy = FromVec(dyv, y.shape(), defaultDevice);
+  auto dx = ToVec(layer->Backward(kTrain, dy).first);
+  auto objective = [&](const std::vector<float> &in) {
+    Tensor xi = FromVec(in, xs, defaultDevice);
+    auto yy = ToVec(layer->Forward(kEval | kTrain, xi));
+    layer->Backward(kTrain, dy);  // pop the cache
+    double acc = 0;
+    for (size_t i = 0; i < yy.size(); ++i) acc += double(yy[i]) * dyv[i];
+    return acc;
+  };
+  const float eps = 1e-2f;
+  for (size_t i = 0; i < xv.size(); i += std::max<size_t>(1, xv.size() / 7)) {
+    auto xp = xv, xm = xv;
+    xp[i] += eps;
+    xm[i] -= eps;
+    double num = (objective(xp) - objective(xm)) / (2 * eps);
+    ++g_checks;
+    if (std::fabs(num - dx[i]) > 2e-2 * (1 + std::fabs(num))) {
+      ++g_failed;
+      std::printf("  FAILED gradcheck %s at %zu: numeric %g vs analytic %g\n",
+                  type.c_str(), i, num, dx[i]);
+    }
+  }
+}
+
+struct LayerCase {
+  std::string type;
+  LayerConf conf;
+  Shape sample;
+  size_t batch;
+};
+
+static std::vector<LayerCase> LayerCases() {
+  std::vector<LayerCase> cases;
+  LayerConf c;
+  c.dense_conf.num_output = 5;
+  cases.push_back({"singacpp_dense", c, {7}, 4});
+  c = LayerConf();
+  c.dense_conf.num_output = 3;
+  c.dense_conf.transpose = true;
+  cases.push_back({"singacpp_dense", c, {6}, 2});
+  c = LayerConf();
+  cases.push_back({"singacpp_relu", c, {3, 4, 4}, 2});
+  cases.push_back({"singacpp_sigmoid", c, {10}, 3});
+  cases.push_back({"singacpp_tanh", c, {10}, 3});
+  c.relu_conf.negative_slope = 0.1f;
+  cases.push_back({"singacpp_relu", c, {10}, 3});
+  c = LayerConf();
+  c.convolution_conf.num_output = 4;
+  c.convolution_conf.set_kernel(3);
+  c.convolution_conf.set_pad(1);
+  cases.push_back({"singacpp_convolution", c, {3, 8, 8}, 2});
+  c.convolution_conf.set_stride(2);
+  c.convolution_conf.bias_term = false;
+  cases.push_back({"singacpp_convolution", c, {4, 9, 9}, 2});
+  c = LayerConf();
+  c.convolution_conf.num_output = 6;
+  c.convolution_conf.set_kernel(1);
+  c.convolution_conf.group = 2;
+  cases.push_back({"singacpp_convolution", c, {4, 5, 5}, 2});
+  c = LayerConf();
+  c.pooling_conf.set_kernel(2);
+  c.pooling_conf.set_stride(2);
+  cases.push_back({"singacpp_pooling", c, {3, 8, 8}, 2});
+  c.pooling_conf.pool = PoolingConf::AVE;
+  c.pooling_conf.set_kernel(3);
+  c.pooling_conf.set_pad(1);
+  cases.push_back({"singacpp_pooling", c, {2, 7, 7}, 2});
+  c = LayerConf();
+  cases.push_back({"singacpp_batchnorm", c, {3, 4, 4}, 4});
+  cases.push_back({"singacpp_lrn", c, {8, 3, 3}, 2});
+  cases.push_back({"singacpp_softmax", c, {6}, 3});
+  cases.push_back({"singacpp_flatten", c, {2, 3, 4}, 2});
+  cases.push_back({"singacpp_prelu", c, {3, 2, 2}, 2});
+  return cases;
+}
+
+static void TestLayersGradient() {
+  for (auto &lc : LayerCases()) {
+    if (lc.type == "singacpp_flatten") continue;
+    GradCheck(lc.type, lc.conf, lc.sample, lc.batch);
+  }
+}
+
+static void TestLayersGpuVsCpu() {
+  unsigned seed = 40;
+  for (auto &lc : LayerCases()) {
+    ++seed;
+    LayerResult c = RunLayer(lc.type, lc.conf, lc.sample, lc.batch,
+                             defaultDevice, seed);
+    LayerResult g = RunLayer(lc.type, lc.conf, lc.sample, lc.batch, g_dev, seed);
+    ExpectVecNear(g.y, c.y, 2e-4, (lc.type + " forward").c_str());
+    ExpectVecNear(g.dx, c.dx, 2e-4, (lc.type + " dx").c_str());
+    EXPECT(g.dp.size() == c.dp.size());
+    for (size_t i = 0; i < std::min(g.dp.size(), c.dp.size()); ++i)
+      ExpectVecNear(g.dp[i], c.dp[i], 5e-4, (lc.type + " dparam").c_str());
+  }
+}
+
+static void TestDropoutAndMulti(std::shared_ptr<Device> dev) {
+  LayerConf c;
+  c.type = "singacpp_dropout";
+  c.dropout_conf.dropout_ratio = 0.4f;
+  auto drop = CreateLayer(c.type);
+  drop->Setup(Shape{1000}, c);
+  Tensor x(Shape{8, 1000}, dev);
+  x.SetValue(1.f);
+  Tensor y = drop->Forward(kTrain, x);
+  float kept = Sum<float>(y) / 8000;  // E[y] = 1
+  EXPECT(kept > 0.93 && kept < 1.07);
+  EXPECT_NEAR(Sum<float>(drop->Forward(kEval, x)), 8000, 1e-6);
+  Tensor dx = drop->Backward(kTrain, x).first;
+  EXPECT_NEAR(Sum<float>(dx), Sum<float>(y), 1e-5);
+
+  LayerConf cc;
+  cc.type = "singacpp_concat";
+  cc.concat_conf.axis = 1;
+  auto concat = CreateLayer(cc.type);
+  concat->Setup(std::vector<Shape>{{3}, {2}}, cc);
+  Tensor a = FromVec(Rand(6, 1), {2, 3}, dev), b = FromVec(Rand(4, 2), {2, 2}, dev);
+  auto out = concat->Forward(kTrain, std::vector<Tensor>{a, b});
+  EXPECT(out[0].shape(1) == 5);
+  auto back = concat->Backward(kTrain, out).first;
+  ExpectVecNear(ToVec(back[1]), ToVec(b), 1e-6, "concat backward");
+
+  LayerConf sc;
+  sc.type = "singacpp_slice";
+  sc.slice_conf.axis = 1;
+  sc.slice_conf.slice_point = {2};
+  auto slice = CreateLayer(sc.type);
+  slice->Setup(Shape{5}, sc);
+  auto parts = slice->Forward(kTrain, std::vector<Tensor>{out[0]});
+  EXPECT(parts.size() == 2 && parts[1].shape(1) == 3);
+  auto joined = slice->Backward(kTrain, parts).first;
+  ExpectVecNear(ToVec(joined[0]), ToVec(out[0]), 1e-6, "slice backward");
+
+  LayerConf pc;
+  pc.type = "singacpp_split";
+  pc.split_conf.output_size = 3;
+  auto split = CreateLayer(pc.type);
+  split->Setup(Shape{3}, pc);
+  auto reps = split->Forward(kTrain, std::vector<Tensor>{a});
+  EXPECT(reps.size() == 3);
+  auto g = split->Backward(kTrain, reps).first;
+  EXPECT_NEAR(ToVec(g[0])[0], 3 * ToVec(a)[0], 1e-5);
+
+  LayerConf mc;
+  mc.type = "singacpp_merge";
+  auto merge = CreateLayer(mc.type);
+  merge->Setup(Shape{3}, mc);
+  auto m = merge->Forward(kTrain, std::vector<Tensor>{a, a});
+  EXPECT_NEAR(ToVec(m[0])[2], 2 * ToVec(a)[2], 1e-5);
+  EXPECT(merge->Backward(kTrain, m).first.size() == 2);
+}
+
+static void TestOptimizers(std::shared_ptr<Device> dev) {
+  OptimizerConf conf;
+  conf.momentum = 0.9f;
+  SGD sgd;
+  sgd.Setup(conf);
+  Tensor w = FromVec({0.1f, 0.2f, 0.3f, 0.4f}, {4}, dev);
+  Tensor g = FromVec({0.1f, 0.1f, 0.1f, 0.1f}, {4}, dev);
+  sgd.Apply(0, 0.1f, "w", g, w);
+  EXPECT_NEAR(ToVec(w)[0], 0.1f - 0.01f, 1e-6);
+  sgd.Apply(1, 0.1f, "w", g, w);  // v = 0.9*0.01 + 0.01
+  EXPECT_NEAR(ToVec(w)[0], 0.09f - 0.019f, 1e-6);
+
+  Nesterov nes;
+  nes.Setup(conf);
+  Tensor w2 = FromVec({0.1f}, {1}, dev), g2 = FromVec({0.1f}, {1}, dev);
+  nes.Apply(0, 0.1f, "w", g2, w2);  // v'=0.01, w -= 1.9*0.01
+  EXPECT_NEAR(ToVec(w2)[0], 0.1f - 0.019f, 1e-6);
+
+  AdaGrad ada;
+  OptimizerConf ac;
+  ac.delta = 1e-8f;
+  ada.Setup(ac);
+  Tensor w3 = FromVec({0.1f}, {1}, dev), g3 = FromVec({0.01f}, {1}, dev);
+  ada.Apply(0, 0.1f, "w", g3, w3);  // g/sqrt(g^2) = 1
+  EXPECT_NEAR(ToVec(w3)[0], 0.0f, 1e-4);
+
+  RMSProp rms;
+  OptimizerConf rc;
+  rc.rho = 0.9f;
+  rc.delta = 1e-8f;
+  rms.Setup(rc);
+  Tensor w4 = FromVec({0.1f}, {1}, dev), g4 = FromVec({0.01f}, {1}, dev);
+  rms.Apply(0, 0.1f, "w", g4, w4);  // h = 0.1*1e-4, upd = 0.01/sqrt(1e-5)
+  EXPECT_NEAR(ToVec(w4)[0], 0.1f - 0.1f * 0.01f / std::sqrt(1e-5f + 1e-8f), 1e-4);
+
+  // regularizer + constraint + lr multiplier through the name-based Apply
+  OptimizerConf oc;
+  oc.has_regularizer = true;
+  oc.regularizer.coefficient = 0.5f;
+  SGD reg;
+  reg.Setup(oc);
+  reg.SetLearningRateGenerator([](int) { return 0.1f; });
+  ParamSpec spec;
+  spec.name = "w";
+  spec.lr_mult = 2.f;
+  reg.Register("w", spec);
+  Tensor w5 = FromVec({1.f}, {1}, dev), g5 = FromVec({0.f}, {1}, dev);
+  reg.Apply(0, "w", g5, w5);  // grad = 0.5*w, lr = 0.2
+  EXPECT_NEAR(ToVec(w5)[0], 1.f - 0.2f * 0.5f, 1e-6);
+  Constraint clip("l2", 1.f);
+  Tensor big = FromVec({3.f, 4.f}, {2}, dev), dummy = big.Clone();
+  clip.Apply(0, big, dummy);
+  EXPECT_NEAR(ToVec(big)[1], 0.8f, 1e-5);
+}
+
+static void TestLossMetric(std::shared_ptr<Device> dev) {
+  Tensor p = FromVec({1, 2, 3, 1, 0, -1}, {2, 3}, dev);
+  Tensor t = FromVec({1, 1, 1, 0, 0, 0}, {2, 3}, dev);
+  MSE mse;
+  Tensor l = mse.Forward(kTrain, p, t);
+  EXPECT_NEAR(ToVec(l)[0], 0.5f * (0 + 1 + 4), 1e-6);
+  Tensor g = mse.Backward();
+  EXPECT_NEAR(ToVec(g)[2], (3 - 1) / 2.f, 1e-6);
+  SoftmaxCrossEntropy ce;
+  Tensor lab = FromInts({2, 0}, {2}, dev);
+  float loss = ce.Evaluate(kTrain, p, lab);
+  double z0 = std::exp(1.) + std::exp(2.) + std::exp(3.);
+  double z1 = std::exp(1.) + std::exp(0.) + std::exp(-1.);
+  EXPECT_NEAR(loss, 0.5 * (-std::log(std::exp(3.) / z0) - std::log(std::exp(1.) / z1)), 1e-5);
+  Tensor cg = ce.Backward();
+  EXPECT_NEAR(ToVec(cg)[2], std::exp(3.) / z0 - 1, 1e-5);
+  Accuracy acc;
+  EXPECT_NEAR(acc.Evaluate(p, lab), 1.0, 1e-6);
+  Tensor lab2 = FromInts({0, 1}, {2}, dev);
+  EXPECT_NEAR(acc.Evaluate(p, lab2), 0.0, 1e-6);
+  Accuracy top2(2);
+  EXPECT_NEAR(top2.Evaluate(p, FromInts({1, 1}, {2}, dev)), 1.0, 1e-6);
+}
+
+static FeedForwardNet MakeMlp() {
+  FeedForwardNet net;
+  Shape in{2};
+  LayerConf d1;
+  d1.name = "fc1";
+  d1.type = "singacpp_dense";
+  d1.dense_conf.num_output = 16;
+  ParamSpec w;
+  w.name = "fc1_w";
+  w.filler.type = "gaussian";
+  w.filler.std = 0.5f;
+  ParamSpec b;
+  b.name = "fc1_b";
+  d1.param = {w, b};
+  net.Add(d1, &in);
+  LayerConf r;
+  r.name = "relu1";
+  r.type = "singacpp_relu";
+  net.Add(r);
+  LayerConf d2;
+  d2.name = "fc2";
+  d2.type = "singacpp_dense";
+  d2.dense_conf.num_output = 2;
+  w.name = "fc2_w";
+  b.name = "fc2_b";
+  d2.param = {w, b};
+  net.Add(d2);
+  return net;
+}
+
+static void MakeToy(std::vector<float> *x, std::vector<int> *y, size_t n) {
+  std::mt19937 g(3);
+  std::uniform_real_distribution<float> u(-1, 1);
+  for (size_t i = 0; i < n; ++i) {
+    float a = u(g), b = u(g);
+    x->push_back(a);
+    x->push_back(b);
+    y->push_back(a * a + b * b < 0.5f ? 1 : 0);
+  }
+}
+
+static void TestFeedForwardNet(std::shared_ptr<Device> dev, bool graph) {
+  defaultDevice->SetRandSeed(1);
+  dev->SetRandSeed(1);
+  FeedForwardNet net = MakeMlp();
+  net.set_verbose(false);
+  SGD sgd;
+  OptimizerConf oc;
+  oc.momentum = 0.9f;
+  sgd.Setup(oc);
+  sgd.SetLearningRateGenerator([](int) { return 0.1f; });
+  SoftmaxCrossEntropy loss;
+  Accuracy acc;
+  net.Compile(true, &sgd, &loss, &acc);
+  net.ToDevice(dev);
+  std::vector<float> xv;
+  std::vector<int> yv;
+  MakeToy(&xv, &yv, 512);
+  Tensor x = FromVec(xv, {512, 2}, dev), y = FromInts(yv, {512}, dev);
+  float first = net.TrainOnBatch(0, x, y).first;
+  if (graph) {
+    // record one training step, then replay it
+    Tensor bx = CopyRows(x, 0, 128), by = CopyRows(y, 0, 128);
+    dev->Sync();
+    dev->EnableGraph(true);
+    Tensor fea = net.Forward(kTrain, bx);
+    Tensor l = loss.Forward(kTrain, fea, by);
+    auto grads = net.Backward(kTrain, loss.Backward() * (1.f / 128));
+    auto values = net.GetParamValues();
+    auto names = net.GetParamNames();
+    for (size_t k = 0; k < grads.size(); ++k)
+      sgd.Apply(0, 0.1f, names[k], grads[k], values[k]);
+    dev->EnableGraph(false);
+    EXPECT(dev->graph()->nodes().size() > 10);
+    for (int it = 0; it < 150; ++it) dev->RunGraph(it % 2 == 0);
+    dev->Sync();
+    dev->ResetGraph();
+  } else {
+    net.Train(64, 25, x, y);
+  }
+  auto ev = net.Evaluate(x, y, 128);
+  float final_loss = Sum<float>(ev.first) / ev.first.Size();
+  float final_acc = Sum<float>(ev.second) / ev.second.Size();
+  EXPECT(final_loss < first);
+  EXPECT(final_acc > (graph ? 0.7f : 0.9f));
+  Tensor pred = net.Predict(x, 100);
+  EXPECT(pred.shape(0) == 512 && pred.shape(1) == 2);
+  // clone shares values, not storage
+  FeedForwardNet twin = net.Clone(defaultDevice);
+  auto a = ToVec(net.GetParamValues()[0]), b = ToVec(twin.GetParamValues()[0]);
+  ExpectVecNear(a, b, 0, "clone copies parameters");
+}
+
+static void TestLocalUpdater() {
+  // two replicas on the host, each sees half of every batch: the averaged
+  // update must equal the single-model update on the whole batch
+  SGD opt;
+  opt.SetLearningRateGenerator([](int) { return 0.5f; });
+  auto up = std::make_shared<LocalUpdater>(2, &opt);
+  ParamSpec spec;
+  spec.name = "w";
+  up->Register("w", spec);
+  Tensor w0 = FromVec({1.f, 2.f}, {2}, defaultDevice), w1 = w0.Clone();
+  Tensor g0 = FromVec({0.2f, 0.4f}, {2}, defaultDevice);
+  Tensor g1 = FromVec({0.6f, 0.0f}, {2}, defaultDevice);
+  std::thread t0([&] { for (int s = 0; s < 3; ++s) up->Apply(s, "w", g0, w0); });
+  std::thread t1([&] { for (int s = 0; s < 3; ++s) up->Apply(s, "w", g1, w1); });
+  t0.join();
+  t1.join();
+  EXPECT_NEAR(ToVec(w0)[0], 1.f - 3 * 0.5f * 0.4f, 1e-5);
+  EXPECT_NEAR(ToVec(w1)[1], 2.f - 3 * 0.5f * 0.2f, 1e-5);
+  ExpectVecNear(ToVec(w0), ToVec(w1), 0, "replicas agree");
+}
+
+static void TestMemPoolAndDevice() {
+  HostMemPool pool;
+  void *a = nullptr, *b = nullptr;
+  pool.Malloc(&a, 1000);
+  pool.Free(a);
+  pool.Malloc(&b, 900);  // same 1 KiB class: the chunk is reused
+  EXPECT(a == b);
+  pool.Free(b);
+  EXPECT(HipMemPool::RoundUp(1) == 512);
+  EXPECT(HipMemPool::RoundUp(513) == 1024);
+  EXPECT(HipMemPool::RoundUp((1 << 20) + 1) == (2u << 20));
+  EXPECT(HipMemPool::RoundUp((2 << 20) + 1) == (4u << 20));
+  // lazy allocation
+  Tensor t(Shape{100});
+  EXPECT(!t.initialized());
+  t.SetValue(1.f);
+  EXPECT(t.initialized());
+  if (g_gpu) {
+    auto *hp = new HipMemPool();
+    int before = hp->driver_calls();
+    void *p = nullptr, *q = nullptr;
+    hp->Malloc(&p, 4096);
+    hp->Free(p);
+    hp->Malloc(&q, 4000);
+    EXPECT(p == q);
+    EXPECT(hp->driver_calls() == size_t(before + 1));
+    hp->Free(q);
+    auto usage = hp->GetMemUsage();
+    EXPECT(usage.second > (size_t(100) << 30));  // 288 GB part
+    delete hp;
+    EXPECT(Platform::GetNumGPUs() >= 1);
+    std::string q0 = Platform::DeviceQuery(0);
+    EXPECT(q0.find("gfx950") != std::string::npos);
+  }
+}
+
+static void TestIo() {
+  // snapshot round trip
+  std::string prefix = "/tmp/singa_cpp_test_snapshot";
+  {
+    Snapshot w(prefix, Snapshot::kWrite);
+    w.Write("a", FromVec({1, 2, 3, 4, 5, 6}, {2, 3}, defaultDevice));
+    w.Write("b", FromInts({7, 8}, {2}, defaultDevice));
+  }
+  Snapshot r(prefix, Snapshot::kRead);
+  auto all = r.Read();
+  EXPECT(all.size() == 2);
+  EXPECT(r.ReadShape("a") == (Shape{2, 3}));
+  EXPECT_NEAR(ToVec(r.Read("a"))[4], 5, 0);
+  EXPECT(r.Read("b").ToVector<int>()[1] == 8);
+  // csv
+  CSVEncoder enc;
+  CSVDecoder dec;
+  std::vector<Tensor> rec{FromVec({1.5f, -2.f, 3.25f}, {3}, defaultDevice),
+                          FromInts({4}, {1}, defaultDevice)};
+  std::string line = enc.Encode(rec);
+  EXPECT(line == "4,1.5,-2,3.25");
+  auto back = dec.Decode(line);
+  EXPECT(back.size() == 2 && back[1].ToVector<int>()[0] == 4);
+  EXPECT_NEAR(ToVec(back[0])[2], 3.25, 0);
+  // image codec, CHW <-> PPM
+  std::vector<float> px(3 * 4 * 5);
+  for (size_t i = 0; i < px.size(); ++i) px[i] = float((i * 7) % 256);
+  ImageEncoder ienc;
+  EncoderConf ec;
+  ec.image_dim_order = "CHW";
+  ienc.Setup(ec);
+  std::vector<Tensor> irec{FromVec(px, {3, 4, 5}, defaultDevice),
+                           FromInts({9}, {1}, defaultDevice)};
+  std::string ppm = ienc.Encode(irec);
+  EXPECT(ppm.substr(0, 2) == "P6");
+  ImageDecoder idec;
+  auto img = idec.Decode(ppm);
+  EXPECT(img.size() == 2 && img[1].ToVector<int>()[0] == 9);
+  ExpectVecNear(ToVec(img[0]), px, 0, "image codec round trip");
+  // transformer
+  ImageTransformer tr;
+  TransformerConf tc;
+  tc.resize_height = 8;
+  tc.resize_width = 10;
+  tc.crop_height = 6;
+  tc.crop_width = 6;
+  tc.horizontal_mirror = true;
+  tr.Setup(tc);
+  Tensor out = tr.Apply(kTrain, img[0]);
+  EXPECT(out.shape() == (Shape{3, 6, 6}));
+  Tensor ev = tr.Apply(kEval, img[0]);
+  Tensor manual = resize(img[0], 8, 10, "CHW");
+  manual = crop(manual, 6, 6, 1, 2, "CHW");
+  ExpectVecNear(ToVec(ev), ToVec(manual), 1e-6, "eval = resize + centre crop");
+  Tensor flipped = mirror(img[0], true, false, "CHW");
+  EXPECT_NEAR(ToVec(flipped)[0], px[4], 0);
+  Tensor same = resize(img[0], 4, 5, "CHW");
+  ExpectVecNear(ToVec(same), px, 1e-5, "identity resize");
+  // varint
+  char buf[16];
+  for (uint64_t v : {0ull, 127ull, 128ull, 16383ull, 16384ull, 2097151ull,
+                     2097152ull, 4294967295ull, 4294967296ull}) {
+    uint64_t got = 0;
+    size_t n = appendInteger(buf, v);
+    EXPECT(readInteger(buf, got) == n && got == v);
+  }
+  Tokenizer tok("a b,c", " ,");
+  std::string s1, s2, s3;
+  tok >> s1 >> s2 >> s3;
+  EXPECT(s1 == "a" && s2 == "b" && s3 == "c" && !tok.Valid());
+}
+
+static void TestEndPoint() {
+  NetworkThread a(0), b(0);
+  EndPoint *to_b = a.epf_->getEp("127.0.0.1", b.port());
+  std::string big(300000, 'x');
+  for (int i = 0; i < 5; ++i) {
+    Message m;
+    std::string meta = "m" + std::to_string(i);
+    m.setMetadata(meta.data(), meta.size());
+    m.setPayload(big.data(), big.size());
+    EXPECT(to_b->send(&m) > 0);
+  }
+  EndPoint *from_a = b.epf_->waitAny(EP_TIMEOUT);
+  EXPECT(from_a != nullptr);
+  if (!from_a) return;
+  EXPECT(from_a->peer() == "127.0.0.1:" + std::to_string(a.port()));
+  for (int i = 0; i < 5; ++i) {
+    Message *m = from_a->recv(EP_TIMEOUT);
+    EXPECT(m != nullptr);
+    if (!m) return;
+    void *meta, *payload;
+    size_t ms = m->getMetadata(&meta), ps = m->getPayload(&payload);
+    EXPECT(std::string(static_cast<char *>(meta), ms) == "m" + std::to_string(i));
+    EXPECT(ps == big.size());
+    delete m;
+  }
+  EXPECT(to_b->drain());
+  EXPECT(to_b->pending_acks() == 0);
+  // reply over the same connection
+  Message reply;
+  reply.setPayload("pong", 4);
+  EXPECT(from_a->send(&reply) > 0);
+  Message *r = to_b->recv(EP_TIMEOUT);
+  EXPECT(r != nullptr);
+  if (r) {
+    void *p;
+    EXPECT(r->getPayload(&p) == 4);
+    delete r;
+  }
+  // an unreachable peer fails after the retries instead of hanging
+  EndPoint *nowhere = a.epf_->getEp("127.0.0.1", 1);
+  Message lost;
+  lost.setPayload("x", 1);
+  EXPECT(nowhere->send(&lost) == -1);
+}
+
+static void Run(const char *name, const std::function<void()> &fn) {
+  int before = g_failed;
+  std::printf("[ RUN  ] %s\n", name);
+  try {
+    fn();
+  } catch (const std::exception &e) {
+    ++g_failed;
+    std::printf("  EXCEPTION %s\n", e.what());
+  }
+  std::printf("[ %s ] %s\n", g_failed == before ? " OK " : "FAIL", name);
+  std::fflush(stdout);
+}
+
+int main(int argc, char **argv) {
+  for (int i = 1; i < argc; ++i)
+    if (std::string(argv[i]) == "--gpu") g_gpu = true;
+  singa::LogToStderr();
+  auto host = defaultDevice;
+  Run("MemPoolAndDevice", TestMemPoolAndDevice);
+  Run("TensorMath/cpu", [&] { TestTensorMath(host); });
+  Run("LayersGradient/cpu", TestLayersGradient);
+  Run("DropoutAndMulti/cpu", [&] { TestDropoutAndMulti(host); });
+  Run("Optimizers/cpu", [&] { TestOptimizers(host); });
+  Run("LossMetric/cpu", [&] { TestLossMetric(host); });
+  Run("FeedForwardNet/cpu", [&] { TestFeedForwardNet(host, false); });
+  Run("FeedForwardNet/cpu-graph", [&] { TestFeedForwardNet(host, true); });
+  Run("LocalUpdater", TestLocalUpdater);
+  Run("Io", TestIo);
+  Run("EndPoint", TestEndPoint);
+  if (g_gpu) {
+    g_dev = Platform::CreateCudaGPUs(1)[0];
+    Run("TensorMath/gpu", [&] { TestTensorMath(g_dev); });
+    Run("LayersGpuVsCpu", TestLayersGpuVsCpu);
+    Run("DropoutAndMulti/gpu", [&] { TestDropoutAndMulti(g_dev); });
+    Run("Optimizers/gpu", [&] { TestOptimizers(g_dev); });
+    Run("LossMetric/gpu", [&] { TestLossMetric(g_dev); });
+    Run("FeedForwardNet/gpu", [&] { TestFeedForwardNet(g_dev, false); });
+    Run("FeedForwardNet/gpu-graph", [&] { TestFeedForwardNet(g_dev, true); });
+    g_dev->Sync();
+  }
+  std::printf("%d checks, %d failed\n", g_checks, g_failed);
+  return g_failed ? 1 : 0;
+}

@@ -28,7 +28,9 @@ def _step(dev, name, shape, classes, steps=2, graph=True, **kw):
 
 
 def test_mlp_learns(dev):
-    losses, _ = _step(dev, "mlp", (32, 10), 4, steps=30, perceptron_size=32)
+    # the initial weights come from the device's own generator, so the exact
+    # trajectory differs between host and GPU: train long enough for any seed
+    losses, _ = _step(dev, "mlp", (32, 10), 4, steps=120, perceptron_size=32)
     assert losses[-1] < 0.7 * losses[0]
 
 

@@ -2183,6 +2183,62 @@ def batchnorm_2d(handle, x, scale, bias, running_mean, running_var):
     return _BatchNorm2d(handle, running_mean, running_var)(x, scale, bias)[0]
 
 
+class _BatchNormAct2d(Operator):
+    """Batch normalisation with the following ReLU -- and optionally the
+    residual addition in front of it -- computed in the normalisation pass:
+    y = relu(bn(x)) or y = relu(bn(x) + residual).  The activation costs no
+    extra trip through HBM in either direction: backward recomputes the ReLU
+    mask from x (or reads the saved y when a residual was added) inside the
+    two BN backward passes.  The reference runs these as separate cuDNN /
+    elementwise nodes (examples/cnn/model/resnet.py:71-101)."""
+
+    def __init__(self, handle, running_mean, running_var, with_residual=False,
+                 name=None):
+        super(_BatchNormAct2d, self).__init__(name)
+        self.handle = handle
+        self.running_mean = running_mean.data
+        self.running_var = running_var.data
+        self.act = singa.BN_ACT_ADD_RELU if with_residual else \
+            singa.BN_ACT_RELU
+
+    def forward(self, x, scale, bias, residual=None):
+        if training:
+            y, mean, var = singa.BatchNormForwardTraining(
+                self.handle, x, scale, bias, self.running_mean,
+                self.running_var, self.act, residual)
+            self.cache = (x, scale, bias, mean, var, y)
+        else:
+            y = singa.BatchNormForwardInference(
+                self.handle, x, scale, bias, self.running_mean,
+                self.running_var, self.act, residual)
+        return y
+
+    def backward(self, dy):
+        assert training is True and hasattr(
+            self, "cache"), "Please set training as True before do BP. "
+        x, scale, bias, mean, var, y = self.cache
+        if self.act == singa.BN_ACT_RELU:
+            dx, ds, db = singa.BatchNormBackward(self.handle, dy, x, scale,
+                                                 mean, var, self.act, bias)
+            return dx, ds, db
+        dx, ds, db, dres = singa.BatchNormBackward(
+            self.handle, dy, x, scale, mean, var, self.act, None, y)
+        return dx, ds, db, dres
+
+
+def batchnorm_relu_2d(handle, x, scale, bias, running_mean, running_var):
+    """relu(batchnorm(x)) as one operator."""
+    return _BatchNormAct2d(handle, running_mean, running_var)(x, scale,
+                                                              bias)[0]
+
+
+def batchnorm_add_relu_2d(handle, x, scale, bias, running_mean, running_var,
+                          residual):
+    """relu(batchnorm(x) + residual) as one operator."""
+    return _BatchNormAct2d(handle, running_mean, running_var, True)(
+        x, scale, bias, residual)[0]
+
+
 class _Pooling2d(Operator):
 
     def __init__(self, handle, odd_padding=(0, 0, 0, 0)):

@@ -223,8 +223,16 @@ class CpuMath(object):
         db.copy_(dy.sum(dim=(0, 2, 3)))
 
     # ---- batch norm ------------------------------------------------------------------------
+    @staticmethod
+    def _bn_act(z, act, residual):
+        if act == 2:
+            z = z + residual.float()
+        if act >= 1:
+            z = torch.relu(z)
+        return z
+
     def bn_fwd_train(self, x, scale, bias, rmean, rvar, factor, eps, y, mean,
-                     invstd):
+                     invstd, act=0, residual=None):
         """Channel statistics over (N, H, W) (or N for 2-d input).  Running
         stats follow running = (1 - factor) * running + factor * batch with the
         unbiased batch variance."""
@@ -235,28 +243,38 @@ class CpuMath(object):
         var = xf.var(dim=dims, unbiased=False)
         istd = torch.rsqrt(var + eps)
         shp = [1, -1] + [1] * (x.dim() - 2)
-        y.copy_(((xf - mu.reshape(shp)) * istd.reshape(shp) *
-                 scale.float().reshape(shp) + bias.float().reshape(shp)
-                 ).to(y.dtype))
+        y.copy_(self._bn_act(
+            (xf - mu.reshape(shp)) * istd.reshape(shp) *
+            scale.float().reshape(shp) + bias.float().reshape(shp), act,
+            residual).to(y.dtype))
         mean.copy_(mu)
         invstd.copy_(istd)
         unbiased = var * (m / max(m - 1, 1))
         rmean.mul_(1 - factor).add_(mu.to(rmean.dtype), alpha=factor)
         rvar.mul_(1 - factor).add_(unbiased.to(rvar.dtype), alpha=factor)
 
-    def bn_fwd_infer(self, x, scale, bias, rmean, rvar, eps, y):
+    def bn_fwd_infer(self, x, scale, bias, rmean, rvar, eps, y, act=0,
+                     residual=None):
         shp = [1, -1] + [1] * (x.dim() - 2)
         istd = torch.rsqrt(rvar.float() + eps)
-        y.copy_(((x.float() - rmean.float().reshape(shp)) * istd.reshape(shp) *
-                 scale.float().reshape(shp) + bias.float().reshape(shp)
-                 ).to(y.dtype))
+        y.copy_(self._bn_act(
+            (x.float() - rmean.float().reshape(shp)) * istd.reshape(shp) *
+            scale.float().reshape(shp) + bias.float().reshape(shp), act,
+            residual).to(y.dtype))
 
-    def bn_bwd(self, dy, x, scale, mean, invstd, dx, dscale, dbias):
+    def bn_bwd(self, dy, x, scale, mean, invstd, dx, dscale, dbias, act=0,
+               bias=None, y=None, dres=None):
         dims = [0] + list(range(2, x.dim()))
         shp = [1, -1] + [1] * (x.dim() - 2)
         m = x.numel() // x.shape[1]
         xhat = (x.float() - mean.reshape(shp)) * invstd.reshape(shp)
         dyf = dy.float()
+        if act == 1:
+            z = xhat * scale.float().reshape(shp) + bias.float().reshape(shp)
+            dyf = dyf * (z > 0)
+        elif act == 2:
+            dyf = dyf * (y.float() > 0)
+            dres.copy_(dyf.to(dres.dtype))
         db = dyf.sum(dim=dims)
         ds = (dyf * xhat).sum(dim=dims)
         g = scale.float().reshape(shp) * invstd.reshape(shp)
@@ -332,6 +350,12 @@ class CpuMath(object):
         dense.index_add_(0, idx[:c].long(), -vals[:c])
 
     # ---- fused optimiser step --------------------------------------------------------------------------
+    def sgd_update_multi(self, ps, gs, bufs, lr, momentum, dampening,
+                         weight_decay, nesterov, scale):
+        for i, (p, g) in enumerate(zip(ps, gs)):
+            self.sgd_update(p, g, bufs[i] if bufs else None, lr, momentum,
+                            dampening, weight_decay, nesterov, scale)
+
     def sgd_update(self, p, g, buf, lr, momentum, dampening, weight_decay,
                    nesterov, scale):
         """One fused SGD step.  lr / momentum / ... are one-element tensors

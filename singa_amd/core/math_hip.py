@@ -432,38 +432,54 @@ class HipMath(object):
         return t if t.dtype == torch.float32 else self._cast(t, torch.float32)
 
     def bn_fwd_train(self, x, scale, bias, rmean, rvar, factor, eps, y, mean,
-                     invstd):
+                     invstd, act=0, residual=None):
+        """act: 0 none, 1 ReLU, 2 add ``residual`` then ReLU (fused into the
+        normalisation pass)."""
         N, C, HW = self._nchw(x)
         work = self._tmp(self.k.bn_workspace(N, C, HW))
         sc, bi = self._f32(scale), self._f32(bias)
         rm, rv = self._f32(rmean), self._f32(rvar)
-        self.k.bn_fwd_train(_code(x), x.data_ptr(), sc.data_ptr(),
-                            bi.data_ptr(), rm.data_ptr(), rv.data_ptr(),
-                            float(factor), float(eps), y.data_ptr(),
-                            mean.data_ptr(), invstd.data_ptr(), N, C, HW,
-                            work.data_ptr(), self._s())
+        self.k.bn_fwd_train_act(_code(x), x.data_ptr(), sc.data_ptr(),
+                                bi.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                float(factor), float(eps), y.data_ptr(),
+                                mean.data_ptr(), invstd.data_ptr(), N, C, HW,
+                                work.data_ptr(), int(act),
+                                residual.data_ptr() if residual is not None
+                                else 0, self._s())
         if rm is not rmean:
             self.copy(rm, rmean)
             self.copy(rv, rvar)
 
-    def bn_fwd_infer(self, x, scale, bias, rmean, rvar, eps, y):
+    def bn_fwd_infer(self, x, scale, bias, rmean, rvar, eps, y, act=0,
+                     residual=None):
         N, C, HW = self._nchw(x)
-        self.k.bn_fwd_infer(_code(x), x.data_ptr(),
-                            self._f32(scale).data_ptr(),
-                            self._f32(bias).data_ptr(),
-                            self._f32(rmean).data_ptr(),
-                            self._f32(rvar).data_ptr(), float(eps),
-                            y.data_ptr(), N, C, HW, self._s())
+        self.k.bn_fwd_infer_act(_code(x), x.data_ptr(),
+                                self._f32(scale).data_ptr(),
+                                self._f32(bias).data_ptr(),
+                                self._f32(rmean).data_ptr(),
+                                self._f32(rvar).data_ptr(), float(eps),
+                                y.data_ptr(), N, C, HW, int(act),
+                                residual.data_ptr() if residual is not None
+                                else 0, self._s())
 
-    def bn_bwd(self, dy, x, scale, mean, invstd, dx, dscale, dbias):
+    def bn_bwd(self, dy, x, scale, mean, invstd, dx, dscale, dbias, act=0,
+               bias=None, y=None, dres=None):
+        """With act 1 the ReLU mask is recomputed from x (needs ``bias``);
+        with act 2 it comes from the saved output ``y`` and the masked
+        gradient is also written to ``dres``."""
         N, C, HW = self._nchw(x)
         work = self._tmp(self.k.bn_workspace(N, C, HW))
         ds = dscale if dscale.dtype == torch.float32 else self._tmp(C)
         db = dbias if dbias.dtype == torch.float32 else self._tmp(C)
-        self.k.bn_bwd(_code(x), dy.data_ptr(), x.data_ptr(),
-                      self._f32(scale).data_ptr(), mean.data_ptr(),
-                      invstd.data_ptr(), dx.data_ptr(), ds.data_ptr(),
-                      db.data_ptr(), N, C, HW, work.data_ptr(), self._s())
+        self.k.bn_bwd_act(_code(x), dy.data_ptr(), x.data_ptr(),
+                          y.data_ptr() if y is not None else 0,
+                          self._f32(scale).data_ptr(),
+                          self._f32(bias).data_ptr() if bias is not None
+                          else 0, mean.data_ptr(), invstd.data_ptr(),
+                          dx.data_ptr(),
+                          dres.data_ptr() if dres is not None else 0,
+                          ds.data_ptr(), db.data_ptr(), N, C, HW,
+                          work.data_ptr(), int(act), self._s())
         if ds is not dscale:
             self.copy(ds, dscale)
             self.copy(db, dbias)
@@ -594,6 +610,24 @@ class HipMath(object):
                           self._f32(weight_decay).data_ptr(),
                           1 if nesterov else 0, float(scale), p.numel(),
                           self._s())
+
+    def sgd_update_multi(self, ps, gs, bufs, lr, momentum, dampening,
+                         weight_decay, nesterov, scale):
+        """One launch per 48 tensors; all tensors share the dtype of ps[0]."""
+        gg = []
+        for p, g in zip(ps, gs):
+            g = self._contig(g)
+            if g.dtype != p.dtype:
+                g = self._cast(g, p.dtype)
+            gg.append(g)
+        self.k.sgd_update_multi(
+            _code(ps[0]), [p.data_ptr() for p in ps],
+            [g.data_ptr() for g in gg],
+            [b.data_ptr() for b in bufs] if bufs else [],
+            [p.numel() for p in ps], self._f32(lr).data_ptr(),
+            self._f32(momentum).data_ptr(), self._f32(dampening).data_ptr(),
+            self._f32(weight_decay).data_ptr(), 1 if nesterov else 0,
+            float(scale), self._s())
 
     # ---- recurrent cells ---------------------------------------------------------------------------------------------
     def lstm_cell_fwd(self, gates, c_prev, c, h, acts):

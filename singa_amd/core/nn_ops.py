@@ -140,47 +140,91 @@ class BatchNormHandle(object):
 CudnnBatchNormHandle = BatchNormHandle
 
 
-def BatchNormForwardTraining(bnh, x, scale, bias, running_mean, running_var):
+BN_ACT_NONE, BN_ACT_RELU, BN_ACT_ADD_RELU = 0, 1, 2
+
+
+def _contig(t):
+    return t if t is None or t.is_contiguous() else Contiguous(t)
+
+
+def BatchNormForwardTraining(bnh, x, scale, bias, running_mean, running_var,
+                             act=BN_ACT_NONE, residual=None):
     """Returns [y, batch_mean, batch_inv_std]; updates the running statistics
-    in place."""
-    xs = x if x.is_contiguous() else Contiguous(x)
+    in place.  ``act`` fuses an activation into the normalisation pass:
+    BN_ACT_RELU gives relu(bn(x)), BN_ACT_ADD_RELU relu(bn(x) + residual)."""
+    xs, res = _contig(x), _contig(residual)
     dev = x.device()
     y = Tensor(x.shape(), dev, x.data_type())
     mean = Tensor([bnh.channels], dev, dtypes.kFloat32)
     invstd = Tensor([bnh.channels], dev, dtypes.kFloat32)
     f, eps = bnh.factor, bnh.eps
-
-    def body(a, s, b, rm_in, rv_in, o, m, iv, rm, rv):
-        a._dev.math.bn_fwd_train(a.view(), s.view(), b.view(), rm.view(),
-                                 rv.view(), f, eps, o.view(), m.view(),
-                                 iv.view())
-    _submit(dev, "BatchNormForwardTraining", body,
-            [xs, scale, bias, running_mean, running_var],
+    if act == BN_ACT_ADD_RELU:
+        def body(a, s, b, rm_in, rv_in, r, o, m, iv, rm, rv):
+            a._dev.math.bn_fwd_train(a.view(), s.view(), b.view(), rm.view(),
+                                     rv.view(), f, eps, o.view(), m.view(),
+                                     iv.view(), act, r.view())
+        reads = [xs, scale, bias, running_mean, running_var, res]
+    else:
+        def body(a, s, b, rm_in, rv_in, o, m, iv, rm, rv):
+            a._dev.math.bn_fwd_train(a.view(), s.view(), b.view(), rm.view(),
+                                     rv.view(), f, eps, o.view(), m.view(),
+                                     iv.view(), act)
+        reads = [xs, scale, bias, running_mean, running_var]
+    _submit(dev, "BatchNormForwardTraining", body, reads,
             [y, mean, invstd, running_mean, running_var])
     return [y, mean, invstd]
 
 
-def BatchNormForwardInference(bnh, x, scale, bias, running_mean, running_var):
-    xs = x if x.is_contiguous() else Contiguous(x)
+def BatchNormForwardInference(bnh, x, scale, bias, running_mean, running_var,
+                              act=BN_ACT_NONE, residual=None):
+    xs, res = _contig(x), _contig(residual)
     dev = x.device()
     y = Tensor(x.shape(), dev, x.data_type())
     eps = bnh.eps
-    _submit(dev, "BatchNormForwardInference",
-            lambda a, s, b, rm, rv, o: a._dev.math.bn_fwd_infer(
-                a.view(), s.view(), b.view(), rm.view(), rv.view(), eps,
-                o.view()),
-            [xs, scale, bias, running_mean, running_var], [y])
+    if act == BN_ACT_ADD_RELU:
+        _submit(dev, "BatchNormForwardInference",
+                lambda a, s, b, rm, rv, r, o: a._dev.math.bn_fwd_infer(
+                    a.view(), s.view(), b.view(), rm.view(), rv.view(), eps,
+                    o.view(), act, r.view()),
+                [xs, scale, bias, running_mean, running_var, res], [y])
+    else:
+        _submit(dev, "BatchNormForwardInference",
+                lambda a, s, b, rm, rv, o: a._dev.math.bn_fwd_infer(
+                    a.view(), s.view(), b.view(), rm.view(), rv.view(), eps,
+                    o.view(), act),
+                [xs, scale, bias, running_mean, running_var], [y])
     return y
 
 
-def BatchNormBackward(bnh, dy, x, scale, mean, invstd):
-    """Returns [dx, dscale, dbias]."""
-    d = dy if dy.is_contiguous() else Contiguous(dy)
-    xs = x if x.is_contiguous() else Contiguous(x)
+def BatchNormBackward(bnh, dy, x, scale, mean, invstd, act=BN_ACT_NONE,
+                      bias=None, y=None):
+    """Returns [dx, dscale, dbias] (+ [dresidual] for BN_ACT_ADD_RELU).  With
+    a fused activation ``dy`` is the gradient of the activated output:
+    BN_ACT_RELU needs ``bias`` (the mask is recomputed from x), BN_ACT_ADD_RELU
+    needs the saved output ``y``."""
+    d, xs = _contig(dy), _contig(x)
     dev = x.device()
     dx = Tensor(x.shape(), dev, x.data_type())
     dscale = Tensor(scale.shape(), dev, scale.data_type())
     dbias = Tensor(scale.shape(), dev, scale.data_type())
+    if act == BN_ACT_RELU:
+        _submit(dev, "BatchNormBackward",
+                lambda a, xx, s, b, m, iv, o, ds, db: a._dev.math.bn_bwd(
+                    a.view(), xx.view(), s.view(), m.view(), iv.view(),
+                    o.view(), ds.view(), db.view(), act, b.view()),
+                [d, xs, scale, bias, mean, invstd], [dx, dscale, dbias])
+        return [dx, dscale, dbias]
+    if act == BN_ACT_ADD_RELU:
+        dres = Tensor(x.shape(), dev, x.data_type())
+        ys = _contig(y)
+        _submit(dev, "BatchNormBackward",
+                lambda a, xx, yy, s, m, iv, o, ds, db, dr:
+                a._dev.math.bn_bwd(
+                    a.view(), xx.view(), s.view(), m.view(), iv.view(),
+                    o.view(), ds.view(), db.view(), act, None, yy.view(),
+                    dr.view()),
+                [d, xs, ys, scale, mean, invstd], [dx, dscale, dbias, dres])
+        return [dx, dscale, dbias, dres]
     _submit(dev, "BatchNormBackward",
             lambda a, xx, s, m, iv, o, ds, db: a._dev.math.bn_bwd(
                 a.view(), xx.view(), s.view(), m.view(), iv.view(), o.view(),

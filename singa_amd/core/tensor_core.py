@@ -1233,6 +1233,39 @@ def SGDUpdate(p, g, buf, lr, momentum, dampening, weight_decay, nesterov,
     return p
 
 
+def SGDUpdateMulti(params, grads, bufs, lr, momentum, dampening, weight_decay,
+                   nesterov, scale=1.0):
+    """The fused SGD step for a whole list of parameters as ONE graph node
+    (and one kernel launch per 48 tensors).  ``bufs`` is a list of momentum
+    buffers or None.  All tensors must live on one device and share a dtype;
+    callers group by dtype."""
+    nesterov = bool(nesterov)
+    scale = float(scale)
+    n = len(params)
+    assert n == len(grads) and n > 0
+    has_buf = bufs is not None
+    bufs = list(bufs) if has_buf else []
+
+    def body(*args):
+        ps_in = args[0:n]
+        gs = args[n:2 * n]
+        off = 2 * n + (n if has_buf else 0)
+        l, m, d, w = args[off:off + 4]
+        outs = args[off + 4:]
+        ps = outs[0:n]
+        bs = outs[n:2 * n] if has_buf else None
+        ps[0]._dev.math.sgd_update_multi(
+            [t.view() for t in ps], [t.view() for t in gs],
+            [t.view() for t in bs] if has_buf else None, l.flat(), m.flat(),
+            d.flat(), w.flat(), nesterov, scale)
+
+    reads = list(params) + list(grads) + bufs + [lr, momentum, dampening,
+                                                 weight_decay]
+    writes = list(params) + bufs
+    _submit(params[0]._dev, "SGDUpdateMulti", body, reads, writes)
+    return params
+
+
 _bin_max, MaxWithRet = _binary("Max", "max")
 _bin_min, MinWithRet = _binary("Min", "min")
 EltwiseMax = _bin_max

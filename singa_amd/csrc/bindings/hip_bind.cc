@@ -231,6 +231,42 @@ PYBIND11_MODULE(_hip, m) {
           "bn_bwd");
   });
 
+  m.def("bn_fwd_train_act", [](int dt, uintptr_t x, uintptr_t scale,
+                               uintptr_t bias, uintptr_t rmean, uintptr_t rvar,
+                               float factor, float eps, uintptr_t y,
+                               uintptr_t mean, uintptr_t invstd, int N, int C,
+                               int HW, uintptr_t work, int act, uintptr_t res,
+                               uintptr_t s) {
+    check(sa_bn_fwd_train_act(dt, CP(x), (const float *)CP(scale),
+                              (const float *)CP(bias), (float *)P(rmean),
+                              (float *)P(rvar), factor, eps, P(y),
+                              (float *)P(mean), (float *)P(invstd), N, C, HW,
+                              (float *)P(work), act, CP(res), S(s)),
+          "bn_fwd_train_act");
+  });
+  m.def("bn_fwd_infer_act", [](int dt, uintptr_t x, uintptr_t scale,
+                               uintptr_t bias, uintptr_t rmean, uintptr_t rvar,
+                               float eps, uintptr_t y, int N, int C, int HW,
+                               int act, uintptr_t res, uintptr_t s) {
+    check(sa_bn_fwd_infer_act(dt, CP(x), (const float *)CP(scale),
+                              (const float *)CP(bias), (const float *)CP(rmean),
+                              (const float *)CP(rvar), eps, P(y), N, C, HW, act,
+                              CP(res), S(s)),
+          "bn_fwd_infer_act");
+  });
+  m.def("bn_bwd_act", [](int dt, uintptr_t dy, uintptr_t x, uintptr_t y,
+                         uintptr_t scale, uintptr_t bias, uintptr_t mean,
+                         uintptr_t invstd, uintptr_t dx, uintptr_t dres,
+                         uintptr_t dscale, uintptr_t dbias, int N, int C,
+                         int HW, uintptr_t work, int act, uintptr_t s) {
+    check(sa_bn_bwd_act(dt, CP(dy), CP(x), CP(y), (const float *)CP(scale),
+                        (const float *)CP(bias), (const float *)CP(mean),
+                        (const float *)CP(invstd), P(dx), P(dres),
+                        (float *)P(dscale), (float *)P(dbias), N, C, HW,
+                        (float *)P(work), act, S(s)),
+          "bn_bwd_act");
+  });
+
   // ---- pooling ----------------------------------------------------------------------------
   py::class_<PoolGeom>(m, "PoolGeom")
       .def(py::init([](int N, int C, int H, int W, int P_, int Q, int kh,
@@ -256,6 +292,26 @@ PYBIND11_MODULE(_hip, m) {
                         (const float *)CP(mom), (const float *)CP(damp),
                         (const float *)CP(wd), nesterov, scale, n, S(s)),
           "sgd_update");
+  });
+
+  m.def("sgd_update_multi", [](int dt, std::vector<uintptr_t> p,
+                               std::vector<uintptr_t> g,
+                               std::vector<uintptr_t> buf,
+                               std::vector<int64_t> n, uintptr_t lr,
+                               uintptr_t mom, uintptr_t damp, uintptr_t wd,
+                               int nesterov, float scale, uintptr_t s) {
+    if (p.size() != g.size() || p.size() != n.size() ||
+        (!buf.empty() && buf.size() != p.size()))
+      throw std::invalid_argument("sgd_update_multi: list lengths differ");
+    check(sa_sgd_update_multi(
+              dt, (int)p.size(), reinterpret_cast<void *const *>(p.data()),
+              reinterpret_cast<const void *const *>(g.data()),
+              buf.empty() ? nullptr
+                          : reinterpret_cast<void *const *>(buf.data()),
+              n.data(), (const float *)CP(lr), (const float *)CP(mom),
+              (const float *)CP(damp), (const float *)CP(wd), nesterov, scale,
+              S(s)),
+          "sgd_update_multi");
   });
 
   // ---- index --------------------------------------------------------------------------------------

@@ -37,15 +37,20 @@ struct Div32 {
   }
 };
 
+// enough (channel, image-group) blocks to keep ~8 MB of loads in flight
 static inline int bn_splits(int N, int C) {
-  int s = 2048 / (C > 0 ? C : 1);
+  int s = 8192 / (C > 0 ? C : 1);
   if (s < 1) s = 1;
   if (s > N) s = N;
   return s;
 }
 
 // work layout: [C][S][2]
-template <typename T>
+//
+// VEC = 4 variants move float4 per lane (rows of HW floats are 16-byte aligned
+// when HW % 4 == 0); VEC = 1 is the general path.  ACT: 0 none, 1 ReLU,
+// 2 add a residual tensor then ReLU (the tail of a ResNet bottleneck).
+template <typename T, int VEC>
 __global__ void bn_stats_kernel(const T *__restrict__ x,
                                 float *__restrict__ work, int N, int C, int HW,
                                 int S) {
@@ -55,10 +60,21 @@ __global__ void bn_stats_kernel(const T *__restrict__ x,
   float sum = 0.f, sq = 0.f;
   for (int n = s; n < N; n += S) {
     const T *p = x + ((size_t)n * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-      const float v = to_f<T>(p[i]) - shift;
-      sum += v;
-      sq += v * v;
+    if constexpr (VEC == 4) {
+      const float4 *p4 = reinterpret_cast<const float4 *>(p);
+      for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+        const float4 v = p4[i];
+        const float a = v.x - shift, b = v.y - shift, cc = v.z - shift,
+                    d = v.w - shift;
+        sum += (a + b) + (cc + d);
+        sq += (a * a + b * b) + (cc * cc + d * d);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float v = to_f<T>(p[i]) - shift;
+        sum += v;
+        sq += v * v;
+      }
     }
   }
   sum = block_sum(sum, smem);
@@ -69,13 +85,21 @@ __global__ void bn_stats_kernel(const T *__restrict__ x,
   }
 }
 
-template <typename T>
+template <int ACT>
+__device__ __forceinline__ float bn_act(float z, float r) {
+  if (ACT == 2) z += r;
+  if (ACT >= 1) z = fmaxf(z, 0.f);
+  return z;
+}
+
+template <typename T, int VEC, int ACT>
 __global__ void bn_apply_train_kernel(
     const T *__restrict__ x, const float *__restrict__ scale,
     const float *__restrict__ bias, float *__restrict__ rmean,
     float *__restrict__ rvar, float factor, float eps, T *__restrict__ y,
     float *__restrict__ mean_out, float *__restrict__ invstd_out,
-    const float *__restrict__ work, int N, int C, int HW, int S) {
+    const float *__restrict__ work, const T *__restrict__ res, int N, int C,
+    int HW, int S) {
   const int c = blockIdx.x, s = blockIdx.y;
   float sum = 0.f, sq = 0.f;
   for (int i = 0; i < S; ++i) {
@@ -99,10 +123,29 @@ __global__ void bn_apply_train_kernel(
   const float g = scale[c] * invstd;
   const float b = bias[c] - mean * g;
   for (int n = s; n < N; n += S) {
-    const T *p = x + ((size_t)n * C + c) * HW;
-    T *q = y + ((size_t)n * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x)
-      q[i] = from_f<T>(fmaf(to_f<T>(p[i]), g, b));
+    const size_t off = ((size_t)n * C + c) * HW;
+    if constexpr (VEC == 4) {
+      const float4 *p4 = reinterpret_cast<const float4 *>(x + off);
+      const float4 *r4 = reinterpret_cast<const float4 *>(res + off);
+      float4 *q4 = reinterpret_cast<float4 *>(y + off);
+      for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+        const float4 v = p4[i];
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ACT == 2) r = r4[i];
+        float4 o;
+        o.x = bn_act<ACT>(fmaf(v.x, g, b), r.x);
+        o.y = bn_act<ACT>(fmaf(v.y, g, b), r.y);
+        o.z = bn_act<ACT>(fmaf(v.z, g, b), r.z);
+        o.w = bn_act<ACT>(fmaf(v.w, g, b), r.w);
+        q4[i] = o;
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float r = ACT == 2 ? to_f<T>(res[off + i]) : 0.f;
+        y[off + i] =
+            from_f<T>(bn_act<ACT>(fmaf(to_f<T>(x[off + i]), g, b), r));
+      }
+    }
   }
 }
 
@@ -113,7 +156,8 @@ __global__ void bn_infer_kernel(const T *__restrict__ x,
                                 const float *__restrict__ rmean,
                                 const float *__restrict__ rvar, float eps,
                                 T *__restrict__ y, int64_t total, int C,
-                                Div32 div_hw, Div32 div_c) {
+                                Div32 div_hw, Div32 div_c, int act,
+                                const T *__restrict__ res) {
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += step) {
@@ -121,14 +165,31 @@ __global__ void bn_infer_kernel(const T *__restrict__ x,
     div_hw.divmod((uint32_t)i, nc, hw);
     div_c.divmod(nc, n, c);
     const float g = scale[c] * rsqrtf(rvar[c] + eps);
-    y[i] = from_f<T>((to_f<T>(x[i]) - rmean[c]) * g + bias[c]);
+    float z = (to_f<T>(x[i]) - rmean[c]) * g + bias[c];
+    if (act == 2) z += to_f<T>(res[i]);
+    if (act >= 1) z = fmaxf(z, 0.f);
+    y[i] = from_f<T>(z);
   }
 }
 
-// pass 1 of backward: sum(dy), sum(dy * xhat)
-template <typename T>
+// pass 1 of backward: sum(dy), sum(dy * xhat).  With an activation the
+// incoming gradient is first masked by (output > 0): for ACT 1 the output sign
+// is recomputed from x (no extra tensor is read), for ACT 2 the saved output y
+// is read.
+template <int ACT>
+__device__ __forceinline__ float bn_mask(float d, float xv, float g, float b,
+                                         float yv) {
+  if (ACT == 1) return fmaf(xv, g, b) > 0.f ? d : 0.f;
+  if (ACT == 2) return yv > 0.f ? d : 0.f;
+  return d;
+}
+
+template <typename T, int VEC, int ACT>
 __global__ void bn_bwd_stats_kernel(const T *__restrict__ dy,
                                     const T *__restrict__ x,
+                                    const T *__restrict__ y,
+                                    const float *__restrict__ scale,
+                                    const float *__restrict__ bias,
                                     const float *__restrict__ mean,
                                     const float *__restrict__ invstd,
                                     float *__restrict__ work, int N, int C,
@@ -136,30 +197,55 @@ __global__ void bn_bwd_stats_kernel(const T *__restrict__ dy,
   __shared__ float smem[32];
   const int c = blockIdx.x, s = blockIdx.y;
   const float m = mean[c], iv = invstd[c];
+  const float g = ACT == 1 ? scale[c] * iv : 0.f;
+  const float b = ACT == 1 ? bias[c] - m * g : 0.f;
   float sdy = 0.f, sdyx = 0.f;
   for (int n = s; n < N; n += S) {
     const size_t off = ((size_t)n * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-      const float d = to_f<T>(dy[off + i]);
-      sdy += d;
-      sdyx += d * (to_f<T>(x[off + i]) - m) * iv;
+    if constexpr (VEC == 4) {
+      const float4 *d4 = reinterpret_cast<const float4 *>(dy + off);
+      const float4 *x4 = reinterpret_cast<const float4 *>(x + off);
+      const float4 *y4 = reinterpret_cast<const float4 *>(y + off);
+      for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+        const float4 d = d4[i], xv = x4[i];
+        float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ACT == 2) yv = y4[i];
+        const float d0 = bn_mask<ACT>(d.x, xv.x, g, b, yv.x);
+        const float d1 = bn_mask<ACT>(d.y, xv.y, g, b, yv.y);
+        const float d2 = bn_mask<ACT>(d.z, xv.z, g, b, yv.z);
+        const float d3 = bn_mask<ACT>(d.w, xv.w, g, b, yv.w);
+        sdy += (d0 + d1) + (d2 + d3);
+        sdyx += (d0 * (xv.x - m) + d1 * (xv.y - m)) +
+                (d2 * (xv.z - m) + d3 * (xv.w - m));
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float xv = to_f<T>(x[off + i]);
+        const float yv = ACT == 2 ? to_f<T>(y[off + i]) : 0.f;
+        const float d = bn_mask<ACT>(to_f<T>(dy[off + i]), xv, g, b, yv);
+        sdy += d;
+        sdyx += d * (xv - m);
+      }
     }
   }
   sdy = block_sum(sdy, smem);
-  sdyx = block_sum(sdyx, smem);
+  sdyx = block_sum(sdyx, smem) * iv;
   if (threadIdx.x == 0) {
     work[((size_t)c * S + s) * 2 + 0] = sdy;
     work[((size_t)c * S + s) * 2 + 1] = sdyx;
   }
 }
 
-template <typename T>
+// pass 2: dx; for ACT 2 also writes the masked gradient `dres` that flows
+// into the residual branch
+template <typename T, int VEC, int ACT>
 __global__ void bn_bwd_apply_kernel(
-    const T *__restrict__ dy, const T *__restrict__ x,
-    const float *__restrict__ scale, const float *__restrict__ mean,
-    const float *__restrict__ invstd, T *__restrict__ dx,
-    float *__restrict__ dscale, float *__restrict__ dbias,
-    const float *__restrict__ work, int N, int C, int HW, int S) {
+    const T *__restrict__ dy, const T *__restrict__ x, const T *__restrict__ y,
+    const float *__restrict__ scale, const float *__restrict__ bias,
+    const float *__restrict__ mean, const float *__restrict__ invstd,
+    T *__restrict__ dx, T *__restrict__ dres, float *__restrict__ dscale,
+    float *__restrict__ dbias, const float *__restrict__ work, int N, int C,
+    int HW, int S) {
   const int c = blockIdx.x, s = blockIdx.y;
   float sdy = 0.f, sdyx = 0.f;
   for (int i = 0; i < S; ++i) {
@@ -173,12 +259,41 @@ __global__ void bn_bwd_apply_kernel(
   const float cnt = (float)N * (float)HW;
   const float m = mean[c], iv = invstd[c];
   const float g = scale[c] * iv;
-  const float k1 = sdy / cnt, k2 = sdyx / cnt;
+  const float b = ACT == 1 ? bias[c] - m * g : 0.f;
+  const float k1 = sdy / cnt, k2 = sdyx / cnt * iv;
+  // dx = g * (d - k1 - (x - m) * k2)  with k2 already carrying one 1/std
   for (int n = s; n < N; n += S) {
     const size_t off = ((size_t)n * C + c) * HW;
-    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
-      const float xhat = (to_f<T>(x[off + i]) - m) * iv;
-      dx[off + i] = from_f<T>(g * (to_f<T>(dy[off + i]) - k1 - xhat * k2));
+    if constexpr (VEC == 4) {
+      const float4 *d4 = reinterpret_cast<const float4 *>(dy + off);
+      const float4 *x4 = reinterpret_cast<const float4 *>(x + off);
+      const float4 *y4 = reinterpret_cast<const float4 *>(y + off);
+      float4 *o4 = reinterpret_cast<float4 *>(dx + off);
+      float4 *r4 = reinterpret_cast<float4 *>(dres + off);
+      for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
+        const float4 d = d4[i], xv = x4[i];
+        float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ACT == 2) yv = y4[i];
+        float4 dm, o;
+        dm.x = bn_mask<ACT>(d.x, xv.x, g, b, yv.x);
+        dm.y = bn_mask<ACT>(d.y, xv.y, g, b, yv.y);
+        dm.z = bn_mask<ACT>(d.z, xv.z, g, b, yv.z);
+        dm.w = bn_mask<ACT>(d.w, xv.w, g, b, yv.w);
+        o.x = g * (dm.x - k1 - (xv.x - m) * k2);
+        o.y = g * (dm.y - k1 - (xv.y - m) * k2);
+        o.z = g * (dm.z - k1 - (xv.z - m) * k2);
+        o.w = g * (dm.w - k1 - (xv.w - m) * k2);
+        o4[i] = o;
+        if (ACT == 2) r4[i] = dm;
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        const float xv = to_f<T>(x[off + i]);
+        const float yv = ACT == 2 ? to_f<T>(y[off + i]) : 0.f;
+        const float d = bn_mask<ACT>(to_f<T>(dy[off + i]), xv, g, b, yv);
+        dx[off + i] = from_f<T>(g * (d - k1 - (xv - m) * k2));
+        if (ACT == 2) dres[off + i] = from_f<T>(d);
+      }
     }
   }
 }
@@ -193,19 +308,79 @@ int64_t sa_bn_workspace(int N, int C, int HW) {
 
 static inline int bn_block(int HW) { return HW >= 256 ? 256 : (HW > 64 ? 128 : 64); }
 
+// float tensors whose channel rows are 16-byte aligned take the float4 path
+static inline bool bn_vec4(int dtype, int HW, const void *a, const void *b,
+                           const void *c, const void *d) {
+  uintptr_t bits = reinterpret_cast<uintptr_t>(a) |
+                   reinterpret_cast<uintptr_t>(b) |
+                   reinterpret_cast<uintptr_t>(c) |
+                   reinterpret_cast<uintptr_t>(d);
+  return dtype == kF32 && HW % 4 == 0 && (bits & 15) == 0;
+}
+
+#define BN_ACT_SWITCH(act, ...)                         \
+  switch (act) {                                        \
+    case 0: { constexpr int ACT = 0; __VA_ARGS__; break; } \
+    case 1: { constexpr int ACT = 1; __VA_ARGS__; break; } \
+    case 2: { constexpr int ACT = 2; __VA_ARGS__; break; } \
+    default: return -4;                                 \
+  }
+
+int sa_bn_fwd_train_act(int dtype, const void *x, const float *scale,
+                        const float *bias, float *rmean, float *rvar,
+                        float factor, float eps, void *y, float *mean,
+                        float *invstd, int N, int C, int HW, float *work,
+                        int act, const void *residual, hipStream_t s) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  if (act == 2 && residual == nullptr) return -5;
+  const int S = bn_splits(N, C);
+  if (bn_vec4(dtype, HW, x, y, residual, nullptr)) {
+    const dim3 grid(C, S), block(bn_block(HW / 4));
+    hipLaunchKernelGGL((bn_stats_kernel<float, 4>), grid, block, 0, s,
+                       (const float *)x, work, N, C, HW, S);
+    BN_ACT_SWITCH(act, {
+      hipLaunchKernelGGL((bn_apply_train_kernel<float, 4, ACT>), grid, block,
+                         0, s, (const float *)x, scale, bias, rmean, rvar,
+                         factor, eps, (float *)y, mean, invstd, work,
+                         (const float *)residual, N, C, HW, S);
+    });
+    return 0;
+  }
+  const dim3 grid(C, S), block(bn_block(HW));
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((bn_stats_kernel<T, 1>), grid, block, 0, s,
+                       (const T *)x, work, N, C, HW, S);
+    BN_ACT_SWITCH(act, {
+      hipLaunchKernelGGL((bn_apply_train_kernel<T, 1, ACT>), grid, block, 0,
+                         s, (const T *)x, scale, bias, rmean, rvar, factor,
+                         eps, (T *)y, mean, invstd, work, (const T *)residual,
+                         N, C, HW, S);
+    });
+  });
+  return 0;
+}
+
 int sa_bn_fwd_train(int dtype, const void *x, const float *scale,
                     const float *bias, float *rmean, float *rvar, float factor,
                     float eps, void *y, float *mean, float *invstd, int N,
                     int C, int HW, float *work, hipStream_t s) {
-  if (N <= 0 || C <= 0 || HW <= 0) return 0;
-  const int S = bn_splits(N, C);
-  const dim3 grid(C, S), block(bn_block(HW));
+  return sa_bn_fwd_train_act(dtype, x, scale, bias, rmean, rvar, factor, eps,
+                             y, mean, invstd, N, C, HW, work, 0, nullptr, s);
+}
+
+int sa_bn_fwd_infer_act(int dtype, const void *x, const float *scale,
+                        const float *bias, const float *rmean,
+                        const float *rvar, float eps, void *y, int N, int C,
+                        int HW, int act, const void *residual, hipStream_t s) {
+  const int64_t total = (int64_t)N * C * HW;
+  if (total <= 0) return 0;
+  if (total >= ((int64_t)1 << 31)) return -2;
+  if (act == 2 && residual == nullptr) return -5;
   SA_DISPATCH_FLOAT(dtype, T, {
-    hipLaunchKernelGGL((bn_stats_kernel<T>), grid, block, 0, s, (const T *)x,
-                       work, N, C, HW, S);
-    hipLaunchKernelGGL((bn_apply_train_kernel<T>), grid, block, 0, s,
-                       (const T *)x, scale, bias, rmean, rvar, factor, eps,
-                       (T *)y, mean, invstd, work, N, C, HW, S);
+    hipLaunchKernelGGL((bn_infer_kernel<T>), dim3(grid_for(total, 256, 4)),
+                       dim3(256), 0, s, (const T *)x, scale, bias, rmean, rvar,
+                       eps, (T *)y, total, C, Div32(HW), Div32(C), act,
+                       (const T *)residual);
   });
   return 0;
 }
@@ -213,13 +388,46 @@ int sa_bn_fwd_train(int dtype, const void *x, const float *scale,
 int sa_bn_fwd_infer(int dtype, const void *x, const float *scale,
                     const float *bias, const float *rmean, const float *rvar,
                     float eps, void *y, int N, int C, int HW, hipStream_t s) {
-  const int64_t total = (int64_t)N * C * HW;
-  if (total <= 0) return 0;
-  if (total >= ((int64_t)1 << 31)) return -2;
+  return sa_bn_fwd_infer_act(dtype, x, scale, bias, rmean, rvar, eps, y, N, C,
+                             HW, 0, nullptr, s);
+}
+
+int sa_bn_bwd_act(int dtype, const void *dy, const void *x, const void *y,
+                  const float *scale, const float *bias, const float *mean,
+                  const float *invstd, void *dx, void *dres, float *dscale,
+                  float *dbias, int N, int C, int HW, float *work, int act,
+                  hipStream_t s) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  if (act == 2 && (y == nullptr || dres == nullptr)) return -5;
+  if (act == 1 && bias == nullptr) return -5;
+  const int S = bn_splits(N, C);
+  if (bn_vec4(dtype, HW, dy, x, dx, act == 2 ? y : nullptr) &&
+      (reinterpret_cast<uintptr_t>(dres) & 15) == 0) {
+    const dim3 grid(C, S), block(bn_block(HW / 4));
+    BN_ACT_SWITCH(act, {
+      hipLaunchKernelGGL((bn_bwd_stats_kernel<float, 4, ACT>), grid, block, 0,
+                         s, (const float *)dy, (const float *)x,
+                         (const float *)y, scale, bias, mean, invstd, work, N,
+                         C, HW, S);
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4, ACT>), grid, block, 0,
+                         s, (const float *)dy, (const float *)x,
+                         (const float *)y, scale, bias, mean, invstd,
+                         (float *)dx, (float *)dres, dscale, dbias, work, N, C,
+                         HW, S);
+    });
+    return 0;
+  }
+  const dim3 grid(C, S), block(bn_block(HW));
   SA_DISPATCH_FLOAT(dtype, T, {
-    hipLaunchKernelGGL((bn_infer_kernel<T>), dim3(grid_for(total, 256, 4)),
-                       dim3(256), 0, s, (const T *)x, scale, bias, rmean, rvar,
-                       eps, (T *)y, total, C, Div32(HW), Div32(C));
+    BN_ACT_SWITCH(act, {
+      hipLaunchKernelGGL((bn_bwd_stats_kernel<T, 1, ACT>), grid, block, 0, s,
+                         (const T *)dy, (const T *)x, (const T *)y, scale, bias,
+                         mean, invstd, work, N, C, HW, S);
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, ACT>), grid, block, 0, s,
+                         (const T *)dy, (const T *)x, (const T *)y, scale, bias,
+                         mean, invstd, (T *)dx, (T *)dres, dscale, dbias, work,
+                         N, C, HW, S);
+    });
   });
   return 0;
 }
@@ -227,16 +435,6 @@ int sa_bn_fwd_infer(int dtype, const void *x, const float *scale,
 int sa_bn_bwd(int dtype, const void *dy, const void *x, const float *scale,
               const float *mean, const float *invstd, void *dx, float *dscale,
               float *dbias, int N, int C, int HW, float *work, hipStream_t s) {
-  if (N <= 0 || C <= 0 || HW <= 0) return 0;
-  const int S = bn_splits(N, C);
-  const dim3 grid(C, S), block(bn_block(HW));
-  SA_DISPATCH_FLOAT(dtype, T, {
-    hipLaunchKernelGGL((bn_bwd_stats_kernel<T>), grid, block, 0, s,
-                       (const T *)dy, (const T *)x, mean, invstd, work, N, C,
-                       HW, S);
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), grid, block, 0, s,
-                       (const T *)dy, (const T *)x, scale, mean, invstd,
-                       (T *)dx, dscale, dbias, work, N, C, HW, S);
-  });
-  return 0;
+  return sa_bn_bwd_act(dtype, dy, x, nullptr, scale, nullptr, mean, invstd, dx,
+                       nullptr, dscale, dbias, N, C, HW, work, 0, s);
 }

@@ -130,6 +130,23 @@ int sa_bn_fwd_infer(int dtype, const void *x, const float *scale,
 int sa_bn_bwd(int dtype, const void *dy, const void *x, const float *scale,
               const float *mean, const float *invstd, void *dx, float *dscale,
               float *dbias, int N, int C, int HW, float *work, hipStream_t s);
+// Fused variants.  act: 0 none, 1 ReLU, 2 add `residual` then ReLU.  The
+// backward masks dy by (output > 0) first; for act 2 it needs the saved output
+// y and also writes the masked gradient to `dres` (gradient of the residual).
+int sa_bn_fwd_train_act(int dtype, const void *x, const float *scale,
+                        const float *bias, float *rmean, float *rvar,
+                        float factor, float eps, void *y, float *mean,
+                        float *invstd, int N, int C, int HW, float *work,
+                        int act, const void *residual, hipStream_t s);
+int sa_bn_fwd_infer_act(int dtype, const void *x, const float *scale,
+                        const float *bias, const float *rmean,
+                        const float *rvar, float eps, void *y, int N, int C,
+                        int HW, int act, const void *residual, hipStream_t s);
+int sa_bn_bwd_act(int dtype, const void *dy, const void *x, const void *y,
+                  const float *scale, const float *bias, const float *mean,
+                  const float *invstd, void *dx, void *dres, float *dscale,
+                  float *dbias, int N, int C, int HW, float *work, int act,
+                  hipStream_t s);
 // number of floats sa_bn_* need in `work`
 int64_t sa_bn_workspace(int N, int C, int HW);
 
@@ -149,6 +166,28 @@ int sa_sgd_update(int dtype, void *p, const void *g, void *buf,
                   const float *lr, const float *momentum,
                   const float *dampening, const float *weight_decay,
                   int nesterov, float scale, int64_t n, hipStream_t s);
+
+// The same update for `count` tensors in ceil(count / kSgdMaxTensors)
+// launches; pointer arrays are host arrays (they are copied into the kernel
+// arguments).  buf may be nullptr (no momentum) or hold nullptr entries.
+namespace sa {
+constexpr int kSgdMaxTensors = 48;
+constexpr int kSgdChunk = 4096;
+struct SgdBatch {
+  void *p[kSgdMaxTensors];
+  const void *g[kSgdMaxTensors];
+  void *buf[kSgdMaxTensors];
+  int64_t n[kSgdMaxTensors];
+  int chunk_start[kSgdMaxTensors + 1];
+  int count;
+};
+}  // namespace sa
+int sa_sgd_update_multi(int dtype, int count, void *const *p,
+                        const void *const *g, void *const *buf,
+                        const int64_t *n, const float *lr,
+                        const float *momentum, const float *dampening,
+                        const float *weight_decay, int nesterov, float scale,
+                        hipStream_t s);
 
 // ---- index.hip -----------------------------------------------------------------------------------------------
 // out[o, j, i] = x[o, idx[j], i]   (x: outer x n_in x inner)

@@ -54,9 +54,97 @@ __global__ void sgd_kernel(T *__restrict__ p, const T *__restrict__ g,
   }
 }
 
+// ---- many tensors per launch ----------------------------------------------------
+// The per-tensor pointers travel in the kernel argument block (not in a device
+// table), so a captured hipGraph node carries them and no host-to-device copy
+// is needed at replay.  Each workgroup updates one 4096-element chunk of one
+// tensor; chunk_start[] is the prefix sum of chunks per tensor.
+template <typename T>
+__global__ void sgd_multi_kernel(SgdBatch batch, const float *__restrict__ lr_p,
+                                 const float *__restrict__ mom_p,
+                                 const float *__restrict__ damp_p,
+                                 const float *__restrict__ wd_p, int nesterov,
+                                 float scale) {
+  const float lr = lr_p[0], mom = mom_p[0], damp = damp_p[0], wd = wd_p[0];
+  int t = 0;
+  const int chunk = blockIdx.x;
+  while (t + 1 < batch.count && chunk >= batch.chunk_start[t + 1]) ++t;
+  const int64_t base = (int64_t)(chunk - batch.chunk_start[t]) * kSgdChunk;
+  const int64_t n = batch.n[t];
+  T *__restrict__ p = static_cast<T *>(batch.p[t]) + base;
+  const T *__restrict__ g = static_cast<const T *>(batch.g[t]) + base;
+  T *__restrict__ buf =
+      batch.buf[t] ? static_cast<T *>(batch.buf[t]) + base : nullptr;
+  const int64_t len = n - base < kSgdChunk ? n - base : kSgdChunk;
+  const bool has_buf = buf != nullptr;
+  auto upd = [&](float pv, float gv, float &bv) {
+    gv = gv * scale + wd * pv;
+    if (has_buf) {
+      bv = mom * bv + (1.f - damp) * gv;
+      gv = nesterov ? gv + mom * bv : bv;
+    }
+    return pv - lr * gv;
+  };
+  constexpr int VEC = 16 / sizeof(T);
+  struct alignas(16) V { T v[VEC]; };
+  const bool aligned =
+      ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) |
+        reinterpret_cast<uintptr_t>(buf)) & 15) == 0;
+  const int64_t nvec = aligned ? len / VEC : 0;
+  V *pv = reinterpret_cast<V *>(p);
+  const V *gv = reinterpret_cast<const V *>(g);
+  V *bv = reinterpret_cast<V *>(buf);
+  for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) {
+    V pp = pv[i], gg = gv[i], bb;
+    if (has_buf) bb = bv[i];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      float b = has_buf ? to_f<T>(bb.v[k]) : 0.f;
+      pp.v[k] = from_f<T>(upd(to_f<T>(pp.v[k]), to_f<T>(gg.v[k]), b));
+      if (has_buf) bb.v[k] = from_f<T>(b);
+    }
+    pv[i] = pp;
+    if (has_buf) bv[i] = bb;
+  }
+  for (int64_t i = nvec * VEC + threadIdx.x; i < len; i += blockDim.x) {
+    float b = has_buf ? to_f<T>(buf[i]) : 0.f;
+    p[i] = from_f<T>(upd(to_f<T>(p[i]), to_f<T>(g[i]), b));
+    if (has_buf) buf[i] = from_f<T>(b);
+  }
+}
+
 }  // namespace sa
 
 using namespace sa;
+
+int sa_sgd_update_multi(int dtype, int count, void *const *p,
+                        const void *const *g, void *const *buf,
+                        const int64_t *n, const float *lr,
+                        const float *momentum, const float *dampening,
+                        const float *weight_decay, int nesterov, float scale,
+                        hipStream_t s) {
+  for (int first = 0; first < count; first += kSgdMaxTensors) {
+    SgdBatch b;
+    b.count = count - first < kSgdMaxTensors ? count - first : kSgdMaxTensors;
+    int chunks = 0;
+    for (int i = 0; i < b.count; ++i) {
+      b.p[i] = p[first + i];
+      b.g[i] = g[first + i];
+      b.buf[i] = buf ? buf[first + i] : nullptr;
+      b.n[i] = n[first + i];
+      b.chunk_start[i] = chunks;
+      chunks += (int)((n[first + i] + kSgdChunk - 1) / kSgdChunk);
+    }
+    b.chunk_start[b.count] = chunks;
+    if (chunks == 0) continue;
+    SA_DISPATCH_FLOAT(dtype, T, {
+      hipLaunchKernelGGL((sgd_multi_kernel<T>), dim3(chunks), dim3(256), 0, s,
+                         b, lr, momentum, dampening, weight_decay, nesterov,
+                         scale);
+    });
+  }
+  return 0;
+}
 
 int sa_sgd_update(int dtype, void *p, const void *g, void *buf,
                   const float *lr, const float *momentum,

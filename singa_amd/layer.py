@@ -497,7 +497,10 @@ class BatchNorm2d(Layer):
     weight of the batch statistics in the running average (see
     ``singa_wrap.BatchNormHandle``)."""
 
-    def __init__(self, *args, momentum=0.9):
+    def __init__(self, *args, momentum=0.9, activation=None):
+        """``activation="RELU"`` computes relu(bn(x)) -- and, when the layer
+        is called with a second tensor, relu(bn(x) + residual) -- inside the
+        normalisation kernel instead of as separate graph nodes."""
         super(BatchNorm2d, self).__init__()
         if len(args) > 0:
             self.channels = args[0]
@@ -505,8 +508,10 @@ class BatchNorm2d(Layer):
             momentum = args[1]
         self.momentum = momentum
         assert 0 <= momentum <= 1.0, ("Illegal momentum")
+        assert activation in (None, "RELU"), "only RELU can be fused"
+        self.activation = activation
 
-    def initialize(self, x):
+    def initialize(self, x, residual=None):
         self.channels = x.shape[1]
         param_shape = (self.channels,)
         self.scale = Tensor(shape=param_shape, requires_grad=True,
@@ -524,13 +529,23 @@ class BatchNorm2d(Layer):
         if not hasattr(self, "handle"):
             self.handle = singa.BatchNormHandle(self.momentum, x.data)
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
         assert x.shape[1] == self.channels, (
             "number of channels dismatched. %d vs %d" %
             (x.shape[1], self.channels))
         self.device_check(x, self.scale, self.bias, self.running_mean,
                           self.running_var)
         # statistics and affine parameters stay in float32 for half inputs
+        if residual is not None:
+            assert self.activation == "RELU", \
+                "a residual input needs activation='RELU'"
+            return autograd.batchnorm_add_relu_2d(
+                self.handle, x, self.scale, self.bias, self.running_mean,
+                self.running_var, residual)
+        if self.activation == "RELU":
+            return autograd.batchnorm_relu_2d(
+                self.handle, x, self.scale, self.bias, self.running_mean,
+                self.running_var)
         return autograd.batchnorm_2d(self.handle, x, self.scale, self.bias,
                                      self.running_mean, self.running_var)
 

@@ -5,8 +5,38 @@ with the stride on the 3x3 convolution, no convolution bias, BatchNorm after
 every convolution, 7x7 average pool, Linear head; ``train_one_batch`` accepts
 the ``dist_option`` / ``spars`` switches of the training scripts).
 """
+import os
+
 from .. import layer
 from .. import model
+
+# The ReLU after a BatchNorm -- and the residual addition in front of the last
+# ReLU of a block -- run inside the BatchNorm kernels (no separate trips
+# through HBM).  SINGA_RESNET_FUSE=0 builds the blocks from separate
+# BatchNorm / Add / ReLU operators instead (same parameters, same numerics),
+# e.g. to export a graph of primitive ONNX nodes.
+FUSE_BN_ACT = os.environ.get("SINGA_RESNET_FUSE", "1") != "0"
+
+
+class _BnRelu(layer.Layer):
+    """relu(bn(x)) or relu(bn(x) + residual); parameters live in ``bn``."""
+
+    def __init__(self, planes):
+        super().__init__()
+        self.fused = FUSE_BN_ACT
+        self.bn = layer.BatchNorm2d(
+            planes, activation="RELU" if self.fused else None)
+        if not self.fused:
+            self.add = layer.Add()
+            self.relu = layer.ReLU()
+
+    def forward(self, x, residual=None):
+        if self.fused:
+            return self.bn(x) if residual is None else self.bn(x, residual)
+        out = self.bn(x)
+        if residual is not None:
+            out = self.add(out, residual)
+        return self.relu(out)
 
 
 def conv3x3(planes, stride=1):
@@ -31,23 +61,19 @@ class BasicBlock(layer.Layer):
     def __init__(self, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = conv3x3(planes, stride)
-        self.bn1 = layer.BatchNorm2d(planes)
-        self.relu1 = layer.ReLU()
+        self.bn1 = _BnRelu(planes)
         self.conv2 = conv3x3(planes)
-        self.bn2 = layer.BatchNorm2d(planes)
-        self.add = layer.Add()
-        self.relu2 = layer.ReLU()
+        self.bn2 = _BnRelu(planes)
         if downsample is not None:
             self.downsample = downsample
         self.has_downsample = downsample is not None
 
     def forward(self, x):
         residual = x
-        out = self.relu1(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
+        out = self.bn1(self.conv1(x))
         if self.has_downsample:
             residual = self.downsample(x)
-        return self.relu2(self.add(out, residual))
+        return self.bn2(self.conv2(out), residual)
 
 
 class Bottleneck(layer.Layer):
@@ -56,28 +82,23 @@ class Bottleneck(layer.Layer):
     def __init__(self, planes, stride=1, downsample=None):
         super().__init__()
         self.conv1 = layer.Conv2d(planes, 1, bias=False)
-        self.bn1 = layer.BatchNorm2d(planes)
-        self.relu1 = layer.ReLU()
+        self.bn1 = _BnRelu(planes)
         self.conv2 = layer.Conv2d(planes, 3, stride=stride, padding=1,
                                   bias=False)
-        self.bn2 = layer.BatchNorm2d(planes)
-        self.relu2 = layer.ReLU()
+        self.bn2 = _BnRelu(planes)
         self.conv3 = layer.Conv2d(planes * self.expansion, 1, bias=False)
-        self.bn3 = layer.BatchNorm2d(planes * self.expansion)
-        self.add = layer.Add()
-        self.relu3 = layer.ReLU()
+        self.bn3 = _BnRelu(planes * self.expansion)
         if downsample is not None:
             self.downsample = downsample
         self.has_downsample = downsample is not None
 
     def forward(self, x):
         residual = x
-        out = self.relu1(self.bn1(self.conv1(x)))
-        out = self.relu2(self.bn2(self.conv2(out)))
-        out = self.bn3(self.conv3(out))
+        out = self.bn1(self.conv1(x))
+        out = self.bn2(self.conv2(out))
         if self.has_downsample:
             residual = self.downsample(x)
-        return self.relu3(self.add(out, residual))
+        return self.bn3(self.conv3(out), residual)
 
 
 class ResNet(model.Model):
@@ -89,8 +110,7 @@ class ResNet(model.Model):
         self.input_size = 224
         self.dimension = 4
         self.conv1 = layer.Conv2d(64, 7, stride=2, padding=3, bias=False)
-        self.bn1 = layer.BatchNorm2d(64)
-        self.relu = layer.ReLU()
+        self.bn1 = _BnRelu(64)
         self.maxpool = layer.MaxPool2d(kernel_size=3, stride=2, padding=1)
         stages = []
         for i, (planes, n, stride) in enumerate(
@@ -115,7 +135,7 @@ class ResNet(model.Model):
         return out
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1(self.conv1(x)))
         for stage in self.stages:
             for blk in stage:
                 x = blk(x)

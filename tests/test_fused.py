@@ -1,0 +1,117 @@
+"""Fused operators against their unfused compositions: relu(bn(x)) and
+relu(bn(x) + residual) computed inside the BatchNorm kernels must match the
+separate BatchNorm / Add / ReLU operators in forward, every gradient and the
+running statistics (host and MI355X)."""
+import numpy as np
+import pytest
+
+from singa_amd import autograd, layer, tensor
+
+
+def _grads(loss_fn, params):
+    loss = loss_fn()
+    got = {id(p): tensor.to_numpy(g) for p, g in autograd.backward(loss)}
+    return [got[id(p)] for p in params]
+
+
+@pytest.mark.parametrize("shape", [(4, 6, 5, 8), (3, 5, 7, 7), (8, 16)])
+@pytest.mark.parametrize("with_residual", [False, True])
+def test_bn_act_matches_unfused(dev, shape, with_residual):
+    if len(shape) == 2 and with_residual:
+        pytest.skip("residual form is used on feature maps")
+    rs = np.random.RandomState(0)
+    xn = rs.randn(*shape).astype(np.float32)
+    rn = rs.randn(*shape).astype(np.float32)
+    wn = rs.randn(*shape).astype(np.float32)   # weights of the scalar loss
+    sn = (rs.rand(shape[1]) + 0.5).astype(np.float32)
+    bn_ = (rs.randn(shape[1]) * 0.3).astype(np.float32)
+    autograd.training = True
+    try:
+        results = []
+        for fused in (True, False):
+            x = tensor.Tensor(device=dev, data=xn, requires_grad=True,
+                              stores_grad=True)
+            r = tensor.Tensor(device=dev, data=rn, requires_grad=True,
+                              stores_grad=True)
+            w = tensor.Tensor(device=dev, data=wn, requires_grad=False)
+            bn = layer.BatchNorm2d(shape[1], momentum=0.3,
+                                   activation="RELU" if fused else None)
+            y0 = bn(x, r) if (fused and with_residual) else bn(x)
+            bn.scale.copy_from_numpy(sn)
+            bn.bias.copy_from_numpy(bn_)
+            bn.running_mean.set_value(0.0)
+            bn.running_var.set_value(1.0)
+
+            def fwd():
+                if fused:
+                    y = bn(x, r) if with_residual else bn(x)
+                else:
+                    y = bn(x)
+                    if with_residual:
+                        y = autograd.add(y, r)
+                    y = autograd.relu(y)
+                fwd.y = y
+                return autograd.mse_loss(y, w)
+
+            params = [x, bn.scale, bn.bias] + ([r] if with_residual else [])
+            g = _grads(fwd, params)
+            results.append((tensor.to_numpy(fwd.y), g,
+                            tensor.to_numpy(bn.running_mean),
+                            tensor.to_numpy(bn.running_var)))
+        (yf, gf, mf, vf), (yu, gu, mu, vu) = results
+        np.testing.assert_allclose(yf, yu, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(mf, mu, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(vf, vu, rtol=1e-5, atol=1e-6)
+        for a, b in zip(gf, gu):
+            np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4)
+    finally:
+        autograd.training = False
+
+
+def test_bn_act_inference(dev):
+    rs = np.random.RandomState(1)
+    xn = rs.randn(2, 4, 3, 3).astype(np.float32)
+    rn = rs.randn(2, 4, 3, 3).astype(np.float32)
+    x = tensor.Tensor(device=dev, data=xn)
+    r = tensor.Tensor(device=dev, data=rn)
+    fused = layer.BatchNorm2d(4, activation="RELU")
+    plain = layer.BatchNorm2d(4)
+    autograd.training = False
+    y1 = tensor.to_numpy(fused(x, r))
+    y2 = tensor.to_numpy(autograd.relu(autograd.add(plain(x), r)))
+    np.testing.assert_allclose(y1, y2, rtol=1e-5, atol=1e-6)
+    fused2 = layer.BatchNorm2d(4, activation="RELU")
+    np.testing.assert_allclose(tensor.to_numpy(fused2(x)),
+                               np.maximum(tensor.to_numpy(plain(x)), 0),
+                               rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("momentum,nesterov", [(0.0, False), (0.9, False),
+                                               (0.9, True)])
+def test_multi_tensor_sgd_matches_per_tensor(dev, momentum, nesterov):
+    """One multi-tensor launch per 48 parameters == the per-parameter kernel,
+    for sizes that straddle the 4096-element chunks and the 16-byte vector
+    width, over two steps (so the momentum buffers are exercised)."""
+    from singa_amd import opt
+    rs = np.random.RandomState(0)
+    sizes = [1, 3, 64, 4095, 4096, 4097, 10001] + [7 + i for i in range(50)]
+    vals = [rs.randn(n).astype(np.float32) for n in sizes]
+    grads = [[rs.randn(n).astype(np.float32) for n in sizes] for _ in range(2)]
+
+    def run(many):
+        sgd = opt.SGD(lr=0.1, momentum=momentum, weight_decay=1e-3,
+                      nesterov=nesterov)
+        ps = [tensor.Tensor(device=dev, data=v.copy(), name="p%d" % i)
+              for i, v in enumerate(vals)]
+        for step in range(2):
+            gs = [tensor.Tensor(device=dev, data=g) for g in grads[step]]
+            if many:
+                sgd.apply_many(list(zip(ps, gs)), scale=0.5)
+            else:
+                for p, g in zip(ps, gs):
+                    sgd.apply(p.name, p, g, scale=0.5)
+            sgd.step()
+        return [tensor.to_numpy(p) for p in ps]
+
+    for a, b in zip(run(True), run(False)):
+        np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)

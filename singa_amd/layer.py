@@ -216,12 +216,12 @@ class Linear(Layer):
         w_shape = (self.in_features, self.out_features)
         b_shape = (self.out_features,)
         self.W = Tensor(shape=w_shape, dtype=x.dtype, requires_grad=True,
-                        stores_grad=True)
+                        stores_grad=True, device=x.device)
         std = math.sqrt(2.0 / (self.in_features + self.out_features))
         self.W.gaussian(0.0, std)
         if self.bias:
             self.b = Tensor(shape=b_shape, dtype=x.dtype, requires_grad=True,
-                            stores_grad=True)
+                            stores_grad=True, device=x.device)
             self.b.set_value(0.0)
         else:
             self.b = None
@@ -515,16 +515,16 @@ class BatchNorm2d(Layer):
         self.channels = x.shape[1]
         param_shape = (self.channels,)
         self.scale = Tensor(shape=param_shape, requires_grad=True,
-                            stores_grad=True)
+                            stores_grad=True, device=x.device)
         self.scale.set_value(1.0)
         self.bias = Tensor(shape=param_shape, requires_grad=True,
-                           stores_grad=True)
+                           stores_grad=True, device=x.device)
         self.bias.set_value(0.0)
         self.running_mean = Tensor(shape=param_shape, requires_grad=False,
-                                   stores_grad=False)
+                                   stores_grad=False, device=x.device)
         self.running_mean.set_value(0.0)
         self.running_var = Tensor(shape=param_shape, requires_grad=False,
-                                  stores_grad=False)
+                                  stores_grad=False, device=x.device)
         self.running_var.set_value(1.0)
         if not hasattr(self, "handle"):
             self.handle = singa.BatchNormHandle(self.momentum, x.data)
@@ -668,13 +668,13 @@ class RNN(RNN_Base):
 
     def initialize(self, xs, h0):
         self.Wx = Tensor(shape=(self.input_size, self.hidden_size),
-                         requires_grad=True, stores_grad=True)
+                         requires_grad=True, stores_grad=True, device=xs[0].device)
         self.Wx.gaussian(0.0, 1.0)
         self.Wh = Tensor(shape=(self.hidden_size, self.hidden_size),
-                         requires_grad=True, stores_grad=True)
+                         requires_grad=True, stores_grad=True, device=xs[0].device)
         self.Wh.gaussian(0.0, 1.0)
         self.b = Tensor(shape=(self.hidden_size,), requires_grad=True,
-                        stores_grad=True)
+                        stores_grad=True, device=xs[0].device)
         self.b.set_value(0.0)
 
     def forward(self, xs, h0):
@@ -748,19 +748,19 @@ class LSTM(RNN_Base):
         for g in self._gates:
             setattr(self, "Wx_" + g,
                     Tensor(shape=(self.input_size, self.hidden_size),
-                           requires_grad=True, stores_grad=True))
+                           requires_grad=True, stores_grad=True, device=xs[0].device))
         for g in self._gates:
             setattr(self, "Wh_" + g,
                     Tensor(shape=(self.hidden_size, self.hidden_size),
-                           requires_grad=True, stores_grad=True))
+                           requires_grad=True, stores_grad=True, device=xs[0].device))
         for g in self._gates:
             setattr(self, "Bx_" + g, Tensor(shape=(self.hidden_size,),
                                             requires_grad=True,
-                                            stores_grad=True))
+                                            stores_grad=True, device=xs[0].device))
         for g in self._gates:
             setattr(self, "Bh_" + g, Tensor(shape=(self.hidden_size,),
                                             requires_grad=True,
-                                            stores_grad=True))
+                                            stores_grad=True, device=xs[0].device))
         ws, bs = self._all()
         for w in ws:
             w.gaussian(0.0, 0.01)

@@ -1568,9 +1568,20 @@ class Split(Operator):
         for _l in self.parts:
             xs.append(singa.SliceOn(x, _s, _s + _l, self.axis))
             _s += _l
+        self._like = (x_shape, x.device(), x.data_type())
         return tuple(xs)
 
     def backward(self, *dys):
+        # outputs that nothing consumed have no gradient: they contribute zeros
+        x_shape, dev, dtype = self._like
+        dys = list(dys)
+        for i, (dy, part) in enumerate(zip(dys, self.parts)):
+            if dy is None:
+                shape = list(x_shape)
+                shape[self.axis] = part
+                z = singa.Tensor(shape, dev, dtype)
+                z.SetFloatValue(0.0)
+                dys[i] = z
         return singa.ConcatOn(singa.VecTensor(dys), self.axis)
 
 

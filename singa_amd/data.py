@@ -72,6 +72,7 @@ class ImageBatchIter(object):
         self.delimiter = delimiter
         self.image_folder = image_folder or ""
         self.num_workers = max(1, int(num_workers))
+        self._capacity = capacity
         self.queue = Queue(capacity)
         self._stop = Event()
         self.p = None
@@ -98,20 +99,21 @@ class ImageBatchIter(object):
     next = __next__
 
     def end(self):
+        """Stop the producer.  Batches still in flight are discarded: the
+        child may exit in the middle of writing one, so the pipe is never read
+        again (a partial message would block the reader forever); ``start``
+        after ``end`` gets a fresh queue."""
         if self.p is None:
             return
         self._stop.set()
-        # drain so a producer blocked in put() sees the event promptly
-        try:
-            while True:
-                self.queue.get_nowait()
-        except _queue.Empty:
-            pass
         self.p.join(timeout=2.0)
         if self.p.is_alive():
             self.p.terminate()
             self.p.join()
         self.p = None
+        self.queue.close()
+        self.queue.cancel_join_thread()
+        self.queue = Queue(self._capacity)
 
     # -- producer side -------------------------------------------------------
     def _load(self, rel_path):

@@ -86,6 +86,19 @@ class Optimizer(object):
         self.step_counter.set_value(0)
         self.lr_value = self.lr(self.step_counter)
 
+    def _state_key(self, name, param):
+        """Key of a parameter's optimizer state.  It is the parameter's name;
+        when two different parameter tensors carry the same name (layers used
+        outside a Model are not given hierarchical names) later ones get a
+        numbered key instead of silently sharing state."""
+        owners = self.__dict__.setdefault("_key_owner", {})
+        key, n = name, 0
+        while key in owners and owners[key] != id(param):
+            n += 1
+            key = "%s#%d" % (name, n)
+        owners[key] = id(param)
+        return key
+
     def get_states(self):
         return {'step_counter': tensor.to_numpy(self.step_counter)[0]}
 
@@ -177,6 +190,7 @@ class SGD(Optimizer):
                           self.mom_value, self.dam_value, self.decay_value)
         assert param_value.dtype == self.dtype
         buf = None
+        param_name = self._state_key(param_name, param_value)
         if self.momentum.init_value != 0:
             if param_name not in self.moments:
                 self.moments[param_name] = self._new_state(param_value)
@@ -208,9 +222,10 @@ class SGD(Optimizer):
             if use_mom:
                 bufs = []
                 for p, _ in items:
-                    if p.name not in self.moments:
-                        self.moments[p.name] = self._new_state(p)
-                    bufs.append(self.moments[p.name].data)
+                    key = self._state_key(p.name, p)
+                    if key not in self.moments:
+                        self.moments[key] = self._new_state(p)
+                    bufs.append(self.moments[key].data)
             singa.SGDUpdateMulti([p.data for p, _ in items],
                                  [g.data for _, g in items], bufs,
                                  self.lr_value.data, self.mom_value.data,
@@ -264,6 +279,7 @@ class RMSProp(Optimizer):
                           self.rho_value, self.epsilon_value, self.decay_value)
         if self.weight_decay.init_value != 0:
             singa.Axpy(self.decay_value.data, param_value.data, param_grad.data)
+        param_name = self._state_key(param_name, param_value)
         if param_name not in self.running_average:
             self.running_average[param_name] = self._new_state(param_value)
         ra = self.running_average[param_name]
@@ -313,6 +329,7 @@ class AdaGrad(Optimizer):
                           self.epsilon_value, self.decay_value)
         if self.weight_decay.init_value != 0:
             singa.Axpy(self.decay_value.data, param_value.data, param_grad.data)
+        param_name = self._state_key(param_name, param_value)
         if param_name not in self.history:
             self.history[param_name] = self._new_state(param_value)
         hist = self.history[param_name]
@@ -369,6 +386,7 @@ class Adam(Optimizer):
                           self.epsilon_value, self.decay_value)
         if self.weight_decay.init_value != 0:
             singa.Axpy(self.decay_value.data, param_value.data, param_grad.data)
+        param_name = self._state_key(param_name, param_value)
         if param_name not in self.m:
             self.m[param_name] = self._new_state(param_value)
             self.v[param_name] = self._new_state(param_value)

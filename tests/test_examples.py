@@ -102,3 +102,19 @@ def test_gan_step():
         sys.path.pop(0)
         for k in ("utils", "model", "vanilla"):
             sys.modules.pop(k, None)
+
+
+def test_raw_autograd_mnist_with_name_clashes():
+    """Layers used outside a Model share parameter names ("W", "b"); the
+    optimizer must still keep one momentum buffer per parameter."""
+    mod = _import(os.path.join("cnn", "autograd"), "mnist_cnn")
+    acc = mod.main(["-m", "2", "-b", "32", "--max-batches", "12"])
+    assert acc > 0.5
+
+
+def test_folder_dataset_with_prefetch(tmp_path, monkeypatch):
+    monkeypatch.setattr("tempfile.tempdir", str(tmp_path))
+    mod = _import("largedataset_cnn", "train_largedata")
+    loss, train_acc, val_acc = mod.main(["cnn", "--synthetic", "-m", "4",
+                                         "-b", "16"])
+    assert val_acc > 0.6

@@ -284,4 +284,40 @@ class Merge : public Layer {
   Shape out_sample_shape_;
 };
 
+/// Single-direction recurrent layer (relu / tanh / lstm / gru) unrolled over a
+/// sequence.  Forward takes {x_0 .. x_{T-1}, hx [, cx]} with x_t of shape
+/// (batch, feature) and hx / cx of shape (batch, hidden) (empty tensors mean
+/// zeros) and returns {y_0 .. y_{T-1}, hy [, cy]}; Backward takes the
+/// gradients in the same order and returns {dx_0 .. dx_{T-1}, dhx [, dcx]}
+/// plus the parameter gradients {dWx, dWh, db [, dbh]}.  Every step is two
+/// GEMMs and element-wise gate math, on either device.
+/// Parity: reference src/model/layer/{rnn,cudnn_rnn}.{h,cc} (same I/O
+/// convention; cuDNN's flat weight blob becomes explicit matrices).
+class RNN : public Layer {
+ public:
+  const std::string layer_type() const override { return "RNN"; }
+  void Setup(const Shape &in_sample, const LayerConf &conf) override;
+  const Shape GetOutputSampleShape() const override { return Shape{hidden_}; }
+  const std::vector<Tensor> Forward(int flag,
+                                    const std::vector<Tensor> &inputs) override;
+  const std::pair<std::vector<Tensor>, std::vector<Tensor>> Backward(
+      int flag, const std::vector<Tensor> &grads) override;
+  size_t hidden_size() const { return hidden_; }
+  bool has_cell() const { return mode_ == "lstm"; }
+
+ protected:
+  std::vector<Tensor *> param_ptrs() override {
+    if (mode_ == "gru") return {&wx_, &wh_, &b_, &bh_};
+    return {&wx_, &wh_, &b_};
+  }
+  struct StepCache {
+    Tensor x, h_prev, c_prev, gates, c, extra;  // what Backward needs
+  };
+  std::string mode_ = "lstm";
+  size_t input_ = 0, hidden_ = 0, ngates_ = 4;
+  Tensor wx_, wh_, b_, bh_;
+  std::stack<std::vector<StepCache>> buf_;
+};
+using CudnnRNN = RNN;
+
 }  // namespace singa

@@ -615,4 +615,168 @@ const std::pair<std::vector<Tensor>, std::vector<Tensor>> Merge::Backward(
   return {std::vector<Tensor>(input_size_, grads[0]), {}};
 }
 
+// ---- RNN ---------------------------------------------------------------------------
+RegisterLayerClass(singa_rnn, RNN);
+RegisterLayerClass(singacpp_rnn, RNN);
+RegisterLayerClass(singacuda_rnn, RNN);
+RegisterLayerClass(cudnn_rnn, RNN);
+
+void RNN::Setup(const Shape &in_sample, const LayerConf &conf) {
+  Layer::Setup(in_sample, conf);
+  CHECK_EQ(in_sample.size(), 1u) << "RNN takes (feature) samples per step";
+  mode_ = ToLowerCase(conf.rnn_conf.rnn_mode);
+  CHECK(mode_ == "relu" || mode_ == "tanh" || mode_ == "lstm" || mode_ == "gru")
+      << "unknown rnn_mode " << mode_;
+  CHECK_EQ(conf.rnn_conf.direction, std::string("unidirectional"));
+  CHECK_EQ(conf.rnn_conf.num_stacks, 1) << "stack RNN layers explicitly";
+  input_ = in_sample[0];
+  hidden_ = conf.rnn_conf.hidden_size;
+  CHECK_GT(hidden_, 0u);
+  ngates_ = mode_ == "lstm" ? 4 : (mode_ == "gru" ? 3 : 1);
+  wx_.Resize(Shape{input_, ngates_ * hidden_});
+  wh_.Resize(Shape{hidden_, ngates_ * hidden_});
+  b_.Resize(Shape{ngates_ * hidden_});
+  if (mode_ == "gru") bh_.Resize(Shape{ngates_ * hidden_});
+  const float k = 1.f / std::sqrt(static_cast<float>(hidden_));
+  Uniform(-k, k, &wx_);
+  Uniform(-k, k, &wh_);
+  b_.SetValue(0.f);
+  if (mode_ == "gru") bh_.SetValue(0.f);
+  EnsureParamSpecs(mode_ == "gru"
+                       ? std::vector<std::string>{"wx", "wh", "b", "bh"}
+                       : std::vector<std::string>{"wx", "wh", "b"});
+}
+
+static Tensor Gate(const Tensor &z, size_t k, size_t H) {
+  return SliceOn(z, k * H, (k + 1) * H, 1);
+}
+static Tensor OneMinus(const Tensor &t) { return t * -1.f + 1.f; }
+static Tensor ZerosLike(const Tensor &ref, const Shape &s) {
+  Tensor z(s, ref.device(), ref.data_type());
+  z.SetValue(0.f);
+  return z;
+}
+
+const std::vector<Tensor> RNN::Forward(int flag,
+                                       const std::vector<Tensor> &inputs) {
+  const size_t extra = has_cell() ? 2 : 1;
+  CHECK_GT(inputs.size(), extra);
+  const size_t T = inputs.size() - extra;
+  const size_t B = inputs[0].shape(0), H = hidden_;
+  Tensor h = inputs[T].Size() ? inputs[T] : ZerosLike(inputs[0], Shape{B, H});
+  Tensor c;
+  if (has_cell())
+    c = inputs[T + 1].Size() ? inputs[T + 1] : ZerosLike(inputs[0], Shape{B, H});
+  std::vector<StepCache> caches;
+  std::vector<Tensor> out;
+  for (size_t t = 0; t < T; ++t) {
+    const Tensor &x = inputs[t];
+    CHECK_EQ(x.shape(1), input_);
+    StepCache sc;
+    sc.x = x;
+    sc.h_prev = h;
+    Tensor a = Mult(x, wx_);
+    AddRow(b_, &a);
+    Tensor u = Mult(h, wh_);
+    if (mode_ == "lstm") {
+      Tensor z = a + u;
+      Tensor i = Sigmoid(Gate(z, 0, H)), f = Sigmoid(Gate(z, 1, H));
+      Tensor o = Sigmoid(Gate(z, 2, H)), g = Tanh(Gate(z, 3, H));
+      sc.c_prev = c;
+      c = f * c + i * g;
+      h = o * Tanh(c);
+      sc.gates = ConcatOn({i, f, o, g}, 1);
+      sc.c = c;
+    } else if (mode_ == "gru") {
+      AddRow(bh_, &u);
+      Tensor r = Sigmoid(Gate(a, 0, H) + Gate(u, 0, H));
+      Tensor zg = Sigmoid(Gate(a, 1, H) + Gate(u, 1, H));
+      Tensor un = Gate(u, 2, H);
+      Tensor n = Tanh(Gate(a, 2, H) + r * un);
+      h = OneMinus(zg) * n + zg * h;
+      sc.gates = ConcatOn({r, zg, n}, 1);
+      sc.extra = un;
+    } else {
+      Tensor z = a + u;
+      h = mode_ == "relu" ? ReLU(z) : Tanh(z);
+      sc.gates = h;
+    }
+    out.push_back(h);
+    if (flag & kTrain) caches.push_back(sc);
+  }
+  out.push_back(h);
+  if (has_cell()) out.push_back(c);
+  if (flag & kTrain) buf_.push(caches);
+  return out;
+}
+
+const std::pair<std::vector<Tensor>, std::vector<Tensor>> RNN::Backward(
+    int flag, const std::vector<Tensor> &grads) {
+  CHECK(!buf_.empty()) << "Backward without a matching training Forward";
+  std::vector<StepCache> caches = buf_.top();
+  buf_.pop();
+  const size_t T = caches.size(), H = hidden_;
+  const size_t extra = has_cell() ? 2 : 1;
+  CHECK_EQ(grads.size(), T + extra);
+  const Tensor &ref = caches[0].x;
+  const size_t B = ref.shape(0);
+  Tensor dh = grads[T].Size() ? grads[T].Clone() : ZerosLike(ref, Shape{B, H});
+  Tensor dc;
+  if (has_cell())
+    dc = grads[T + 1].Size() ? grads[T + 1].Clone()
+                             : ZerosLike(ref, Shape{B, H});
+  Tensor dwx = ZerosLike(ref, wx_.shape()), dwh = ZerosLike(ref, wh_.shape());
+  Tensor db = ZerosLike(ref, b_.shape()), dbh;
+  if (mode_ == "gru") dbh = ZerosLike(ref, bh_.shape());
+  std::vector<Tensor> dxs(T);
+  Tensor rowsum(Shape{ngates_ * H}, ref.device(), ref.data_type());
+  for (int t = static_cast<int>(T) - 1; t >= 0; --t) {
+    const StepCache &sc = caches[t];
+    if (grads[t].Size()) dh += grads[t];
+    Tensor da, du;  // gradients of the input and recurrent pre-activations
+    if (mode_ == "lstm") {
+      Tensor i = Gate(sc.gates, 0, H), f = Gate(sc.gates, 1, H);
+      Tensor o = Gate(sc.gates, 2, H), g = Gate(sc.gates, 3, H);
+      Tensor tc = Tanh(sc.c);
+      Tensor dct = dc + dh * o * OneMinus(tc * tc);
+      Tensor di = dct * g * i * OneMinus(i);
+      Tensor df = dct * sc.c_prev * f * OneMinus(f);
+      Tensor d_o = dh * tc * o * OneMinus(o);
+      Tensor dg = dct * i * OneMinus(g * g);
+      dc = dct * f;
+      da = ConcatOn({di, df, d_o, dg}, 1);
+      du = da;
+    } else if (mode_ == "gru") {
+      Tensor r = Gate(sc.gates, 0, H), zg = Gate(sc.gates, 1, H);
+      Tensor n = Gate(sc.gates, 2, H);
+      Tensor dn = dh * OneMinus(zg) * OneMinus(n * n);
+      Tensor dz = dh * (sc.h_prev - n) * zg * OneMinus(zg);
+      Tensor dr = dn * sc.extra * r * OneMinus(r);
+      da = ConcatOn({dr, dz, dn}, 1);
+      du = ConcatOn({dr, dz, dn * r}, 1);
+    } else {
+      Tensor h = sc.gates;
+      da = mode_ == "relu" ? ReLUBackward(dh, h) : dh * OneMinus(h * h);
+      du = da;
+    }
+    Mult<float>(1.f, sc.x.T(), da, 1.f, &dwx);
+    Mult<float>(1.f, sc.h_prev.T(), du, 1.f, &dwh);
+    SumRows(da, &rowsum);
+    db += rowsum;
+    if (mode_ == "gru") {
+      SumRows(du, &rowsum);
+      dbh += rowsum;
+    }
+    dxs[t] = Mult(da, wx_.T());
+    Tensor dh_prev = Mult(du, wh_.T());
+    if (mode_ == "gru") dh_prev += dh * Gate(sc.gates, 1, H);
+    dh = dh_prev;
+  }
+  dxs.push_back(dh);
+  if (has_cell()) dxs.push_back(dc);
+  std::vector<Tensor> pg{dwx, dwh, db};
+  if (mode_ == "gru") pg.push_back(dbh);
+  return {dxs, pg};
+}
+
 }  // namespace singa

@@ -376,6 +376,99 @@ static void TestDropoutAndMulti(std::shared_ptr<Device> dev) {
   EXPECT(merge->Backward(kTrain, m).first.size() == 2);
 }
 
+struct RnnResult {
+  double objective;
+  std::vector<std::vector<float>> dx, dp;
+};
+
+// objective = sum_t <y_t, w_t> + <hy, w_T> (+ <cy, w_T+1>)
+static RnnResult RunRnn(const std::string &mode, std::shared_ptr<Device> dev,
+                        const std::vector<std::vector<float>> &xs,
+                        const std::vector<std::vector<float>> &params,
+                        bool backward) {
+  const size_t T = xs.size(), B = 3, F = 4, H = 5;
+  LayerConf conf;
+  conf.name = "rnn";
+  conf.type = "singacpp_rnn";
+  conf.rnn_conf.rnn_mode = mode;
+  conf.rnn_conf.hidden_size = H;
+  auto layer = CreateLayer(conf.type);
+  layer->Setup(Shape{F}, conf);
+  layer->ToDevice(dev);
+  auto pv = layer->param_values();
+  for (size_t i = 0; i < pv.size(); ++i)
+    pv[i].CopyDataFromHostPtr(params[i].data(), params[i].size());
+  bool cell = mode == "lstm";
+  std::vector<Tensor> in;
+  for (size_t t = 0; t < T; ++t) in.push_back(FromVec(xs[t], {B, F}, dev));
+  in.push_back(FromVec(Rand(B * H, 71, 0.5f), {B, H}, dev));
+  if (cell) in.push_back(FromVec(Rand(B * H, 72, 0.5f), {B, H}, dev));
+  auto out = layer->Forward(kTrain, in);
+  RnnResult r;
+  r.objective = 0;
+  std::vector<Tensor> grads;
+  for (size_t k = 0; k < out.size(); ++k) {
+    auto w = Rand(B * H, 80 + k);
+    auto y = ToVec(out[k]);
+    for (size_t i = 0; i < y.size(); ++i) r.objective += double(y[i]) * w[i];
+    grads.push_back(FromVec(w, {B, H}, dev));
+  }
+  if (backward) {
+    auto ret = layer->Backward(kTrain, grads);
+    for (auto &g : ret.first) r.dx.push_back(ToVec(g));
+    for (auto &g : ret.second) r.dp.push_back(ToVec(g));
+  } else {
+    layer->Backward(kTrain, grads);
+  }
+  return r;
+}
+
+static void TestRnn() {
+  const size_t T = 3, B = 3, F = 4, H = 5;
+  for (std::string mode : {"tanh", "relu", "lstm", "gru"}) {
+    size_t G = mode == "lstm" ? 4 : (mode == "gru" ? 3 : 1);
+    std::vector<std::vector<float>> xs, params;
+    for (size_t t = 0; t < T; ++t) xs.push_back(Rand(B * F, 60 + t));
+    params.push_back(Rand(F * G * H, 90, 0.4f));
+    params.push_back(Rand(H * G * H, 91, 0.4f));
+    params.push_back(Rand(G * H, 92, 0.2f));
+    if (mode == "gru") params.push_back(Rand(G * H, 93, 0.2f));
+    RnnResult ref = RunRnn(mode, defaultDevice, xs, params, true);
+    EXPECT(ref.dx.size() == T + (mode == "lstm" ? 2 : 1));
+    const float eps = 1e-2f;
+    // inputs
+    for (size_t t = 0; t < T; ++t)
+      for (size_t i : {size_t(0), size_t(5), size_t(11)}) {
+        auto p = xs, m = xs;
+        p[t][i] += eps;
+        m[t][i] -= eps;
+        double num = (RunRnn(mode, defaultDevice, p, params, false).objective -
+                      RunRnn(mode, defaultDevice, m, params, false).objective) /
+                     (2 * eps);
+        EXPECT_NEAR(ref.dx[t][i], num, 3e-2);
+      }
+    // parameters
+    for (size_t k = 0; k < params.size(); ++k)
+      for (size_t i : {size_t(0), params[k].size() / 2, params[k].size() - 1}) {
+        auto p = params, m = params;
+        p[k][i] += eps;
+        m[k][i] -= eps;
+        double num = (RunRnn(mode, defaultDevice, xs, p, false).objective -
+                      RunRnn(mode, defaultDevice, xs, m, false).objective) /
+                     (2 * eps);
+        EXPECT_NEAR(ref.dp[k][i], num, 3e-2);
+      }
+    if (g_gpu) {
+      RnnResult gpu = RunRnn(mode, g_dev, xs, params, true);
+      EXPECT_NEAR(gpu.objective, ref.objective, 1e-4);
+      for (size_t k = 0; k < ref.dx.size(); ++k)
+        ExpectVecNear(gpu.dx[k], ref.dx[k], 2e-4, (mode + " rnn dx").c_str());
+      for (size_t k = 0; k < ref.dp.size(); ++k)
+        ExpectVecNear(gpu.dp[k], ref.dp[k], 5e-4, (mode + " rnn dparam").c_str());
+    }
+  }
+}
+
 static void TestOptimizers(std::shared_ptr<Device> dev) {
   OptimizerConf conf;
   conf.momentum = 0.9f;
@@ -749,12 +842,14 @@ int main(int argc, char **argv) {
   Run("FeedForwardNet/cpu", [&] { TestFeedForwardNet(host, false); });
   Run("FeedForwardNet/cpu-graph", [&] { TestFeedForwardNet(host, true); });
   Run("LocalUpdater", TestLocalUpdater);
+  if (!g_gpu) Run("Rnn/cpu", TestRnn);
   Run("Io", TestIo);
   Run("EndPoint", TestEndPoint);
   if (g_gpu) {
     g_dev = Platform::CreateCudaGPUs(1)[0];
     Run("TensorMath/gpu", [&] { TestTensorMath(g_dev); });
     Run("LayersGpuVsCpu", TestLayersGpuVsCpu);
+    Run("Rnn/cpu+gpu", TestRnn);
     Run("DropoutAndMulti/gpu", [&] { TestDropoutAndMulti(g_dev); });
     Run("Optimizers/gpu", [&] { TestOptimizers(g_dev); });
     Run("LossMetric/gpu", [&] { TestLossMetric(g_dev); });

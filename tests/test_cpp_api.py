@@ -31,13 +31,15 @@ def _run(args, timeout):
 def test_cpp_api_host(exe):
     out = _run([exe], 600)
     for name in ("TensorMath/cpu", "LayersGradient/cpu", "FeedForwardNet/cpu",
-                 "FeedForwardNet/cpu-graph", "LocalUpdater", "Io", "EndPoint"):
+                 "FeedForwardNet/cpu-graph", "LocalUpdater", "Rnn/cpu", "Io",
+                 "EndPoint"):
         assert "[  OK  ] " + name in out
 
 
 @pytest.mark.gpu
 def test_cpp_api_gpu(exe):
     out = _run([exe, "--gpu"], 600)
-    for name in ("TensorMath/gpu", "LayersGpuVsCpu", "FeedForwardNet/gpu",
+    for name in ("TensorMath/gpu", "LayersGpuVsCpu", "Rnn/cpu+gpu",
+                 "FeedForwardNet/gpu",
                  "FeedForwardNet/gpu-graph"):
         assert "[  OK  ] " + name in out

@@ -11,6 +11,8 @@ the graph's private pool).
 Contract parity: reference src/core/tensor/tensor_math.h:86-485 and
 tensor_math_cuda.h (the CUDA specialisations this backend stands in for).
 """
+import os
+
 import torch
 
 from . import dtypes
@@ -59,6 +61,8 @@ def _collapse(shape, strides_list):
 def _is_linear(shp, st):
     return len(shp) == 1 and st[0] == 1
 
+
+_CONV_AUTOTUNE = os.environ.get("SINGA_CONV_AUTOTUNE", "1") != "0"
 
 class HipMath(object):
     name = "hip"
@@ -388,29 +392,80 @@ class HipMath(object):
         return self.k.ConvGeom(N, C, H, W, K, R, S, yshape[2], yshape[3],
                                stride[0], stride[1], pad[0], pad[1], groups)
 
+    # Launch-plan autotuning (the role of cuDNN's algorithm search in the
+    # reference, convolution.cc:514-640): the first time a (pass, geometry,
+    # dtype) is seen outside stream capture, every candidate tile edge / split
+    # target is timed on the real operands and the fastest one is cached for
+    # the life of the process.  SINGA_CONV_AUTOTUNE=0 keeps the heuristic.
+    _conv_plans = {}
+    _CONV_CANDIDATES = ((64, 512), (64, 1024), (64, 2048), (128, 256),
+                        (128, 512), (128, 1024), (128, 2048))
+
+    def _tuned(self, mode, g, key, launch):
+        """Set g.tile / g.split_target for this launch.  ``launch(g)`` runs the
+        convolution once (it only overwrites the output)."""
+        plan = self._conv_plans.get((mode,) + key)
+        if plan is None:
+            if not _CONV_AUTOTUNE or torch.cuda.is_current_stream_capturing():
+                return
+            best, best_t = (0, 0), None
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            stream = torch.cuda.current_stream()
+            for cand in ((0, 0),) + self._CONV_CANDIDATES:
+                g.tile, g.split_target = cand
+                launch(g)                      # warm up / page in code
+                e0.record(stream)
+                for _ in range(3):
+                    launch(g)
+                e1.record(stream)
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                if best_t is None or t < best_t * 0.97:   # prefer the default
+                    best, best_t = cand, t
+            plan = best
+            self._conv_plans[(mode,) + key] = plan
+        g.tile, g.split_target = plan
+
     def conv_fwd(self, x, w, b, y, stride, pad, groups):
         g = self._geom(x.shape, w.shape, y.shape, stride, pad, groups)
         w = self._contig(w)
-        self.k.conv_fwd(_code(x), g, x.data_ptr(), w.data_ptr(),
-                        b.data_ptr() if b is not None else 0, y.data_ptr(),
-                        self._s())
+        args = (x.data_ptr(), w.data_ptr(),
+                b.data_ptr() if b is not None else 0, y.data_ptr())
+        code = _code(x)
+        key = (tuple(x.shape), tuple(w.shape), tuple(stride), tuple(pad),
+               groups, code)
+        self._tuned(0, g, key,
+                    lambda gg: self.k.conv_fwd(code, gg, *args, self._s()))
+        self.k.conv_fwd(code, g, *args, self._s())
 
     def conv_bwd_data(self, dy, w, dx, stride, pad, groups):
         g = self._geom(dx.shape, w.shape, dy.shape, stride, pad, groups)
         w = self._contig(w)
-        self.k.conv_bwd_data(_code(dx), g, dy.data_ptr(), w.data_ptr(),
-                             dx.data_ptr(), self._s())
+        args = (dy.data_ptr(), w.data_ptr(), dx.data_ptr())
+        code = _code(dx)
+        key = (tuple(dx.shape), tuple(w.shape), tuple(stride), tuple(pad),
+               groups, code)
+        self._tuned(1, g, key,
+                    lambda gg: self.k.conv_bwd_data(code, gg, *args,
+                                                    self._s()))
+        self.k.conv_bwd_data(code, g, *args, self._s())
 
     def conv_bwd_weight(self, dy, x, dw, stride, pad, groups):
         g = self._geom(x.shape, dw.shape, dy.shape, stride, pad, groups)
+        key = (tuple(x.shape), tuple(dw.shape), tuple(stride), tuple(pad),
+               groups, _code(x))
         if dw.dtype == torch.float32:
-            self.k.conv_bwd_weight(0, g, dy.data_ptr(), x.data_ptr(),
-                                   dw.data_ptr(), self._s())
+            args = (dy.data_ptr(), x.data_ptr(), dw.data_ptr())
         else:
             acc = torch.empty(dw.shape, dtype=torch.float32, device=dw.device)
-            self.k.conv_bwd_weight(0, g, self._f32c(dy).data_ptr(),
-                                   self._f32c(x).data_ptr(), acc.data_ptr(),
-                                   self._s())
+            dyf, xf = self._f32c(dy), self._f32c(x)
+            args = (dyf.data_ptr(), xf.data_ptr(), acc.data_ptr())
+        self._tuned(2, g, key,
+                    lambda gg: self.k.conv_bwd_weight(0, gg, *args,
+                                                      self._s()))
+        self.k.conv_bwd_weight(0, g, *args, self._s())
+        if dw.dtype != torch.float32:
             self.copy(acc, dw)
 
     def conv_bwd_bias(self, dy, db):

@@ -178,7 +178,9 @@ PYBIND11_MODULE(_hip, m) {
         ConvGeom g{N, C, H, W, K, R, Sw, P_, Q, sh, sw, ph, pw, groups};
         return g;
       }))
-      .def_readwrite("N", &ConvGeom::N);
+      .def_readwrite("N", &ConvGeom::N)
+      .def_readwrite("tile", &ConvGeom::tile)
+      .def_readwrite("split_target", &ConvGeom::split_target);
   m.def("conv_fwd", [](int dt, const ConvGeom &g, uintptr_t x, uintptr_t w,
                        uintptr_t bias, uintptr_t y, uintptr_t s) {
     check(sa_conv_fwd(dt, &g, CP(x), CP(w), CP(bias), P(y), S(s)), "conv_fwd");

@@ -15,7 +15,7 @@ inline hipStream_t S(Context *ctx) { return static_cast<hipStream_t>(ctx->stream
 constexpr float kBnEps = 1e-5f;
 
 ConvGeom MakeGeom(const Shape &x, const ConvParams &p) {
-  ConvGeom g;
+  ConvGeom g{};
   g.N = x[0]; g.C = x[1]; g.H = x[2]; g.W = x[3];
   g.K = p.num_filters; g.R = p.kernel_h; g.S = p.kernel_w;
   g.stride_h = p.stride_h; g.stride_w = p.stride_w;

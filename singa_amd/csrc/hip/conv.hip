@@ -547,7 +547,10 @@ conv_igemm_kernel(ConvArgs a) {
   const int lrow = lane & 31, lk = lane >> 5;
   for (int t = 0; t < nt; ++t) {
     const float *as = As[t & 1], *bs = Bs[t & 1];
+#ifndef SA_EXP_NOLOAD
     if (t + 1 < nt) load_tiles(kbeg + (t + 1) * BK);
+#endif
+#ifndef SA_EXP_NOMMA
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 2) {
       float av[TM], bv[TN];
@@ -564,7 +567,12 @@ conv_igemm_kernel(ConvArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j],
                                                            acc[i][j], 0, 0, 0);
     }
+#else
+    if (t == 0) acc[0][0][0] += as[lane] + bs[lane];
+#endif
+#ifndef SA_EXP_NOLOAD
     if (t + 1 < nt) store_tiles((t + 1) & 1);
+#endif
     __syncthreads();
   }
 
@@ -694,8 +702,9 @@ static const int kSplitTarget = env_int("SA_CONV_SPLIT_TARGET", 1024);
 static const int kForceTile = env_int("SA_CONV_TILE", 0);
 
 static inline bool use_big_tile(const ConvArgs &a) {
-  if (kForceTile == 64) return false;
-  if (kForceTile == 128) return true;
+  const int force = a.g.tile ? a.g.tile : kForceTile;
+  if (force == 64) return false;
+  if (force == 128) return true;
   const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.Ngemm + 127) / 128) *
                        a.g.groups * a.ncls;
   return a.M >= 96 && a.Ngemm >= 96 && t128 >= 256;
@@ -708,7 +717,8 @@ static inline bool use_big_tile(const ConvArgs &a) {
 // zero-filled output.
 static void plan_splits(ConvArgs &a, int64_t tiles, int min_k) {
   int64_t splits = 1;
-  if (tiles < kSplitTarget) splits = kSplitTarget / tiles;
+  const int target = a.g.split_target ? a.g.split_target : kSplitTarget;
+  if (tiles < target) splits = target / tiles;
   const int64_t max_splits = (a.Kgemm + min_k - 1) / min_k;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;

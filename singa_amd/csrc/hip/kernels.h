@@ -107,6 +107,10 @@ struct ConvGeom {
   int P, Q;            // output spatial size
   int stride_h, stride_w, pad_h, pad_w;
   int groups;
+  // launch plan overrides, 0 = built-in heuristic: tile edge (64 or 128) and
+  // the number of workgroups below which the reduction is split
+  int tile = 0;
+  int split_target = 0;
 };
 int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                 const void *bias, void *y, hipStream_t s);

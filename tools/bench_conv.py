@@ -128,6 +128,9 @@ def main():
             t = timeit(lambda: m.gemm(1.0, a, b, 0.0, c), args.iters)
             print("gemm %dx%dx%d: %.3f ms %.1f TF/s" %
                   (M, Nn, Kk, t, 2.0 * M * Nn * Kk / t / 1e9))
+    for k, v in sorted(type(m)._conv_plans.items(), key=str):
+        print("plan", k[0], k[1], k[2][2:], "->", v)
+
 
 
 if __name__ == "__main__":

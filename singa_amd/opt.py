@@ -188,7 +188,6 @@ class SGD(Optimizer):
                                                        param_grad.shape)
         self.device_check(param_value, self.step_counter, self.lr_value,
                           self.mom_value, self.dam_value, self.decay_value)
-        assert param_value.dtype == self.dtype
         buf = None
         param_name = self._state_key(param_name, param_value)
         if self.momentum.init_value != 0:
@@ -214,7 +213,8 @@ class SGD(Optimizer):
                 p.name = id(p)
             groups.setdefault((p.dtype, id(p.device)), []).append((p, g))
         for (dt, _), items in groups.items():
-            assert dt == self.dtype
+            # mixed precision: fp16 weights next to fp32 BatchNorm parameters
+            # are updated by one launch per dtype
             self.device_check(items[0][0], self.step_counter, self.lr_value,
                               self.mom_value, self.dam_value,
                               self.decay_value)

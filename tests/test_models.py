@@ -73,3 +73,29 @@ def test_xception_builds_and_runs_forward(cpu_dev):
         assert len(m.get_params()) > 150
     finally:
         autograd.training = True
+
+
+@pytest.mark.gpu
+def test_half_precision_training_step():
+    """fp16 activations / weights with fp32 BatchNorm parameters train through
+    the same graph path (reference train_cnn.py -p float16)."""
+    from singa_amd import device
+    dev = device.create_cuda_gpu()
+    rs = np.random.RandomState(0)
+    x = rs.randn(4, 3, 224, 224).astype(np.float16)
+    y = rs.randint(0, 10, 4).astype(np.int32)
+    tx = tensor.Tensor(device=dev, data=x)
+    ty = tensor.Tensor(device=dev, data=y)
+    assert tx.dtype == tensor.float16
+    m = models.create("resnet18", num_classes=10)
+    m.set_optimizer(opt.SGD(lr=0.01, momentum=0.9, dtype=tensor.float16))
+    m.compile([tx], is_train=True, use_graph=True, sequential=False)
+    losses = []
+    for _ in range(4):
+        out, loss = m(tx, ty, 'plain', None)
+        losses.append(float(tensor.to_numpy(loss).astype(np.float32)
+                            .reshape(-1)[0]))
+    dev.EnableGraph(False)
+    dev.ResetGraph()
+    assert np.all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses

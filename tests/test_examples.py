@@ -118,3 +118,21 @@ def test_folder_dataset_with_prefetch(tmp_path, monkeypatch):
     loss, train_acc, val_acc = mod.main(["cnn", "--synthetic", "-m", "4",
                                          "-b", "16"])
     assert val_acc > 0.6
+
+
+def test_lime_finds_the_informative_region():
+    mod = _import("singa_easy", "lime")
+    label, w = mod.demo()
+    assert int(np.argmax(w)) == label
+
+
+def test_model_selection_two_phase():
+    eng = _import("model_selection", "engine")
+    data, val = eng.toy_data(n=384)
+    out = eng.model_selection(data, val, n_candidates=6, top_k=2)
+    assert out["val_acc"] > 0.8
+    assert len(out["filtered"]) == 2 and len(out["rounds"]) == 2
+    for name in ("grad_norm", "synflow"):
+        s = eng.SCORES[name]((16,), data[0][:32], data[1][:32], data[2],
+                             eng.device.get_default_device())
+        assert np.isfinite(s) and s > 0

@@ -49,7 +49,7 @@ def back_broadcast(y_shape, x_shape, x):
 
 def infer_dependency(op):
     """Count, for the sub-graph ending at ``op``, how many consumers every
-    producing op and every tensor (by python id) has."""
+    producing op and every tensor (by ``Tensor.uid``) has."""
     op_count = Counter()
     tensor_count = Counter()
     queue = deque([op])
@@ -107,11 +107,24 @@ def backward(y, dy=None):
         op, dys = ready.pop()
         if not op.requires_grad or isinstance(op, Dummy):
             continue
+        # An op whose kernel can add onto an existing gradient is handed the
+        # partial sum already collected for its first input; what it returns
+        # then replaces that partial sum instead of being added in a pass of
+        # its own.
+        folded = False
+        if getattr(op, "fuses_dx_addend", False) and op.src:
+            part = not_ready.get(op.src[0][0])
+            if part is not None:
+                p_idx = op.src[0][0].y_id2idx[op.src[0][1]]
+                if part[p_idx] is not None:
+                    op.dx_addend = part[p_idx]
+                    folded = True
         dxs = op._do_backward(*dys)
         assert len(op.src) == len(dxs), (
             "the number of src ops (=%d) and dx (=%d) not match" %
             (len(op.src), len(dxs)))
-        for (src_op, x_id, y_t, y_stores_grad), dx in zip(op.src, dxs):
+        for i, ((src_op, x_id, y_t, y_stores_grad),
+                dx) in enumerate(zip(op.src, dxs)):
             if isinstance(src_op, Dummy) and (not src_op.stores_grad):
                 continue
             y_idx = src_op.y_id2idx[x_id]
@@ -120,7 +133,7 @@ def backward(y, dy=None):
                 not_ready[src_op][y_idx] = dx
             else:
                 dxs_ = not_ready[src_op]
-                if dxs_[y_idx] is None:
+                if dxs_[y_idx] is None or (folded and i == 0):
                     dxs_[y_idx] = dx
                 elif dx is not None:
                     # a tensor consumed by several ops: gradients add up
@@ -185,9 +198,9 @@ class Operator(object):
         self.src = []
         for x in xs:
             if x.stores_grad:
-                self.src.append((x.creator, id(x), x, x.stores_grad))
+                self.src.append((x.creator, x.uid, x, x.stores_grad))
             else:
-                self.src.append((x.creator, id(x), None, x.stores_grad))
+                self.src.append((x.creator, x.uid, None, x.stores_grad))
         xs = tuple(x.data for x in xs)
         ys = self.forward(*xs)
         if not isinstance(ys, tuple):
@@ -196,7 +209,7 @@ class Operator(object):
             Tensor(device=y.device(), data=y, requires_grad=self.requires_grad,
                    creator=self, name=self.output_name(idx))
             for idx, y in enumerate(ys))
-        self.y_id2idx = {id(y): i for i, y in enumerate(ys)}
+        self.y_id2idx = {y.uid: i for i, y in enumerate(ys)}
         return ys
 
     def _do_backward(self, *dys):
@@ -223,7 +236,7 @@ class Dummy(Operator):
     def __init__(self, tensor, name=None):
         super(Dummy, self).__init__(name)
         self.src = []
-        self.y_id2idx = {id(tensor): 0}
+        self.y_id2idx = {tensor.uid: 0}
         self.tensor = tensor
         self.requires_grad = False
 
@@ -2127,6 +2140,10 @@ class _Conv2d(Operator):
         super(_Conv2d, self).__init__()
         self.handle = handle
         self.odd_padding = tuple(odd_padding)
+        # the backward-data kernel adds a gradient that already reached x
+        # along another path (residual forks) in its epilogue
+        self.fuses_dx_addend = self.odd_padding == (0, 0, 0, 0)
+        self.dx_addend = None
 
     def forward(self, x, W, b=None):
         assert x.nDim() == 4, "The dimensions of input should be 4D."
@@ -2143,7 +2160,8 @@ class _Conv2d(Operator):
         dx = None
         if self.x_needs_grad[0]:
             dx = singa.ConvBackwardx(dy, self.inputs[1], self.inputs[0],
-                                     self.handle)
+                                     self.handle, self.dx_addend)
+            self.dx_addend = None
         dW = singa.ConvBackwardW(dy, self.inputs[0], self.inputs[1],
                                  self.handle)
         db = singa.ConvBackwardb(dy, self.inputs[2], self.handle) \

@@ -209,10 +209,10 @@ class CpuMath(object):
     def conv_fwd(self, x, w, b, y, stride, pad, groups):
         y.copy_(F.conv2d(x, w, b, stride=stride, padding=pad, groups=groups))
 
-    def conv_bwd_data(self, dy, w, dx, stride, pad, groups):
+    def conv_bwd_data(self, dy, w, dx, stride, pad, groups, addend=None):
         r = torch.nn.grad.conv2d_input(dx.shape, w, dy, stride=stride,
                                        padding=pad, groups=groups)
-        dx.copy_(r)
+        dx.copy_(r if addend is None else r + addend)
 
     def conv_bwd_weight(self, dy, x, dw, stride, pad, groups):
         r = torch.nn.grad.conv2d_weight(x, dw.shape, dy, stride=stride,

@@ -439,7 +439,10 @@ class HipMath(object):
                     lambda gg: self.k.conv_fwd(code, gg, *args, self._s()))
         self.k.conv_fwd(code, g, *args, self._s())
 
-    def conv_bwd_data(self, dy, w, dx, stride, pad, groups):
+    def conv_bwd_data(self, dy, w, dx, stride, pad, groups, addend=None):
+        """dx = backward-data(dy, w) [+ addend]: the sum with a gradient that
+        reached the same input along another path happens in the kernel's
+        epilogue instead of in a separate pass over dx."""
         g = self._geom(dx.shape, w.shape, dy.shape, stride, pad, groups)
         w = self._contig(w)
         args = (dy.data_ptr(), w.data_ptr(), dx.data_ptr())
@@ -449,7 +452,14 @@ class HipMath(object):
         self._tuned(1, g, key,
                     lambda gg: self.k.conv_bwd_data(code, gg, *args,
                                                     self._s()))
-        self.k.conv_bwd_data(code, g, *args, self._s())
+        if addend is None:
+            self.k.conv_bwd_data(code, g, *args, self._s())
+        else:
+            assert addend.shape == dx.shape and addend.dtype == dx.dtype \
+                and addend.data_ptr() != dx.data_ptr()
+            addend = self._contig(addend)
+            self.k.conv_bwd_data_acc(code, g, args[0], args[1],
+                                     addend.data_ptr(), args[2], self._s())
 
     def conv_bwd_weight(self, dy, x, dw, stride, pad, groups):
         g = self._geom(x.shape, dw.shape, dy.shape, stride, pad, groups)

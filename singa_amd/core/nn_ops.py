@@ -78,14 +78,23 @@ def ConvForward(x, W, b, ch):
     return y
 
 
-def ConvBackwardx(dy, W, x, ch):
+def ConvBackwardx(dy, W, x, ch, addend=None):
+    """Gradient w.r.t. the convolution input; ``addend`` (a tensor of x's
+    shape) is added to it inside the kernel."""
     d = dy if dy.is_contiguous() else Contiguous(dy)
     dx = Tensor(x.shape(), x.device(), x.data_type())
     st, pd, g = (ch.stride_h, ch.stride_w), (ch.pad_h, ch.pad_w), ch.group
-    _submit(x.device(), "ConvBackwardx",
-            lambda a, w, o: a._dev.math.conv_bwd_data(
-                a.view(), w.view(), o.view(), st, pd, g),
-            [d, W], [dx])
+    if addend is None:
+        _submit(x.device(), "ConvBackwardx",
+                lambda a, w, o: a._dev.math.conv_bwd_data(
+                    a.view(), w.view(), o.view(), st, pd, g),
+                [d, W], [dx])
+    else:
+        ad = addend if addend.is_contiguous() else Contiguous(addend)
+        _submit(x.device(), "ConvBackwardxAcc",
+                lambda a, w, p, o: a._dev.math.conv_bwd_data(
+                    a.view(), w.view(), o.view(), st, pd, g, p.view()),
+                [d, W, ad], [dx])
     return dx
 
 

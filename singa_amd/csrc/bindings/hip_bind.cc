@@ -190,6 +190,12 @@ PYBIND11_MODULE(_hip, m) {
     check(sa_conv_bwd_data(dt, &g, CP(dy), CP(w), P(dx), S(s)),
           "conv_bwd_data");
   });
+  m.def("conv_bwd_data_acc", [](int dt, const ConvGeom &g, uintptr_t dy,
+                                uintptr_t w, uintptr_t addend, uintptr_t dx,
+                                uintptr_t s) {
+    check(sa_conv_bwd_data_acc(dt, &g, CP(dy), CP(w), CP(addend), P(dx), S(s)),
+          "conv_bwd_data_acc");
+  });
   m.def("conv_bwd_weight", [](int dt, const ConvGeom &g, uintptr_t dy,
                               uintptr_t x, uintptr_t dw, uintptr_t s) {
     check(sa_conv_bwd_weight(dt, &g, CP(dy), CP(x), P(dw), S(s)),

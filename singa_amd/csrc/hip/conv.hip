@@ -62,6 +62,9 @@ struct ConvArgs {
   const void *b;  // fwd: X        bwd-data: dY       bwd-weight: X
   void *out;      // fwd: Y        bwd-data: dX       bwd-weight: dW (float)
   const void *bias;
+  // backward-data: tensor of dX's shape added to the result (the gradient that
+  // reached the same input along another path); may alias `out`
+  const void *addend;
   int M, Ngemm, Kgemm;  // GEMM extents per group
   int Cg, Kg, RS, PQ, HW;
   int splits, k_per_split;
@@ -547,10 +550,7 @@ conv_igemm_kernel(ConvArgs a) {
   const int lrow = lane & 31, lk = lane >> 5;
   for (int t = 0; t < nt; ++t) {
     const float *as = As[t & 1], *bs = Bs[t & 1];
-#ifndef SA_EXP_NOLOAD
     if (t + 1 < nt) load_tiles(kbeg + (t + 1) * BK);
-#endif
-#ifndef SA_EXP_NOMMA
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 2) {
       float av[TM], bv[TN];
@@ -567,12 +567,7 @@ conv_igemm_kernel(ConvArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j],
                                                            acc[i][j], 0, 0, 0);
     }
-#else
-    if (t == 0) acc[0][0][0] += as[lane] + bs[lane];
-#endif
-#ifndef SA_EXP_NOLOAD
     if (t + 1 < nt) store_tiles((t + 1) & 1);
-#endif
     __syncthreads();
   }
 
@@ -619,9 +614,15 @@ conv_igemm_kernel(ConvArgs a) {
           else atomicAdd((float *)dst, v + bv);  // float outputs only
         } else if (MODE == CONV_BWD_DATA) {
           const int ch = grp * a.Cg + row;
-          T *dst = (T *)a.out + col_off + (size_t)ch * chan_stride;
-          if (a.splits == 1) *dst = from_f<T>(v);
-          else atomicAdd((float *)dst, v);
+          const size_t off = col_off + (size_t)ch * chan_stride;
+          T *dst = (T *)a.out + off;
+          if (a.splits == 1) {
+            const float add =
+                a.addend ? to_f<T>(((const T *)a.addend)[off]) : 0.f;
+            *dst = from_f<T>(v + add);
+          } else {
+            atomicAdd((float *)dst, v);
+          }
         } else {
           float *dst = (float *)a.out +
                        (size_t)(grp * a.Kg + row) * chan_stride + col_off;
@@ -668,6 +669,7 @@ static ConvArgs make_args(const ConvGeom &g, int mode) {
   a.splits = 1;
   a.k_per_split = 0;
   a.bias = nullptr;
+  a.addend = nullptr;
   a.mt = a.nt = 1;
   a.ncls = 1;
   a.tap_mask = a.RS <= 63;
@@ -754,7 +756,14 @@ void launch_conv(ConvArgs &a, size_t out_bytes, hipStream_t s,
                         ((a.Ngemm + tb - 1) / tb) * g.groups * a.ncls;
   if (may_split && (std::is_same<T, float>::value || MODE == CONV_BWD_WEIGHT))
     plan_splits(a, tiles, 256);
-  if (a.splits > 1 && out_bytes) (void)hipMemsetAsync(a.out, 0, out_bytes, s);
+  if (a.splits > 1 && out_bytes) {
+    // partial sums land with atomics: start from the addend, or from zero
+    if (MODE == CONV_BWD_DATA && a.addend && a.addend != a.out)
+      (void)hipMemcpyAsync(a.out, a.addend, out_bytes, hipMemcpyDeviceToDevice,
+                           s);
+    else
+      (void)hipMemsetAsync(a.out, 0, out_bytes, s);
+  }
   bool v1 = false;
   if (MODE != CONV_BWD_WEIGHT)
     v1 = a.RS == 1 && g.stride_h == 1 && g.stride_w == 1 && g.pad_h == 0 &&
@@ -808,7 +817,18 @@ int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
 
 int sa_conv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
                      const void *w, void *dx, hipStream_t s) {
+  return sa_conv_bwd_data_acc(dtype, g, dy, w, nullptr, dx, s);
+}
+
+// dx = addend + conv_bwd_data(dy, w); addend (of dx's shape, distinct from dx)
+// may be null.  While dx is still unwritten the kernels read the addend
+// themselves; once dx has been initialised from it (classes no tap reaches,
+// or partial sums combined with atomics) later launches add onto dx in place.
+int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
+                         const void *w, const void *addend, void *dx,
+                         hipStream_t s) {
   if (!geom_ok(g)) return -2;
+  if (addend == dx) return -2;
   ConvArgs base = make_args(*g, CONV_BWD_DATA);
   base.a = w; base.b = dy; base.out = dx;
   base.a_elems = (int64_t)g->K * base.Cg * base.RS;
@@ -847,9 +867,12 @@ int sa_conv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
       c.div_wc = FastDiv(c.Wc);
       classes.push_back(c);
     }
-  bool zeroed = false;
+  bool zeroed = false;  // dx holds its starting value (zero or the addend)
   if (untouched || classes.empty()) {
-    (void)hipMemsetAsync(dx, 0, bytes, s);
+    if (addend)
+      (void)hipMemcpyAsync(dx, addend, bytes, hipMemcpyDeviceToDevice, s);
+    else
+      (void)hipMemsetAsync(dx, 0, bytes, s);
     zeroed = true;
   }
   for (size_t first = 0; first < classes.size(); first += 4) {
@@ -865,6 +888,7 @@ int sa_conv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
     // launch may clear the output for split accumulation
     const size_t clear = (zeroed || first > 0) ? 0 : bytes;
     const bool may_split = zeroed || first == 0;
+    a.addend = !addend ? nullptr : (zeroed ? (const void *)dx : addend);
     SA_DISPATCH_FLOAT(dtype, T, {
       launch_conv<T, CONV_BWD_DATA>(a, clear, s, may_split);
     });

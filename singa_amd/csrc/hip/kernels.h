@@ -116,6 +116,11 @@ int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                 const void *bias, void *y, hipStream_t s);
 int sa_conv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
                      const void *w, void *dx, hipStream_t s);
+// dx = addend + backward-data; addend has dx's shape and dtype, is a buffer
+// other than dx, or null
+int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
+                         const void *w, const void *addend, void *dx,
+                         hipStream_t s);
 // dw must be zero-filled by the launcher (it does so itself)
 int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
                        const void *x, void *dw, hipStream_t s);

@@ -757,7 +757,7 @@ class SingaFrontend(object):
                 raise ValueError(
                     "graph input %s is not among the given inputs" % name)
         g_out = [helper.make_tensor_value_info(
-            yy.creator.output_name(yy.creator.y_id2idx[id(yy)]),
+            yy.creator.output_name(yy.creator.y_id2idx[yy.uid]),
             _singa_dtype_to_onnx(yy.dtype), list(yy.shape)) for yy in ys]
         return helper.make_graph(nodes, model_name, g_in, g_out, initializers)
 

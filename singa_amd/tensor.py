@@ -10,6 +10,8 @@ tensor with that axis removed; ``PlaceHolder`` is an alias of ``Tensor``.
 import re
 from functools import reduce
 
+import itertools
+
 import numpy as np
 
 from . import singa_wrap as singa
@@ -26,6 +28,18 @@ _NP2DTYPE = {np.float32: float32, np.float64: float32, np.float16: float16,
 
 class Tensor(object):
     tensor_count = 0
+    _serial = itertools.count(1)
+
+    @property
+    def uid(self):
+        """Process-wide serial number of this tensor object.  The autograd
+        graph identifies tensors by it: unlike ``id()`` it is never handed to
+        a second tensor after the first one has been garbage-collected, which
+        would merge the consumer counts of two unrelated tensors."""
+        u = self.__dict__.get("_uid")
+        if u is None:
+            u = self.__dict__["_uid"] = next(Tensor._serial)
+        return u
 
     def __init__(self, shape=(), device=None, dtype=None, data=None,
                  requires_grad=True, stores_grad=False, creator=None,

@@ -115,3 +115,84 @@ def test_multi_tensor_sgd_matches_per_tensor(dev, momentum, nesterov):
 
     for a, b in zip(run(True), run(False)):
         np.testing.assert_allclose(a, b, rtol=1e-6, atol=1e-6)
+
+
+def _run_fork(dev, fold):
+    from singa_amd import autograd, layer, tensor
+    import numpy as np
+    autograd.training = True
+    saved = autograd._Conv2d.__init__
+    if not fold:
+        def no_fold(self, handle, odd_padding=(0, 0, 0, 0)):
+            saved(self, handle, odd_padding)
+            self.fuses_dx_addend = False
+        autograd._Conv2d.__init__ = no_fold
+    try:
+        rng = np.random.RandomState(3)
+        x = tensor.from_numpy(rng.randn(2, 4, 9, 9).astype(np.float32), dev)
+        x.requires_grad = True
+        x.stores_grad = True
+        dev.SetRandSeed(11)
+        c_in = layer.Conv2d(8, 3, padding=1, bias=False)
+        c_a = layer.Conv2d(8, 3, padding=1, stride=1, bias=False)
+        c_b = layer.Conv2d(8, 1, bias=True)
+        c_s = layer.Conv2d(8, 3, padding=1, stride=2, bias=False)
+        x0 = c_in(x)
+        y = autograd.add(autograd.add(c_a(x0), c_b(x0)), x0)
+        z = c_s(x0)
+        t = tensor.from_numpy(rng.randn(*y.shape).astype(np.float32), dev)
+        tz = tensor.from_numpy(rng.randn(*z.shape).astype(np.float32), dev)
+        loss = autograd.add(autograd.mse_loss(y, t), autograd.mse_loss(z, tz))
+        return [tensor.to_numpy(g) for _, g in autograd.backward(loss)]
+    finally:
+        autograd._Conv2d.__init__ = saved
+
+
+def _check_fold(dev, tol):
+    import numpy as np
+    a = _run_fork(dev, True)
+    b = _run_fork(dev, False)
+    assert len(a) == len(b) and len(a) >= 5
+    for u, v in zip(a, b):
+        np.testing.assert_allclose(u, v, rtol=tol, atol=tol)
+
+
+def test_conv_backward_folds_fork_gradient_cpu():
+    from singa_amd import device
+    _check_fold(device.get_default_device(), 1e-5)
+
+
+@pytest.mark.gpu
+def test_conv_backward_folds_fork_gradient_gpu():
+    from singa_amd import device
+    _check_fold(device.create_cuda_gpu(), 1e-4)
+
+
+@pytest.mark.gpu
+def test_conv_bwd_data_acc_kernel_matches_reference():
+    """Every launch plan of the accumulate path: direct epilogue add, split
+    reduction seeded from the addend, strided classes, untouched classes."""
+    import torch
+    from singa_amd import device
+    dev = device.create_cuda_gpu()
+    m = dev.math
+    cases = [  # N, C, H, W, K, R, stride, pad
+        (4, 64, 56, 56, 64, 1, 1, 0),     # many tiles, no split
+        (2, 512, 7, 7, 512, 3, 1, 1),     # few tiles: split reduction
+        (2, 32, 28, 28, 64, 3, 2, 1),     # stride classes
+        (2, 16, 16, 16, 32, 1, 2, 0),     # classes no tap reaches
+        (2, 8, 15, 15, 8, 3, 3, 1),       # nine classes, two launches
+    ]
+    for (N, C, H, W, K, R, st, pd) in cases:
+        P = (H + 2 * pd - R) // st + 1
+        dy = torch.randn(N, K, P, P, device="cuda")
+        w = torch.randn(K, C, R, R, device="cuda") * 0.1
+        add = torch.randn(N, C, H, W, device="cuda")
+        dx = torch.full((N, C, H, W), float("nan"), device="cuda")
+        m.conv_bwd_data(dy, w, dx, (st, st), (pd, pd), 1, add)
+        ref = torch.nn.grad.conv2d_input((N, C, H, W), w.double().cpu(),
+                                         dy.double().cpu(), stride=st,
+                                         padding=pd) + add.double().cpu()
+        err = (dx.double().cpu() - ref).abs().max().item()
+        assert err < 2e-3 * max(1.0, ref.abs().max().item()), \
+            ((N, C, H, W, K, R, st, pd), err)

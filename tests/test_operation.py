@@ -377,3 +377,31 @@ def test_ranking_loss(dev):
           lambda p, n: np.asarray(np.mean(np.maximum(0.2 - p + n, 0))).reshape(
               tensor.to_numpy(autograd.ranking_loss(
                   to_t(pos, dev), to_t(neg, dev), 0.2)).shape), [pos, neg])
+
+
+def test_graph_keys_survive_garbage_collection():
+    """Tensors are keyed in the autograd graph by a serial number, so a
+    temporary that is collected during the forward pass cannot lend its
+    identity to a parameter created afterwards (every parameter must get
+    its gradient)."""
+    import gc
+    from singa_amd import layer
+    autograd.training = True
+    seen = set()
+    for _ in range(50):
+        t = tensor.Tensor((1,))
+        assert t.uid not in seen
+        seen.add(t.uid)
+        del t
+        gc.collect()
+    x = tensor.from_numpy(np.random.randn(2, 4, 9, 9).astype(np.float32))
+    c_in = layer.Conv2d(8, 3, padding=1, bias=False)
+    c_a = layer.Conv2d(8, 3, padding=1, bias=False)
+    c_b = layer.Conv2d(8, 1, bias=True)
+    c_s = layer.Conv2d(8, 3, padding=1, stride=2, bias=False)
+    x0 = c_in(x)
+    y = autograd.add(autograd.add(c_a(x0), c_b(x0)), x0)
+    z = c_s(x0)
+    loss = autograd.add(autograd.mse_loss(y, tensor.Tensor(y.shape)),
+                        autograd.mse_loss(z, tensor.Tensor(z.shape)))
+    assert len(list(autograd.backward(loss))) == 5

@@ -427,9 +427,26 @@ class HipMath(object):
             self._conv_plans[(mode,) + key] = plan
         g.tile, g.split_target = plan
 
+    def _split_scratch(self, g, out, rows, cols, groups):
+        """16-bit outputs: lend the launcher a float buffer of the output's
+        size when the launch is small enough for a split reduction to pay
+        (fewer 64 x 64 tiles than the largest split target).  The returned
+        tensor must stay referenced until the launch has been issued."""
+        if out.dtype == torch.float32:
+            return None
+        tiles = -(-rows // 64) * -(-cols // 64) * groups
+        if tiles >= 2048:
+            return None
+        buf = torch.empty(out.numel(), dtype=torch.float32, device=out.device)
+        g.set_scratch(buf.data_ptr(), buf.numel())
+        return buf
+
     def conv_fwd(self, x, w, b, y, stride, pad, groups):
         g = self._geom(x.shape, w.shape, y.shape, stride, pad, groups)
         w = self._contig(w)
+        scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)
+            g, y, w.shape[0] // groups, y.shape[0] * y.shape[2] * y.shape[3],
+            groups)
         args = (x.data_ptr(), w.data_ptr(),
                 b.data_ptr() if b is not None else 0, y.data_ptr())
         code = _code(x)
@@ -445,6 +462,9 @@ class HipMath(object):
         epilogue instead of in a separate pass over dx."""
         g = self._geom(dx.shape, w.shape, dy.shape, stride, pad, groups)
         w = self._contig(w)
+        scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)
+            g, dx, dx.shape[1] // groups,
+            dx.shape[0] * dx.shape[2] * dx.shape[3], groups)
         args = (dy.data_ptr(), w.data_ptr(), dx.data_ptr())
         code = _code(dx)
         key = (tuple(dx.shape), tuple(w.shape), tuple(stride), tuple(pad),
@@ -465,16 +485,16 @@ class HipMath(object):
         g = self._geom(x.shape, dw.shape, dy.shape, stride, pad, groups)
         key = (tuple(x.shape), tuple(dw.shape), tuple(stride), tuple(pad),
                groups, _code(x))
-        if dw.dtype == torch.float32:
-            args = (dy.data_ptr(), x.data_ptr(), dw.data_ptr())
-        else:
-            acc = torch.empty(dw.shape, dtype=torch.float32, device=dw.device)
-            dyf, xf = self._f32c(dy), self._f32c(x)
-            args = (dyf.data_ptr(), xf.data_ptr(), acc.data_ptr())
+        code = _code(x)
+        assert dy.dtype == x.dtype
+        # the kernel reads dy / x in their own type and always writes floats
+        acc = dw if dw.dtype == torch.float32 else torch.empty(
+            dw.shape, dtype=torch.float32, device=dw.device)
+        args = (dy.data_ptr(), x.data_ptr(), acc.data_ptr())
         self._tuned(2, g, key,
-                    lambda gg: self.k.conv_bwd_weight(0, gg, *args,
+                    lambda gg: self.k.conv_bwd_weight(code, gg, *args,
                                                       self._s()))
-        self.k.conv_bwd_weight(0, g, *args, self._s())
+        self.k.conv_bwd_weight(code, g, *args, self._s())
         if dw.dtype != torch.float32:
             self.copy(acc, dw)
 

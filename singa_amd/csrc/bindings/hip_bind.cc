@@ -180,7 +180,11 @@ PYBIND11_MODULE(_hip, m) {
       }))
       .def_readwrite("N", &ConvGeom::N)
       .def_readwrite("tile", &ConvGeom::tile)
-      .def_readwrite("split_target", &ConvGeom::split_target);
+      .def_readwrite("split_target", &ConvGeom::split_target)
+      .def("set_scratch", [](ConvGeom &g, uintptr_t p, int64_t elems) {
+        g.scratch = reinterpret_cast<float *>(p);
+        g.scratch_elems = elems;
+      });
   m.def("conv_fwd", [](int dt, const ConvGeom &g, uintptr_t x, uintptr_t w,
                        uintptr_t bias, uintptr_t y, uintptr_t s) {
     check(sa_conv_fwd(dt, &g, CP(x), CP(w), CP(bias), P(y), S(s)), "conv_fwd");

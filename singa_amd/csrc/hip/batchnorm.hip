@@ -45,10 +45,37 @@ static inline int bn_splits(int N, int C) {
   return s;
 }
 
+// Four consecutive elements as floats: one 16-byte access for float tensors,
+// one 8-byte access for the 16-bit types.
+template <typename T> struct V4 {
+  static __device__ __forceinline__ float4 ld(const T *p, int i) {
+    const uint2 w = reinterpret_cast<const uint2 *>(p)[i];
+    T e[4];
+    __builtin_memcpy(e, &w, 8);
+    return make_float4(to_f<T>(e[0]), to_f<T>(e[1]), to_f<T>(e[2]),
+                       to_f<T>(e[3]));
+  }
+  static __device__ __forceinline__ void st(T *p, int i, float4 v) {
+    T e[4] = {from_f<T>(v.x), from_f<T>(v.y), from_f<T>(v.z), from_f<T>(v.w)};
+    uint2 w;
+    __builtin_memcpy(&w, e, 8);
+    reinterpret_cast<uint2 *>(p)[i] = w;
+  }
+};
+template <> struct V4<float> {
+  static __device__ __forceinline__ float4 ld(const float *p, int i) {
+    return reinterpret_cast<const float4 *>(p)[i];
+  }
+  static __device__ __forceinline__ void st(float *p, int i, float4 v) {
+    reinterpret_cast<float4 *>(p)[i] = v;
+  }
+};
+
 // work layout: [C][S][2]
 //
-// VEC = 4 variants move float4 per lane (rows of HW floats are 16-byte aligned
-// when HW % 4 == 0); VEC = 1 is the general path.  ACT: 0 none, 1 ReLU,
+// VEC = 4 variants move four elements per lane and access (channel rows are
+// 16-byte aligned for float / 8-byte aligned for 16-bit types when
+// HW % 4 == 0); VEC = 1 is the general path.  ACT: 0 none, 1 ReLU,
 // 2 add a residual tensor then ReLU (the tail of a ResNet bottleneck).
 template <typename T, int VEC>
 __global__ void bn_stats_kernel(const T *__restrict__ x,
@@ -61,9 +88,8 @@ __global__ void bn_stats_kernel(const T *__restrict__ x,
   for (int n = s; n < N; n += S) {
     const T *p = x + ((size_t)n * C + c) * HW;
     if constexpr (VEC == 4) {
-      const float4 *p4 = reinterpret_cast<const float4 *>(p);
       for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
-        const float4 v = p4[i];
+        const float4 v = V4<T>::ld(p, i);
         const float a = v.x - shift, b = v.y - shift, cc = v.z - shift,
                     d = v.w - shift;
         sum += (a + b) + (cc + d);
@@ -125,19 +151,16 @@ __global__ void bn_apply_train_kernel(
   for (int n = s; n < N; n += S) {
     const size_t off = ((size_t)n * C + c) * HW;
     if constexpr (VEC == 4) {
-      const float4 *p4 = reinterpret_cast<const float4 *>(x + off);
-      const float4 *r4 = reinterpret_cast<const float4 *>(res + off);
-      float4 *q4 = reinterpret_cast<float4 *>(y + off);
       for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
-        const float4 v = p4[i];
+        const float4 v = V4<T>::ld(x + off, i);
         float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ACT == 2) r = r4[i];
+        if (ACT == 2) r = V4<T>::ld(res + off, i);
         float4 o;
         o.x = bn_act<ACT>(fmaf(v.x, g, b), r.x);
         o.y = bn_act<ACT>(fmaf(v.y, g, b), r.y);
         o.z = bn_act<ACT>(fmaf(v.z, g, b), r.z);
         o.w = bn_act<ACT>(fmaf(v.w, g, b), r.w);
-        q4[i] = o;
+        V4<T>::st(y + off, i, o);
       }
     } else {
       for (int i = threadIdx.x; i < HW; i += blockDim.x) {
@@ -203,13 +226,10 @@ __global__ void bn_bwd_stats_kernel(const T *__restrict__ dy,
   for (int n = s; n < N; n += S) {
     const size_t off = ((size_t)n * C + c) * HW;
     if constexpr (VEC == 4) {
-      const float4 *d4 = reinterpret_cast<const float4 *>(dy + off);
-      const float4 *x4 = reinterpret_cast<const float4 *>(x + off);
-      const float4 *y4 = reinterpret_cast<const float4 *>(y + off);
       for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
-        const float4 d = d4[i], xv = x4[i];
+        const float4 d = V4<T>::ld(dy + off, i), xv = V4<T>::ld(x + off, i);
         float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ACT == 2) yv = y4[i];
+        if (ACT == 2) yv = V4<T>::ld(y + off, i);
         const float d0 = bn_mask<ACT>(d.x, xv.x, g, b, yv.x);
         const float d1 = bn_mask<ACT>(d.y, xv.y, g, b, yv.y);
         const float d2 = bn_mask<ACT>(d.z, xv.z, g, b, yv.z);
@@ -265,15 +285,10 @@ __global__ void bn_bwd_apply_kernel(
   for (int n = s; n < N; n += S) {
     const size_t off = ((size_t)n * C + c) * HW;
     if constexpr (VEC == 4) {
-      const float4 *d4 = reinterpret_cast<const float4 *>(dy + off);
-      const float4 *x4 = reinterpret_cast<const float4 *>(x + off);
-      const float4 *y4 = reinterpret_cast<const float4 *>(y + off);
-      float4 *o4 = reinterpret_cast<float4 *>(dx + off);
-      float4 *r4 = reinterpret_cast<float4 *>(dres + off);
       for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
-        const float4 d = d4[i], xv = x4[i];
+        const float4 d = V4<T>::ld(dy + off, i), xv = V4<T>::ld(x + off, i);
         float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ACT == 2) yv = y4[i];
+        if (ACT == 2) yv = V4<T>::ld(y + off, i);
         float4 dm, o;
         dm.x = bn_mask<ACT>(d.x, xv.x, g, b, yv.x);
         dm.y = bn_mask<ACT>(d.y, xv.y, g, b, yv.y);
@@ -283,8 +298,8 @@ __global__ void bn_bwd_apply_kernel(
         o.y = g * (dm.y - k1 - (xv.y - m) * k2);
         o.z = g * (dm.z - k1 - (xv.z - m) * k2);
         o.w = g * (dm.w - k1 - (xv.w - m) * k2);
-        o4[i] = o;
-        if (ACT == 2) r4[i] = dm;
+        V4<T>::st(dx + off, i, o);
+        if (ACT == 2) V4<T>::st(dres + off, i, dm);
       }
     } else {
       for (int i = threadIdx.x; i < HW; i += blockDim.x) {
@@ -308,14 +323,14 @@ int64_t sa_bn_workspace(int N, int C, int HW) {
 
 static inline int bn_block(int HW) { return HW >= 256 ? 256 : (HW > 64 ? 128 : 64); }
 
-// float tensors whose channel rows are 16-byte aligned take the float4 path
+// tensors whose channel rows are aligned to four elements take the VEC 4 path
 static inline bool bn_vec4(int dtype, int HW, const void *a, const void *b,
                            const void *c, const void *d) {
   uintptr_t bits = reinterpret_cast<uintptr_t>(a) |
                    reinterpret_cast<uintptr_t>(b) |
                    reinterpret_cast<uintptr_t>(c) |
                    reinterpret_cast<uintptr_t>(d);
-  return dtype == kF32 && HW % 4 == 0 && (bits & 15) == 0;
+  return HW % 4 == 0 && (bits & (dtype == kF32 ? 15 : 7)) == 0;
 }
 
 #define BN_ACT_SWITCH(act, ...)                         \
@@ -336,13 +351,15 @@ int sa_bn_fwd_train_act(int dtype, const void *x, const float *scale,
   const int S = bn_splits(N, C);
   if (bn_vec4(dtype, HW, x, y, residual, nullptr)) {
     const dim3 grid(C, S), block(bn_block(HW / 4));
-    hipLaunchKernelGGL((bn_stats_kernel<float, 4>), grid, block, 0, s,
-                       (const float *)x, work, N, C, HW, S);
-    BN_ACT_SWITCH(act, {
-      hipLaunchKernelGGL((bn_apply_train_kernel<float, 4, ACT>), grid, block,
-                         0, s, (const float *)x, scale, bias, rmean, rvar,
-                         factor, eps, (float *)y, mean, invstd, work,
-                         (const float *)residual, N, C, HW, S);
+    SA_DISPATCH_FLOAT(dtype, T, {
+      hipLaunchKernelGGL((bn_stats_kernel<T, 4>), grid, block, 0, s,
+                         (const T *)x, work, N, C, HW, S);
+      BN_ACT_SWITCH(act, {
+        hipLaunchKernelGGL((bn_apply_train_kernel<T, 4, ACT>), grid, block, 0,
+                           s, (const T *)x, scale, bias, rmean, rvar, factor,
+                           eps, (T *)y, mean, invstd, work,
+                           (const T *)residual, N, C, HW, S);
+      });
     });
     return 0;
   }
@@ -404,16 +421,16 @@ int sa_bn_bwd_act(int dtype, const void *dy, const void *x, const void *y,
   if (bn_vec4(dtype, HW, dy, x, dx, act == 2 ? y : nullptr) &&
       (reinterpret_cast<uintptr_t>(dres) & 15) == 0) {
     const dim3 grid(C, S), block(bn_block(HW / 4));
-    BN_ACT_SWITCH(act, {
-      hipLaunchKernelGGL((bn_bwd_stats_kernel<float, 4, ACT>), grid, block, 0,
-                         s, (const float *)dy, (const float *)x,
-                         (const float *)y, scale, bias, mean, invstd, work, N,
-                         C, HW, S);
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<float, 4, ACT>), grid, block, 0,
-                         s, (const float *)dy, (const float *)x,
-                         (const float *)y, scale, bias, mean, invstd,
-                         (float *)dx, (float *)dres, dscale, dbias, work, N, C,
-                         HW, S);
+    SA_DISPATCH_FLOAT(dtype, T, {
+      BN_ACT_SWITCH(act, {
+        hipLaunchKernelGGL((bn_bwd_stats_kernel<T, 4, ACT>), grid, block, 0, s,
+                           (const T *)dy, (const T *)x, (const T *)y, scale,
+                           bias, mean, invstd, work, N, C, HW, S);
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4, ACT>), grid, block, 0, s,
+                           (const T *)dy, (const T *)x, (const T *)y, scale,
+                           bias, mean, invstd, (T *)dx, (T *)dres, dscale,
+                           dbias, work, N, C, HW, S);
+      });
     });
     return 0;
   }

@@ -145,6 +145,50 @@ template <> struct BufLd<__hip_bfloat16> {
   }
 };
 
+// 16-bit element types: a lane's fragment of the 32x32x16 MFMA is eight
+// consecutive reduction indices of one row.  LDS tiles hold floats converted
+// from the 16-bit inputs, so narrowing them back is exact.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Frag16;
+template <> struct Frag16<__half> {
+  using V = h16x8;
+  static __device__ __forceinline__ unsigned two(float lo, float hi) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+  }
+  static __device__ __forceinline__ f32x16 mma(V a, V b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Frag16<__hip_bfloat16> {
+  using V = b16x8;
+  static __device__ __forceinline__ unsigned two(float lo, float hi) {
+    return (__builtin_bit_cast(unsigned, lo) >> 16) |
+           (__builtin_bit_cast(unsigned, hi) & 0xffff0000u);
+  }
+  static __device__ __forceinline__ f32x16 mma(V a, V b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Frag16<float> {  // never instantiated for MFMA
+  using V = u32x4;
+  static __device__ __forceinline__ unsigned two(float, float) { return 0; }
+  static __device__ __forceinline__ f32x16 mma(V, V, f32x16 c) { return c; }
+};
+
+// eight floats at p[0], p[ld], ..., p[7 * ld] -> one packed fragment
+template <typename T>
+__device__ __forceinline__ typename Frag16<T>::V frag16(const float *p, int ld) {
+  u32x4 w;
+  w.x = Frag16<T>::two(p[0], p[ld]);
+  w.y = Frag16<T>::two(p[2 * ld], p[3 * ld]);
+  w.z = Frag16<T>::two(p[4 * ld], p[5 * ld]);
+  w.w = Frag16<T>::two(p[6 * ld], p[7 * ld]);
+  return __builtin_bit_cast(typename Frag16<T>::V, w);
+}
+
 // V1: both operands are plain matrices (1x1 filter, stride 1, no padding,
 // H*W and the channel count multiples of 4): tiles are staged with 4-wide
 // loads and no per-element index arithmetic.
@@ -551,21 +595,43 @@ conv_igemm_kernel(ConvArgs a) {
   for (int t = 0; t < nt; ++t) {
     const float *as = As[t & 1], *bs = Bs[t & 1];
     if (t + 1 < nt) load_tiles(kbeg + (t + 1) * BK);
+    if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
-    for (int ks = 0; ks < BK; ks += 2) {
-      float av[TM], bv[TN];
+      for (int ks = 0; ks < BK; ks += 2) {
+        float av[TM], bv[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        av[i] = as[(ks + lk) * LDA + wm * WM + 32 * i + lrow];
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        bv[j] = bs[(ks + lk) * LDB + wn * WN + 32 * j + lrow];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
+          av[i] = as[(ks + lk) * LDA + wm * WM + 32 * i + lrow];
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j],
-                                                           acc[i][j], 0, 0, 0);
+          bv[j] = bs[(ks + lk) * LDB + wn * WN + 32 * j + lrow];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+      // 16-bit inputs: 32x32x16 MFMA, lane (row, half) holds reduction
+      // indices 8 * half .. 8 * half + 7 of its row
+#pragma unroll
+      for (int ks = 0; ks < BK; ks += 16) {
+        typename Frag16<T>::V av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          av[i] = frag16<T>(
+              &as[(ks + 8 * lk) * LDA + wm * WM + 32 * i + lrow], LDA);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          bv[j] = frag16<T>(
+              &bs[(ks + 8 * lk) * LDB + wn * WN + 32 * j + lrow], LDB);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = Frag16<T>::mma(av[i], bv[j], acc[i][j]);
+      }
     }
     if (t + 1 < nt) store_tiles((t + 1) & 1);
     __syncthreads();
@@ -609,19 +675,19 @@ conv_igemm_kernel(ConvArgs a) {
           const int ch = grp * a.Kg + row;
           const float bv = (a.bias && split == 0)
                                ? to_f<T>(((const T *)a.bias)[ch]) : 0.f;
-          T *dst = (T *)a.out + col_off + (size_t)ch * chan_stride;
-          if (a.splits == 1) *dst = from_f<T>(v + bv);
-          else atomicAdd((float *)dst, v + bv);  // float outputs only
+          const size_t off = col_off + (size_t)ch * chan_stride;
+          // split reductions accumulate in a float buffer whatever T is
+          if (a.splits == 1) ((T *)a.out)[off] = from_f<T>(v + bv);
+          else atomicAdd((float *)a.out + off, v + bv);
         } else if (MODE == CONV_BWD_DATA) {
           const int ch = grp * a.Cg + row;
           const size_t off = col_off + (size_t)ch * chan_stride;
-          T *dst = (T *)a.out + off;
           if (a.splits == 1) {
             const float add =
                 a.addend ? to_f<T>(((const T *)a.addend)[off]) : 0.f;
-            *dst = from_f<T>(v + add);
+            ((T *)a.out)[off] = from_f<T>(v + add);
           } else {
-            atomicAdd((float *)dst, v);
+            atomicAdd((float *)a.out + off, v);
           }
         } else {
           float *dst = (float *)a.out +
@@ -633,14 +699,15 @@ conv_igemm_kernel(ConvArgs a) {
   }
 }
 
-// dW accumulated in float -> parameter dtype
+// split partial sums combined in float (+ addend) -> output dtype
 template <typename T>
 __global__ void cast_out_kernel(const float *__restrict__ in,
+                                const T *__restrict__ addend,
                                 T *__restrict__ out, int64_t n) {
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += step)
-    out[i] = from_f<T>(in[i]);
+    out[i] = from_f<T>(in[i] + (addend ? to_f<T>(addend[i]) : 0.f));
 }
 
 // db[k] = sum_{n, pq} dy[n, k, pq]: one block per channel
@@ -745,24 +812,36 @@ void launch_tile(ConvArgs &a, hipStream_t s) {
                      dim3(256), 0, s, a);
 }
 
-// a.Ngemm / a.Kgemm hold the largest per-class extents for backward-data
+// a.Ngemm / a.Kgemm hold the largest per-class extents for backward-data.
+// out_elems: size of the output tensor; clear: this launch may initialise the
+// whole output (to zero or to the addend) when it splits its reduction.
 template <typename T, int MODE>
-void launch_conv(ConvArgs &a, size_t out_bytes, hipStream_t s,
+void launch_conv(ConvArgs &a, int64_t out_elems, bool clear, hipStream_t s,
                  bool may_split = true) {
   const ConvGeom &g = a.g;
   const bool big = use_big_tile(a);
   const int tb = big ? 128 : 64;
   const int64_t tiles = (int64_t)((a.M + tb - 1) / tb) *
                         ((a.Ngemm + tb - 1) / tb) * g.groups * a.ncls;
-  if (may_split && (std::is_same<T, float>::value || MODE == CONV_BWD_WEIGHT))
-    plan_splits(a, tiles, 256);
-  if (a.splits > 1 && out_bytes) {
+  // 16-bit outputs combine their partial sums in the caller's float scratch
+  constexpr bool kFloatOut =
+      std::is_same<T, float>::value || MODE == CONV_BWD_WEIGHT;
+  const bool via_scratch = !kFloatOut && clear && g.scratch != nullptr &&
+                           g.scratch_elems >= out_elems;
+  if (may_split && (kFloatOut || via_scratch)) plan_splits(a, tiles, 256);
+  void *const out = a.out;
+  const void *const addend = a.addend;
+  const bool staged = a.splits > 1 && !kFloatOut;
+  if (staged) {
+    a.out = g.scratch;
+    (void)hipMemsetAsync(g.scratch, 0, (size_t)out_elems * sizeof(float), s);
+  } else if (a.splits > 1 && clear) {
     // partial sums land with atomics: start from the addend, or from zero
+    const size_t bytes = (size_t)out_elems * sizeof(float);
     if (MODE == CONV_BWD_DATA && a.addend && a.addend != a.out)
-      (void)hipMemcpyAsync(a.out, a.addend, out_bytes, hipMemcpyDeviceToDevice,
-                           s);
+      (void)hipMemcpyAsync(a.out, a.addend, bytes, hipMemcpyDeviceToDevice, s);
     else
-      (void)hipMemsetAsync(a.out, 0, out_bytes, s);
+      (void)hipMemsetAsync(a.out, 0, bytes, s);
   }
   bool v1 = false;
   if (MODE != CONV_BWD_WEIGHT)
@@ -774,6 +853,12 @@ void launch_conv(ConvArgs &a, size_t out_bytes, hipStream_t s,
   } else {
     if (big) launch_tile<T, MODE, 128, 128, 16, false>(a, s);
     else launch_tile<T, MODE, 64, 64, 32, false>(a, s);
+  }
+  if (staged) {
+    hipLaunchKernelGGL((cast_out_kernel<T>), dim3(grid_for(out_elems, 256, 4)),
+                       dim3(256), 0, s, (const float *)g.scratch,
+                       (const T *)addend, (T *)out, out_elems);
+    a.out = out;
   }
 }
 
@@ -810,8 +895,8 @@ int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
   if (!window_ok((int64_t)g->C * a.HW, 128 / a.PQ + 2, a.a_elems,
                  elem_size(dtype)))
     return -2;
-  const size_t bytes = (size_t)g->N * g->K * g->P * g->Q * elem_size(dtype);
-  SA_DISPATCH_FLOAT(dtype, T, { launch_conv<T, CONV_FWD>(a, bytes, s); });
+  const int64_t elems = (int64_t)g->N * g->K * g->P * g->Q;
+  SA_DISPATCH_FLOAT(dtype, T, { launch_conv<T, CONV_FWD>(a, elems, true, s); });
   return 0;
 }
 
@@ -840,7 +925,8 @@ int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
                    elem_size(dtype)))
       return -2;
   }
-  const size_t bytes = (size_t)g->N * g->C * g->H * g->W * elem_size(dtype);
+  const int64_t elems = (int64_t)g->N * g->C * g->H * g->W;
+  const size_t bytes = (size_t)elems * elem_size(dtype);
   // one dense sub-problem per (h % sh, w % sw) class; classes no tap reaches
   // (filter smaller than the stride) stay zero
   std::vector<ConvArgs::Cls> classes;
@@ -886,11 +972,14 @@ int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
     }
     // an earlier batch may already have written its classes: only the first
     // launch may clear the output for split accumulation
-    const size_t clear = (zeroed || first > 0) ? 0 : bytes;
-    const bool may_split = zeroed || first == 0;
+    const bool clear = !(zeroed || first > 0);
+    // 16-bit outputs split only when one launch produces the whole tensor
+    const bool may_split =
+        dtype == kF32 ? (zeroed || first == 0)
+                      : (!zeroed && classes.size() <= 4);
     a.addend = !addend ? nullptr : (zeroed ? (const void *)dx : addend);
     SA_DISPATCH_FLOAT(dtype, T, {
-      launch_conv<T, CONV_BWD_DATA>(a, clear, s, may_split);
+      launch_conv<T, CONV_BWD_DATA>(a, elems, clear, s, may_split);
     });
     if (a.splits > 1) zeroed = true;
   }
@@ -900,16 +989,17 @@ int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
 int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
                        const void *x, void *dw, hipStream_t s) {
   if (!geom_ok(g)) return -2;
-  if (dtype != kF32) return -3;  // half types accumulate via a float buffer
   ConvArgs a = make_args(*g, CONV_BWD_WEIGHT);
   a.a = dy; a.b = x; a.out = dw;
   a.a_elems = (int64_t)g->N * g->K * a.PQ;
   a.b_elems = (int64_t)g->N * g->C * a.HW;
   if (!window_ok(std::max((int64_t)g->K * a.PQ, (int64_t)g->C * a.HW),
-                 32 / a.PQ + 2, 0, sizeof(float)))
+                 32 / a.PQ + 2, 0, elem_size(dtype)))
     return -2;
-  launch_conv<float, CONV_BWD_WEIGHT>(
-      a, (size_t)g->K * a.Cg * a.RS * sizeof(float), s);
+  const int64_t elems = (int64_t)g->K * a.Cg * a.RS;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    launch_conv<T, CONV_BWD_WEIGHT>(a, elems, true, s);
+  });
   return 0;
 }
 

@@ -111,6 +111,11 @@ struct ConvGeom {
   // the number of workgroups below which the reduction is split
   int tile = 0;
   int split_target = 0;
+  // optional float buffer of at least scratch_elems elements: lets a 16-bit
+  // forward / backward-data launch split its reduction (partial sums are
+  // combined in float there and rounded once into the output)
+  float *scratch = nullptr;
+  int64_t scratch_elems = 0;
 };
 int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                 const void *bias, void *y, hipStream_t s);
@@ -121,7 +126,8 @@ int sa_conv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
 int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
                          const void *w, const void *addend, void *dx,
                          hipStream_t s);
-// dw must be zero-filled by the launcher (it does so itself)
+// dtype is the type of dy and x; dw is always a float buffer (zero-filled by
+// the launcher itself when the reduction is split)
 int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
                        const void *x, void *dw, hipStream_t s);
 int sa_conv_bwd_bias(int dtype, const void *dy, void *db, int N, int K,

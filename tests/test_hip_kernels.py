@@ -348,6 +348,49 @@ def test_conv_all_passes(maths, case):
                                rtol=1e-4)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_all_passes_16bit(maths, case, dt):
+    """16-bit inputs run on the 32x32x16 MFMA path (float accumulation, split
+    reductions staged through a float scratch); the reference is the fp32
+    result on the same rounded inputs, so only the final rounding differs."""
+    hm, cm, dev = maths
+    N, C, H, W, K, R, S, st, pd, grp = case
+    x = rnd(N, C, H, W, seed=30).to(dt)
+    w = rnd(K, C // grp, R, S, seed=31).to(dt)
+    b = rnd(K, seed=32).to(dt)
+    P = (H + 2 * pd - R) // st + 1
+    Q = (W + 2 * pd - S) // st + 1
+    eps = 2 ** -10 if dt == torch.float16 else 2 ** -7
+
+    def close(got, ref):
+        ref = ref.numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got.float().cpu().numpy(), ref,
+                                   atol=eps * scale, rtol=2 * eps)
+
+    ry = torch.empty(N, K, P, Q)
+    cm.conv_fwd(x.float(), w.float(), b.float(), ry, (st, st), (pd, pd), grp)
+    y = torch.empty(N, K, P, Q, device=dev.torch_device, dtype=dt)
+    hm.conv_fwd(g(x, dev), g(w, dev), g(b, dev), y, (st, st), (pd, pd), grp)
+    close(y, ry)
+    dy = rnd(N, K, P, Q, seed=33).to(dt)
+    add = rnd(N, C, H, W, seed=34).to(dt)
+    rdx = torch.empty(N, C, H, W)
+    cm.conv_bwd_data(dy.float(), w.float(), rdx, (st, st), (pd, pd), grp)
+    dx = torch.empty_like(x, device=dev.torch_device)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (st, st), (pd, pd), grp)
+    close(dx, rdx)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (st, st), (pd, pd), grp,
+                     g(add, dev))
+    close(dx, rdx + add.float())
+    rdw = torch.empty(K, C // grp, R, S)
+    cm.conv_bwd_weight(dy.float(), x.float(), rdw, (st, st), (pd, pd), grp)
+    dw = torch.empty_like(w, device=dev.torch_device)
+    hm.conv_bwd_weight(g(dy, dev), g(x, dev), dw, (st, st), (pd, pd), grp)
+    close(dw, rdw)
+
+
 @pytest.mark.parametrize("shape", [(8, 16, 14, 14), (32, 64, 7, 7), (16, 10),
                                    (4, 3, 33, 17)])
 def test_batchnorm(maths, shape):
@@ -389,6 +432,42 @@ def test_batchnorm(maths, shape):
                     g(rv, dev), 1e-5, iy)
     np.testing.assert_allclose(iy.cpu().numpy(), riy.numpy(), atol=2e-5,
                                rtol=1e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(8, 16, 14, 14), (4, 3, 33, 17)])
+def test_batchnorm_16bit(maths, shape, dt):
+    """16-bit activations, float parameters and statistics; (8, 16, 14, 14)
+    takes the four-elements-per-access path, (4, 3, 33, 17) the scalar one."""
+    hm, cm, dev = maths
+    C = shape[1]
+    d = dev.torch_device
+    eps = 2 ** -9 if dt == torch.float16 else 2 ** -6
+    x = rnd(*shape, seed=40, lo=-2, hi=5).to(dt)
+    scale, bias = rnd(C, seed=41, lo=0.5, hi=1.5), rnd(C, seed=42)
+    rm, rv = rnd(C, seed=43), rnd(C, seed=44, lo=0.5, hi=2.0)
+    ry, rmean, ristd = torch.empty(shape), torch.empty(C), torch.empty(C)
+    cm.bn_fwd_train(x.float(), scale, bias, rm.clone(), rv.clone(), 0.1, 1e-5,
+                    ry, rmean, ristd)
+    y = torch.empty(shape, device=d, dtype=dt)
+    mean, istd = torch.empty(C, device=d), torch.empty(C, device=d)
+    hm.bn_fwd_train(g(x, dev), g(scale, dev), g(bias, dev), g(rm, dev),
+                    g(rv, dev), 0.1, 1e-5, y, mean, istd)
+    np.testing.assert_allclose(y.float().cpu().numpy(), ry.numpy(),
+                               atol=4 * eps, rtol=2 * eps)
+    np.testing.assert_allclose(mean.cpu().numpy(), rmean.numpy(), atol=1e-4)
+    dy = rnd(*shape, seed=45).to(dt)
+    rdx, rds, rdb = torch.empty(shape), torch.empty(C), torch.empty(C)
+    cm.bn_bwd(dy.float(), x.float(), scale, rmean, ristd, rdx, rds, rdb)
+    dx = torch.empty(shape, device=d, dtype=dt)
+    ds, db = torch.empty(C, device=d), torch.empty(C, device=d)
+    hm.bn_bwd(g(dy, dev), g(x, dev), g(scale, dev), mean, istd, dx, ds, db)
+    np.testing.assert_allclose(dx.float().cpu().numpy(), rdx.numpy(),
+                               atol=2 * eps, rtol=2 * eps)
+    np.testing.assert_allclose(ds.cpu().numpy(), rds.numpy(), atol=2e-2,
+                               rtol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), rdb.numpy(), atol=2e-2,
+                               rtol=1e-3)
 
 
 @pytest.mark.parametrize("k,s,p,is_max", [(3, 2, 1, True), (2, 2, 0, True),

@@ -65,6 +65,14 @@ def infer_dependency(op):
     return op_count, tensor_count
 
 
+def make_slice(arr, axis, i):
+    """Index list selecting position(s) ``i`` along ``axis`` of ``arr``
+    (reference python/singa/autograd.py:1631)."""
+    slc = [slice(None)] * arr.ndim
+    slc[axis] = i
+    return slc
+
+
 def gradients(y, dy=None):
     """Dictionary id(param) -> gradient for every tensor that stores grad."""
     grads = {}

@@ -49,6 +49,18 @@ create_hip_gpus = create_cuda_gpus
 create_hip_gpus_on = create_cuda_gpus_on
 
 
+def get_num_opencl_platforms():
+    """No OpenCL target exists in this build (reference
+    python/singa/device.py:44-51 asserts USE_OPENCL)."""
+    assert False, 'singa_amd is built for HIP devices only (USE_OPENCL is False).'
+    return 0
+
+
+def get_num_opencl_devices():
+    assert False, 'singa_amd is built for HIP devices only (USE_OPENCL is False).'
+    return 0
+
+
 def create_opencl_device():
     raise NotImplementedError("OpenCL devices are not part of the MI355X build")
 

@@ -661,14 +661,17 @@ class HipMath(object):
         return vals, idx, cnt
 
     def topk_abs(self, x, k):
-        """The k entries of largest magnitude.  Selection uses the tensor
-        library's radix select; gathering the signed values is ours."""
-        _, idx = torch.topk(x.abs(), k)
-        idx32 = idx.to(torch.int32)
+        """The k entries of largest magnitude (values with their sign, and
+        int32 positions), in no particular order: radix select on the device,
+        no host synchronisation."""
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        k = int(k)
         vals = self._tmp(k)
-        self.k.index_select(0, x.data_ptr(), idx32.data_ptr(), vals.data_ptr(),
-                            1, x.numel(), k, 1, self._s())
-        return vals, idx32
+        idx = self._tmp(k, torch.int32)
+        work = self._tmp(self.k.topk_abs_workspace(), torch.int32)
+        self.k.topk_abs(x.data_ptr(), x.numel(), k, vals.data_ptr(),
+                        idx.data_ptr(), work.data_ptr(), self._s())
+        return vals, idx
 
     def scatter_add_sparse(self, vals, idx, cnt, dense):
         self.k.scatter_add_sparse(vals.data_ptr(), idx.data_ptr(),

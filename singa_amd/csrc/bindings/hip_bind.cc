@@ -381,6 +381,13 @@ PYBIND11_MODULE(_hip, m) {
                                 (int *)P(idx), (int *)P(count), n, cap, S(s)),
           "sparsify_threshold");
   });
+  m.def("topk_abs_workspace", &sa_topk_abs_workspace);
+  m.def("topk_abs", [](uintptr_t x, int64_t n, int64_t k, uintptr_t vals,
+                       uintptr_t idx, uintptr_t work, uintptr_t s) {
+    check(sa_topk_abs((const float *)CP(x), n, k, (float *)P(vals),
+                      (int *)P(idx), (unsigned *)P(work), S(s)),
+          "topk_abs");
+  });
   m.def("scatter_add_sparse", [](uintptr_t vals, uintptr_t idx, uintptr_t count,
                                  int64_t max_count, uintptr_t dense, int64_t n,
                                  uintptr_t s) {

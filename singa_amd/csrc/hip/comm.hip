@@ -58,6 +58,80 @@ __global__ void sparsify_threshold_kernel(const float *__restrict__ x,
   }
 }
 
+// ---- top-k by magnitude: most-significant-digit radix select -------------------
+// The magnitude of a float, read as an unsigned integer, orders like the
+// magnitude itself.  Four passes over the data, one per byte from the top,
+// histogram the current byte of the elements that share the prefix found so
+// far; a one-thread scan of the 256 bins picks the bin holding the k-th
+// largest key and how many entries of that bin are still wanted.  After the
+// last pass the prefix is the k-th largest key T: a final pass emits every
+// element above T plus the first `ties` elements equal to T.  Everything stays
+// on the device (k is known to the host, the threshold never is).
+//
+// work: 4 * 256 histogram bins, then {prefix, remaining, n_above, n_ties}.
+constexpr int kTopkState = 4 * 256;
+
+__device__ __forceinline__ unsigned mag_key(float v) {
+  return __float_as_uint(v) & 0x7fffffffu;
+}
+
+__global__ void topk_hist_kernel(const float *__restrict__ x, int64_t n,
+                                 int pass, unsigned *__restrict__ work) {
+  __shared__ unsigned h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned prefix = work[kTopkState];
+  const int shift = 24 - 8 * pass;
+  const unsigned hi_mask = pass == 0 ? 0u : 0xffffffffu << (shift + 8);
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += step) {
+    const unsigned key = mag_key(x[i]);
+    if ((key & hi_mask) == prefix) atomicAdd(&h[(key >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&work[pass * 256 + threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void topk_scan_kernel(int pass, unsigned k,
+                                 unsigned *__restrict__ work) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const unsigned *h = work + pass * 256;
+  unsigned rem = pass == 0 ? k : work[kTopkState + 1];
+  int d = 255;
+  for (; d > 0; --d) {
+    if (h[d] >= rem) break;
+    rem -= h[d];
+  }
+  work[kTopkState] |= (unsigned)d << (24 - 8 * pass);
+  work[kTopkState + 1] = rem;
+}
+
+__global__ void topk_select_kernel(const float *__restrict__ x, int64_t n,
+                                   unsigned k, float *__restrict__ vals,
+                                   int *__restrict__ idx,
+                                   unsigned *__restrict__ work) {
+  const unsigned T = work[kTopkState], ties = work[kTopkState + 1];
+  const unsigned above = k - ties;  // slots [0, above) hold the keys > T
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += step) {
+    const float v = x[i];
+    const unsigned key = mag_key(v);
+    if (key > T) {
+      const unsigned slot = atomicAdd(&work[kTopkState + 2], 1u);
+      vals[slot] = v;
+      idx[slot] = (int)i;
+    } else if (key == T) {
+      const unsigned t = atomicAdd(&work[kTopkState + 3], 1u);
+      if (t < ties) {
+        vals[above + t] = v;
+        idx[above + t] = (int)i;
+      }
+    }
+  }
+}
+
 __global__ void scatter_add_sparse_kernel(const float *__restrict__ vals,
                                           const int *__restrict__ idx,
                                           const int *__restrict__ count,
@@ -127,6 +201,24 @@ int sa_sparsify_threshold(const float *x, float thr, float *vals, int *idx,
   if (n <= 0) return 0;
   hipLaunchKernelGGL(sparsify_threshold_kernel, dim3(grid_for(n, 256, 4)),
                      dim3(256), 0, s, x, thr, vals, idx, count, n, cap);
+  return 0;
+}
+
+int64_t sa_topk_abs_workspace() { return kTopkState + 4; }
+
+int sa_topk_abs(const float *x, int64_t n, int64_t k, float *vals, int *idx,
+                unsigned *work, hipStream_t s) {
+  if (k <= 0) return 0;
+  if (k > n || n >= ((int64_t)1 << 31)) return -2;
+  (void)hipMemsetAsync(work, 0, (kTopkState + 4) * sizeof(unsigned), s);
+  const dim3 grid(grid_for(n, 256, 8)), block(256);
+  for (int pass = 0; pass < 4; ++pass) {
+    hipLaunchKernelGGL(topk_hist_kernel, grid, block, 0, s, x, n, pass, work);
+    hipLaunchKernelGGL(topk_scan_kernel, dim3(1), dim3(64), 0, s, pass,
+                       (unsigned)k, work);
+  }
+  hipLaunchKernelGGL(topk_select_kernel, grid, block, 0, s, x, n, (unsigned)k,
+                     vals, idx, work);
   return 0;
 }
 

@@ -237,6 +237,11 @@ int sa_unpack(int src_dtype, int dst_dtype, const PackEntry *table,
               int n_tensors, const void *bucket, int64_t total, float scale,
               hipStream_t s);
 // threshold sparsification helpers
+// the k entries of largest magnitude of x[0..n), in no particular order;
+// work holds sa_topk_abs_workspace() 32-bit words
+int64_t sa_topk_abs_workspace();
+int sa_topk_abs(const float *x, int64_t n, int64_t k, float *vals, int *idx,
+                unsigned *work, hipStream_t s);
 int sa_sparsify_threshold(const float *x, float thr, float *vals, int *idx,
                           int *count, int64_t n, int64_t cap, hipStream_t s);
 int sa_scatter_add_sparse(const float *vals, const int *idx, const int *count,

@@ -549,3 +549,25 @@ def test_lstm_cell(maths):
                                atol=1e-6)
     np.testing.assert_allclose(dcp.cpu().numpy(), rdcp.numpy(), rtol=1e-4,
                                atol=1e-6)
+
+
+@pytest.mark.parametrize("n,k", [(1000, 1), (1000, 37), (65537, 4096),
+                                 (1 << 20, 10000), (300, 300)])
+def test_topk_abs_radix_select(maths, n, k):
+    """Device radix select against a sort on the host: the multiset of
+    selected magnitudes must match, each value must sit at its index, and no
+    index may repeat.  A block of equal magnitudes straddles the cut."""
+    hm, cm, dev = maths
+    x = rnd(n, seed=90, lo=-4, hi=4)
+    x[::7] = 0.5          # many ties
+    x[3] = -1e30
+    x[5] = float("inf") if n > 5 else x[5]
+    xg = g(x, dev)
+    vals, idx = hm.topk_abs(xg, k)
+    torch.cuda.synchronize()
+    vals, idx = vals.cpu(), idx.cpu().long()
+    assert idx.unique().numel() == k
+    assert torch.equal(x[idx], vals)
+    ref = torch.sort(x.abs(), descending=True).values[:k]
+    got = torch.sort(vals.abs(), descending=True).values
+    assert torch.equal(ref, got)

@@ -396,6 +396,237 @@ gemm_h16_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// fp16 / bf16 fast path: 128 x 128 x 64 tiles, 16-byte staging
+// ---------------------------------------------------------------------------
+// Each operand tile (128 rows of the operand's own dimension x 64 reduction
+// indices, 16 KB) is fetched with 16-byte buffer loads (four per thread),
+// parked in registers under the MFMAs of the previous tile and written to one
+// of two LDS buffers with 16-byte stores: one barrier per 64-deep step.
+//
+// The LDS image depends on which index is contiguous in memory:
+//   * reduction index contiguous ("KC"): image [row][64 k], 128-byte rows;
+//     a lane's 32x32x16 fragment (8 consecutive k of one row) is one
+//     ds_read_b128.  Chunk c of row r sits at c ^ ((r >> 1) & 7): any 16 rows
+//     with distinct r & 15 hit 16 distinct 16-byte slots of the 64 banks.
+//   * row index contiguous: image [k][128 rows], 256-byte rows, read with the
+//     transposing ds_read_b64_tr_b16 (a 16-lane group fetches a 4 k x 16 row
+//     block and each lane receives its row's 4 k values), two reads per
+//     fragment.  Chunk c of k-row r sits at c ^ (((r & 3) << 2) | ((r >> 2) & 3)).
+// Rows past the matrix edge read zeros (or neighbouring data) through the
+// buffer resource and only feed outputs that are never stored; reduction
+// indices past K are forced to zero.
+namespace h16 {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kImage = 128 * BK * 2;  // bytes per operand tile
+constexpr int kOobOff = (int)0x80000000;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ int row_off(int r, int ch) {
+  return r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
+}
+__device__ __forceinline__ int kmaj_off(int r, int ch) {
+  return r * 256 + ((ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4);
+}
+
+// One operand: `rows` x K elements, element (i, k) at base[i * rs + k * ks];
+// KC means ks == 1, otherwise rs == 1.
+template <bool KC>
+struct Operand {
+  rsrc_t rsrc;
+  int rs, ks, row0, K;
+
+  // byte offsets of this thread's four 16-byte pieces of the tile at k0
+  __device__ __forceinline__ void plan(int tid, int k0, int *off) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (KC) {
+        const int ch = tid & 7, r = (tid >> 3) + 32 * j;
+        const int k = k0 + 8 * ch;
+        off[j] = k < K ? ((row0 + r) * rs + k) * 2 : kOobOff;
+      } else {
+        const int ch = tid & 15, kr = (tid >> 4) + 16 * j;
+        const int k = k0 + kr;
+        off[j] = k < K ? (k * ks + row0 + 8 * ch) * 2 : kOobOff;
+      }
+    }
+  }
+  __device__ __forceinline__ void load(const int *off, u32x4 *v) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      v[j] = __builtin_bit_cast(
+          u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[j], 0, 0));
+  }
+  static __device__ __forceinline__ void store(int tid, char *img,
+                                               const u32x4 *v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int o = KC ? row_off((tid >> 3) + 32 * j, tid & 7)
+                       : kmaj_off((tid >> 4) + 16 * j, tid & 15);
+      *reinterpret_cast<u32x4 *>(img + o) = v[j];
+    }
+  }
+  // fragment of rows [r0, r0 + 32) for reduction step ks16 (16 indices)
+  static __device__ __forceinline__ u32x4 frag(const char *img, int r0,
+                                               int ks16, int lane) {
+    if (KC) {
+      return *reinterpret_cast<const u32x4 *>(
+          img + row_off(r0 + (lane & 31), 2 * ks16 + (lane >> 5)));
+    } else {
+      const int i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+      const int ch = ((r0 + 16 * ((lane >> 4) & 1)) >> 3) + (p >> 1);
+      const int kr = 16 * ks16 + 8 * (lane >> 5) + q;
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (lds_s16x4 *)(img + kmaj_off(kr, ch) + 8 * (p & 1)));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (lds_s16x4 *)(img + kmaj_off(kr + 4, ch) + 8 * (p & 1)));
+      typedef unsigned long long u64;
+      u32x4 w;
+      const u64 a = __builtin_bit_cast(u64, lo), b = __builtin_bit_cast(u64, hi);
+      w.x = (unsigned)a; w.y = (unsigned)(a >> 32);
+      w.z = (unsigned)b; w.w = (unsigned)(b >> 32);
+      return w;
+    }
+  }
+};
+
+}  // namespace h16
+
+template <typename T, bool A_KC, bool B_KC>
+__global__ void __launch_bounds__(256)
+gemm_h16_fast_kernel(GemmArgs g, int ntm, int ntn) {
+  using namespace h16;
+  using frag = typename Half16<T>::frag;
+  __shared__ __attribute__((aligned(16))) char smem[2][2][kImage];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+
+  // Workgroup ids go round-robin over the 8 XCDs: give XCD x the x-th eighth
+  // of the tile list, walked in bands of 8 tile rows so that the workgroups
+  // resident on one XCD share A and B panels through its L2.
+  int pid_m, pid_n;
+  {
+    const int w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (w >= ntm * ntn) return;
+    const int band = 8 * ntn;
+    const int first = (w / band) * 8;
+    const int rows = min(8, ntm - first);
+    const int in_band = w - (w / band) * band;
+    pid_m = first + in_band % rows;
+    pid_n = in_band / rows;
+  }
+  const int m0 = pid_m * BM, n0 = pid_n * BN;
+  const int K = (int)g.K;
+
+  const T *Ab = (const T *)g.A + (int64_t)blockIdx.z * g.a_bs;
+  const T *Bb = (const T *)g.B + (int64_t)blockIdx.z * g.b_bs;
+  T *C = (T *)g.C + (int64_t)blockIdx.z * g.c_bs;
+  const int64_t a_extent = ((g.M - 1) * g.a_rs + (g.K - 1) * g.a_cs + 1) * 2;
+  const int64_t b_extent = ((g.K - 1) * g.b_rs + (g.N - 1) * g.b_cs + 1) * 2;
+  Operand<A_KC> opa{__builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<T *>(Ab), 0, (int)a_extent, 0x00020000),
+                    (int)g.a_rs, (int)g.a_cs, m0, K};
+  Operand<B_KC> opb{__builtin_amdgcn_make_buffer_rsrc(
+                        const_cast<T *>(Bb), 0, (int)b_extent, 0x00020000),
+                    (int)g.b_cs, (int)g.b_rs, n0, K};
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[4], rb[4];
+  int oa[4], ob[4];
+  const int nt = (K + BK - 1) / BK;
+  opa.plan(tid, 0, oa);
+  opb.plan(tid, 0, ob);
+  opa.load(oa, ra);
+  opb.load(ob, rb);
+  Operand<A_KC>::store(tid, smem[0][0], ra);
+  Operand<B_KC>::store(tid, smem[0][1], rb);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const char *as = smem[t & 1][0], *bs = smem[t & 1][1];
+    if (t + 1 < nt) {
+      opa.plan(tid, (t + 1) * BK, oa);
+      opb.plan(tid, (t + 1) * BK, ob);
+      opa.load(oa, ra);
+      opb.load(ob, rb);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      frag a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i] = __builtin_bit_cast(
+            frag, Operand<A_KC>::frag(as, wm * 64 + 32 * i, ks, lane));
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        b[j] = __builtin_bit_cast(
+            frag, Operand<B_KC>::frag(bs, wn * 64 + 32 * j, ks, lane));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = Half16<T>::mma(a[i], b[j], acc[i][j]);
+    }
+    if (t + 1 < nt) {
+      // the other buffer was last read before the previous barrier
+      Operand<A_KC>::store(tid, smem[(t + 1) & 1][0], ra);
+      Operand<B_KC>::store(tid, smem[(t + 1) & 1][1], rb);
+    }
+    __syncthreads();
+  }
+
+  const T *bias = (const T *)g.bias;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t col = n0 + wn * 64 + 32 * j + (lane & 31);
+      if (col >= g.N) continue;
+      const float bv = bias ? to_f<T>(bias[col]) : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row =
+            m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float v = g.alpha * acc[i][j][r] + bv;
+        T *cp = C + row * g.ldc + col;
+        if (g.beta != 0.f) v += g.beta * to_f<T>(*cp);
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        *cp = from_f<T>(v);
+      }
+    }
+}
+
+template <typename T>
+static void launch_h16_fast(const GemmArgs &g, bool a_kc, bool b_kc,
+                            int64_t batch, hipStream_t s) {
+  const int ntm = (int)((g.M + 127) / 128), ntn = (int)((g.N + 127) / 128);
+  const dim3 grid((unsigned)(((int64_t)ntm * ntn + 7) / 8 * 8), 1,
+                  (unsigned)batch);
+#define SA_H16_CASE(AK, BK_)                                                 \
+  if (a_kc == AK && b_kc == BK_) {                                           \
+    hipLaunchKernelGGL((gemm_h16_fast_kernel<T, AK, BK_>), grid, dim3(256),  \
+                       0, s, g, ntm, ntn);                                   \
+    return;                                                                  \
+  }
+  SA_H16_CASE(true, true)
+  SA_H16_CASE(true, false)
+  SA_H16_CASE(false, true)
+  SA_H16_CASE(false, false)
+#undef SA_H16_CASE
+}
+
 template <int BM, int BN>
 void launch_f32(const GemmArgs &g, int amode, int bmode, dim3 grid,
                 hipStream_t s) {
@@ -461,6 +692,26 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
     return 0;
   }
   if (dtype == kF16 || dtype == kBF16) {
+    // fast path: both operands readable in aligned 16-byte pieces along their
+    // contiguous index, every byte offset within 31 bits
+    auto al16 = [](const void *p) {
+      return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+    };
+    const bool a_kc = a_cs == 1, b_kc = b_rs == 1;
+    const bool a_ok = al16(A) && a_bs % 8 == 0 &&
+                      (a_kc ? a_rs % 8 == 0 : (a_rs == 1 && a_cs % 8 == 0));
+    const bool b_ok = al16(B) && b_bs % 8 == 0 &&
+                      (b_kc ? b_cs % 8 == 0 : (b_cs == 1 && b_rs % 8 == 0));
+    const int64_t lim = ((int64_t)1 << 30) - 1024;  // elements
+    const int64_t a_ext = (M - 1) * a_rs + (K - 1) * a_cs;
+    const int64_t b_ext = (K - 1) * b_rs + (N - 1) * b_cs;
+    if (a_ok && b_ok && K % 8 == 0 && K >= 64 && M >= 64 && N >= 64 &&
+        a_ext >= 0 && b_ext >= 0 && a_ext + 128 * a_rs < lim &&
+        b_ext + 128 * b_cs < lim && M < lim && N < lim) {
+      if (dtype == kF16) launch_h16_fast<__half>(g, a_kc, b_kc, batch, s);
+      else launch_h16_fast<__hip_bfloat16>(g, a_kc, b_kc, batch, s);
+      return 0;
+    }
     if (big) {
       dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128),
                 (unsigned)batch);

@@ -283,6 +283,54 @@ def test_gemm_half(maths, dt):
     np.testing.assert_allclose(ct.cpu().float().numpy(), ref.numpy(), atol=tol)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True),
+                                   (True, False), (True, True)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (200, 136, 72),
+                                   (128, 384, 1000), (64, 64, 64)])
+def test_gemm_16bit_tile_path(maths, dt, ta, tb, M, N, K):
+    """128 x 128 x 64 kernel: every combination of row- / column-contiguous
+    operands (16-byte row reads and transposing LDS reads), ragged M, N and
+    reduction tails, against an fp32 product of the same rounded inputs.
+    Small integers keep every product and partial sum exact in float."""
+    hm, cm, dev = maths
+    r = np.random.RandomState(M + N + K)
+    a = torch.from_numpy(r.randint(-3, 4, (M, K)).astype(np.float32)).to(dt)
+    b = torch.from_numpy(r.randint(-3, 4, (K, N)).astype(np.float32)).to(dt)
+    # an identity-like marker so a swapped row / column map cannot cancel out
+    a[:, 0] = torch.arange(M).to(dt) % 5
+    b[0, :] = torch.arange(N).to(dt) % 7
+    ref = (a.float() @ b.float())
+    ag = g(a.t().contiguous(), dev).t() if ta else g(a, dev)
+    bg = g(b.t().contiguous(), dev).t() if tb else g(b, dev)
+    c = torch.empty(M, N, dtype=dt, device=dev.torch_device)
+    hm.gemm(1.0, ag, bg, 0.0, c)
+    want = ref.to(dt).float()     # only the final rounding differs
+    assert torch.equal(c.float().cpu(), want)
+    # alpha, beta, bias and the ReLU epilogue
+    bias = torch.from_numpy(r.randint(-2, 3, (N,)).astype(np.float32)).to(dt)
+    c0 = torch.from_numpy(r.randint(-2, 3, (M, N)).astype(np.float32)).to(dt)
+    c = g(c0, dev).clone()
+    hm.gemm(0.5, ag, bg, 2.0, c, bias=g(bias, dev), act=1)
+    want = torch.relu(0.5 * ref + 2.0 * c0.float() + bias.float()).to(dt)
+    assert torch.equal(c.float().cpu(), want.float())
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_16bit_batched(maths, dt):
+    hm, cm, dev = maths
+    a, b = rnd(6, 192, 128, seed=61).to(dt), rnd(6, 128, 256, seed=62).to(dt)
+    ref = torch.matmul(a.float(), b.float())
+    c = torch.empty(6, 192, 256, dtype=dt, device=dev.torch_device)
+    hm.gemm(1.0, g(a, dev), g(b, dev), 0.0, c)
+    tol = 0.03 if dt == torch.float16 else 0.25
+    np.testing.assert_allclose(c.float().cpu().numpy(), ref.numpy(), atol=tol)
+    # attention-style: batch of Q K^T with K given as a transposed view
+    kt = g(b.transpose(1, 2).contiguous(), dev).transpose(1, 2)
+    hm.gemm(1.0, g(a, dev), kt, 0.0, c)
+    np.testing.assert_allclose(c.float().cpu().numpy(), ref.numpy(), atol=tol)
+
+
 CONV_CASES = [
     # N, C, H, W, K, R, S, stride, pad, groups
     (2, 3, 32, 32, 16, 7, 7, 2, 3, 1),

@@ -418,8 +418,7 @@ gemm_h16_kernel(GemmArgs g) {
 // indices past K are forced to zero.
 namespace h16 {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kImage = 128 * BK * 2;  // bytes per operand tile
+constexpr int BK = 64;
 constexpr int kOobOff = (int)0x80000000;
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -429,27 +428,30 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 __device__ __forceinline__ int row_off(int r, int ch) {
   return r * 128 + ((ch ^ ((r >> 1) & 7)) << 4);
 }
+template <int ROWS>
 __device__ __forceinline__ int kmaj_off(int r, int ch) {
-  return r * 256 + ((ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4);
+  return r * (ROWS * 2) + ((ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4);
 }
 
-// One operand: `rows` x K elements, element (i, k) at base[i * rs + k * ks];
-// KC means ks == 1, otherwise rs == 1.
-template <bool KC>
+// One operand tile: ROWS x 64 elements staged by NT threads; element (i, k)
+// of the matrix at base[i * rs + k * ks]; KC means ks == 1, otherwise rs == 1.
+template <bool KC, int ROWS, int NT>
 struct Operand {
+  static constexpr int PER = ROWS * 8 / NT;  // 16-byte pieces per thread
+  static constexpr int CPR = ROWS / 8;       // pieces per k-row ([k][row] image)
   rsrc_t rsrc;
   int rs, ks, row0, K;
 
-  // byte offsets of this thread's four 16-byte pieces of the tile at k0
+  // byte offsets of this thread's pieces of the tile at k0
   __device__ __forceinline__ void plan(int tid, int k0, int *off) const {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < PER; ++j) {
       if (KC) {
-        const int ch = tid & 7, r = (tid >> 3) + 32 * j;
+        const int ch = tid & 7, r = (tid >> 3) + (NT / 8) * j;
         const int k = k0 + 8 * ch;
         off[j] = k < K ? ((row0 + r) * rs + k) * 2 : kOobOff;
       } else {
-        const int ch = tid & 15, kr = (tid >> 4) + 16 * j;
+        const int ch = tid % CPR, kr = tid / CPR + (NT / CPR) * j;
         const int k = k0 + kr;
         off[j] = k < K ? (k * ks + row0 + 8 * ch) * 2 : kOobOff;
       }
@@ -457,16 +459,16 @@ struct Operand {
   }
   __device__ __forceinline__ void load(const int *off, u32x4 *v) const {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < PER; ++j)
       v[j] = __builtin_bit_cast(
           u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[j], 0, 0));
   }
   static __device__ __forceinline__ void store(int tid, char *img,
                                                const u32x4 *v) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int o = KC ? row_off((tid >> 3) + 32 * j, tid & 7)
-                       : kmaj_off((tid >> 4) + 16 * j, tid & 15);
+    for (int j = 0; j < PER; ++j) {
+      const int o = KC ? row_off((tid >> 3) + (NT / 8) * j, tid & 7)
+                       : kmaj_off<ROWS>(tid / CPR + (NT / CPR) * j, tid % CPR);
       *reinterpret_cast<u32x4 *>(img + o) = v[j];
     }
   }
@@ -481,9 +483,9 @@ struct Operand {
       const int ch = ((r0 + 16 * ((lane >> 4) & 1)) >> 3) + (p >> 1);
       const int kr = 16 * ks16 + 8 * (lane >> 5) + q;
       const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (lds_s16x4 *)(img + kmaj_off(kr, ch) + 8 * (p & 1)));
+          (lds_s16x4 *)(img + kmaj_off<ROWS>(kr, ch) + 8 * (p & 1)));
       const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-          (lds_s16x4 *)(img + kmaj_off(kr + 4, ch) + 8 * (p & 1)));
+          (lds_s16x4 *)(img + kmaj_off<ROWS>(kr + 4, ch) + 8 * (p & 1)));
       typedef unsigned long long u64;
       u32x4 w;
       const u64 a = __builtin_bit_cast(u64, lo), b = __builtin_bit_cast(u64, hi);
@@ -496,15 +498,24 @@ struct Operand {
 
 }  // namespace h16
 
-template <typename T, bool A_KC, bool B_KC>
-__global__ void __launch_bounds__(256)
+// WVM x WVN waves, each computing TM x TN blocks of 32 x 32:
+// 2 x 2 waves of 2 x 2 blocks = 128 x 128 tile (two workgroups per CU),
+// 2 x 4 waves of 4 x 2 blocks = 256 x 256 tile (one workgroup of 8 waves per
+// CU; half the LDS traffic per multiply, for problems with enough tiles).
+template <typename T, bool A_KC, bool B_KC, int WVM, int WVN, int TM, int TN>
+__global__ void __launch_bounds__(64 * WVM * WVN)
 gemm_h16_fast_kernel(GemmArgs g, int ntm, int ntn) {
   using namespace h16;
   using frag = typename Half16<T>::frag;
-  __shared__ __attribute__((aligned(16))) char smem[2][2][kImage];
+  constexpr int NT = 64 * WVM * WVN;
+  constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
+  using OpA = Operand<A_KC, BM, NT>;
+  using OpB = Operand<B_KC, BN, NT>;
+  constexpr int kImgA = BM * BK * 2, kImgB = BN * BK * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2][kImgA + kImgB];
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WVN, wn = wid % WVN;
 
   // Workgroup ids go round-robin over the 8 XCDs: give XCD x the x-th eighth
   // of the tile list, walked in bands of 8 tile rows so that the workgroups
@@ -528,33 +539,33 @@ gemm_h16_fast_kernel(GemmArgs g, int ntm, int ntn) {
   T *C = (T *)g.C + (int64_t)blockIdx.z * g.c_bs;
   const int64_t a_extent = ((g.M - 1) * g.a_rs + (g.K - 1) * g.a_cs + 1) * 2;
   const int64_t b_extent = ((g.K - 1) * g.b_rs + (g.N - 1) * g.b_cs + 1) * 2;
-  Operand<A_KC> opa{__builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<T *>(Ab), 0, (int)a_extent, 0x00020000),
-                    (int)g.a_rs, (int)g.a_cs, m0, K};
-  Operand<B_KC> opb{__builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<T *>(Bb), 0, (int)b_extent, 0x00020000),
-                    (int)g.b_cs, (int)g.b_rs, n0, K};
+  OpA opa{__builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Ab), 0,
+                                            (int)a_extent, 0x00020000),
+          (int)g.a_rs, (int)g.a_cs, m0, K};
+  OpB opb{__builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(Bb), 0,
+                                            (int)b_extent, 0x00020000),
+          (int)g.b_cs, (int)g.b_rs, n0, K};
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  u32x4 ra[4], rb[4];
-  int oa[4], ob[4];
+  u32x4 ra[OpA::PER], rb[OpB::PER];
+  int oa[OpA::PER], ob[OpB::PER];
   const int nt = (K + BK - 1) / BK;
   opa.plan(tid, 0, oa);
   opb.plan(tid, 0, ob);
   opa.load(oa, ra);
   opb.load(ob, rb);
-  Operand<A_KC>::store(tid, smem[0][0], ra);
-  Operand<B_KC>::store(tid, smem[0][1], rb);
+  OpA::store(tid, smem[0], ra);
+  OpB::store(tid, smem[0] + kImgA, rb);
   __syncthreads();
   for (int t = 0; t < nt; ++t) {
-    const char *as = smem[t & 1][0], *bs = smem[t & 1][1];
+    const char *as = smem[t & 1], *bs = smem[t & 1] + kImgA;
     if (t + 1 < nt) {
       opa.plan(tid, (t + 1) * BK, oa);
       opb.plan(tid, (t + 1) * BK, ob);
@@ -563,41 +574,41 @@ gemm_h16_fast_kernel(GemmArgs g, int ntm, int ntn) {
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      frag a[2], b[2];
+      frag a[TM], b[TN];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
         a[i] = __builtin_bit_cast(
-            frag, Operand<A_KC>::frag(as, wm * 64 + 32 * i, ks, lane));
+            frag, OpA::frag(as, (wm * TM + i) * 32, ks, lane));
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TN; ++j)
         b[j] = __builtin_bit_cast(
-            frag, Operand<B_KC>::frag(bs, wn * 64 + 32 * j, ks, lane));
+            frag, OpB::frag(bs, (wn * TN + j) * 32, ks, lane));
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
           acc[i][j] = Half16<T>::mma(a[i], b[j], acc[i][j]);
     }
     if (t + 1 < nt) {
       // the other buffer was last read before the previous barrier
-      Operand<A_KC>::store(tid, smem[(t + 1) & 1][0], ra);
-      Operand<B_KC>::store(tid, smem[(t + 1) & 1][1], rb);
+      OpA::store(tid, smem[(t + 1) & 1], ra);
+      OpB::store(tid, smem[(t + 1) & 1] + kImgA, rb);
     }
     __syncthreads();
   }
 
   const T *bias = (const T *)g.bias;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t col = n0 + wn * 64 + 32 * j + (lane & 31);
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + (wn * TN + j) * 32 + (lane & 31);
       if (col >= g.N) continue;
       const float bv = bias ? to_f<T>(bias[col]) : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row =
-            m0 + wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) +
+                            4 * (lane >> 5);
         if (row >= g.M) continue;
         float v = g.alpha * acc[i][j][r] + bv;
         T *cp = C + row * g.ldc + col;
@@ -608,16 +619,18 @@ gemm_h16_fast_kernel(GemmArgs g, int ntm, int ntn) {
     }
 }
 
-template <typename T>
-static void launch_h16_fast(const GemmArgs &g, bool a_kc, bool b_kc,
-                            int64_t batch, hipStream_t s) {
-  const int ntm = (int)((g.M + 127) / 128), ntn = (int)((g.N + 127) / 128);
+template <typename T, int WVM, int WVN, int TM, int TN>
+static void launch_h16_shape(const GemmArgs &g, bool a_kc, bool b_kc,
+                             int64_t batch, hipStream_t s) {
+  constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
+  const int ntm = (int)((g.M + BM - 1) / BM), ntn = (int)((g.N + BN - 1) / BN);
   const dim3 grid((unsigned)(((int64_t)ntm * ntn + 7) / 8 * 8), 1,
                   (unsigned)batch);
 #define SA_H16_CASE(AK, BK_)                                                 \
   if (a_kc == AK && b_kc == BK_) {                                           \
-    hipLaunchKernelGGL((gemm_h16_fast_kernel<T, AK, BK_>), grid, dim3(256),  \
-                       0, s, g, ntm, ntn);                                   \
+    hipLaunchKernelGGL(                                                      \
+        (gemm_h16_fast_kernel<T, AK, BK_, WVM, WVN, TM, TN>), grid,          \
+        dim3(64 * WVM * WVN), 0, s, g, ntm, ntn);                            \
     return;                                                                  \
   }
   SA_H16_CASE(true, true)
@@ -625,6 +638,24 @@ static void launch_h16_fast(const GemmArgs &g, bool a_kc, bool b_kc,
   SA_H16_CASE(false, true)
   SA_H16_CASE(false, false)
 #undef SA_H16_CASE
+}
+
+static const int kGemmTile = [] {
+  const char *v = getenv("SA_GEMM_TILE");
+  return v && *v ? atoi(v) : 0;
+}();
+
+template <typename T>
+static void launch_h16_fast(const GemmArgs &g, bool a_kc, bool b_kc,
+                            int64_t batch, hipStream_t s) {
+  // 256 x 256 tiles (one workgroup per CU at a time) when their rounds over
+  // the 256 CUs are at least 80 % full
+  const int64_t t256 = ((g.M + 255) / 256) * ((g.N + 255) / 256) * batch;
+  bool big = t256 * 5 >= (t256 + 255) / 256 * 256 * 4;
+  if (kGemmTile == 128) big = false;
+  if (kGemmTile == 256) big = true;
+  if (big) launch_h16_shape<T, 2, 4, 4, 2>(g, a_kc, b_kc, batch, s);
+  else launch_h16_shape<T, 2, 2, 2, 2>(g, a_kc, b_kc, batch, s);
 }
 
 template <int BM, int BN>
@@ -706,8 +737,8 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
     const int64_t a_ext = (M - 1) * a_rs + (K - 1) * a_cs;
     const int64_t b_ext = (K - 1) * b_rs + (N - 1) * b_cs;
     if (a_ok && b_ok && K % 8 == 0 && K >= 64 && M >= 64 && N >= 64 &&
-        a_ext >= 0 && b_ext >= 0 && a_ext + 128 * a_rs < lim &&
-        b_ext + 128 * b_cs < lim && M < lim && N < lim) {
+        a_ext >= 0 && b_ext >= 0 && a_ext + 256 * a_rs < lim &&
+        b_ext + 256 * b_cs < lim && M < lim && N < lim) {
       if (dtype == kF16) launch_h16_fast<__half>(g, a_kc, b_kc, batch, s);
       else launch_h16_fast<__hip_bfloat16>(g, a_kc, b_kc, batch, s);
       return 0;

@@ -322,10 +322,42 @@ class HipMath(object):
         if c.stride()[-1] != 1:
             raise ValueError("GEMM output must be row-major")
         ldc = c.stride()[-2] if c.dim() >= 2 else N
+        splits = self._gemm_splits(M, N, K) if (
+            batch == 1 and c.dtype == torch.float32) else 1
+        if splits > 1:
+            # skinny product: too few output tiles to occupy the chip, so the
+            # reduction is cut into `splits` equal slices computed as a batch
+            # of partial products, summed by one epilogue kernel
+            kc = K // splits
+            part = torch.empty(splits * M * N, dtype=torch.float32,
+                               device=c.device)
+            self.k.gemm(0, M, N, kc, 1.0, a.data_ptr(), a_rs, a_cs, kc * a_cs,
+                        b.data_ptr(), b_rs, b_cs, kc * b_rs, 0.0,
+                        part.data_ptr(), N, M * N, splits, 0, 0, self._s())
+            self.k.gemm_splitk_reduce(
+                0, part.data_ptr(), splits, M, N, float(alpha), float(beta),
+                c.data_ptr(), ldc,
+                bias.data_ptr() if bias is not None else 0, act, self._s())
+            return
         self.k.gemm(_code(c), M, N, K, float(alpha), a.data_ptr(), a_rs, a_cs,
                     a_bs, b.data_ptr(), b_rs, b_cs, b_bs, float(beta),
                     c.data_ptr(), ldc, c_bs, batch,
                     bias.data_ptr() if bias is not None else 0, act, self._s())
+
+    @staticmethod
+    def _gemm_splits(M, N, K):
+        """Number of equal reduction slices for a product with few 64 x 64
+        output tiles: the largest divisor of K that keeps slices at least 64
+        deep (and 4-aligned for the vector loads) and the launch within about
+        one workgroup per CU."""
+        tiles = -(-M // 64) * -(-N // 64)
+        if tiles > 64 or K < 512:
+            return 1
+        best = 1
+        for d in range(2, min(32, 256 // tiles) + 1):
+            if K % d == 0 and (K // d) >= 64 and (K // d) % 4 == 0:
+                best = d
+        return best
 
     def gemv(self, alpha, a, v, beta, out):
         self.gemm(alpha, a, v.reshape(-1, 1), beta, out.reshape(-1, 1))

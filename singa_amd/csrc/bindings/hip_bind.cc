@@ -171,6 +171,15 @@ PYBIND11_MODULE(_hip, m) {
           "gemm");
   });
 
+  m.def("gemm_splitk_reduce", [](int dt, uintptr_t part, int splits, int64_t M,
+                                 int64_t N, float alpha, float beta,
+                                 uintptr_t C, int64_t ldc, uintptr_t bias,
+                                 int act, uintptr_t s) {
+    check(sa_gemm_splitk_reduce(dt, (const float *)CP(part), splits, M, N,
+                                alpha, beta, P(C), ldc, CP(bias), act, S(s)),
+          "gemm_splitk_reduce");
+  });
+
   // ---- convolution -----------------------------------------------------------------
   py::class_<ConvGeom>(m, "ConvGeom")
       .def(py::init([](int N, int C, int H, int W, int K, int R, int Sw, int P_,

@@ -677,9 +677,47 @@ void launch_f32(const GemmArgs &g, int amode, int bmode, dim3 grid,
                      dim3(256), 0, s, g);
 }
 
+// Split-K epilogue: C = act(alpha * sum_s part[s] + beta * C + bias), part is
+// [splits][M][N] float; dtype is C's and the bias's element type.
+template <typename T>
+__global__ void splitk_reduce_kernel(const float *__restrict__ part, int splits,
+                                     int64_t M, int64_t N, float alpha,
+                                     float beta, T *__restrict__ C,
+                                     int64_t ldc, const T *__restrict__ bias,
+                                     int act) {
+  const int64_t total = M * N;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += step) {
+    float v = 0.f;
+    for (int sp = 0; sp < splits; ++sp) v += part[sp * total + i];
+    const int64_t r = i / N, c = i - r * N;
+    v *= alpha;
+    if (bias) v += to_f<T>(bias[c]);
+    T *cp = C + r * ldc + c;
+    if (beta != 0.f) v += beta * to_f<T>(*cp);
+    if (act == 1) v = fmaxf(v, 0.f);
+    *cp = from_f<T>(v);
+  }
+}
+
 }  // namespace sa
 
 using namespace sa;
+
+int sa_gemm_splitk_reduce(int dtype, const float *part, int splits, int64_t M,
+                          int64_t N, float alpha, float beta, void *C,
+                          int64_t ldc, const void *bias, int act,
+                          hipStream_t s) {
+  if (M <= 0 || N <= 0 || splits <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>),
+                       dim3(grid_for(M * N, 256)), dim3(256), 0, s, part,
+                       splits, M, N, alpha, beta, (T *)C, ldc, (const T *)bias,
+                       act);
+  });
+  return 0;
+}
 
 int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
             const void *A, int64_t a_rs, int64_t a_cs, int64_t a_bs,

@@ -100,6 +100,12 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
             float beta, void *C, int64_t ldc, int64_t c_bs, int64_t batch,
             const void *bias, int act, hipStream_t s);
 
+// epilogue of a reduction split over `splits` partial products [splits][M][N]
+int sa_gemm_splitk_reduce(int dtype, const float *part, int splits, int64_t M,
+                          int64_t N, float alpha, float beta, void *C,
+                          int64_t ldc, const void *bias, int act,
+                          hipStream_t s);
+
 // ---- conv.hip ---------------------------------------------------------------------------------
 struct ConvGeom {
   int N, C, H, W;      // input

@@ -619,3 +619,24 @@ def test_topk_abs_radix_select(maths, n, k):
     ref = torch.sort(x.abs(), descending=True).values[:k]
     got = torch.sort(vals.abs(), descending=True).values
     assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 1000, 2048), (32, 2048, 1000),
+                                   (8, 8, 4096), (100, 70, 1536)])
+def test_gemm_skinny_split_reduction(maths, M, N, K):
+    """Few output tiles and a long reduction: the product is computed as a
+    batch of partial products over slices of K and summed by the epilogue
+    kernel (alpha, beta, bias, ReLU applied there)."""
+    hm, cm, dev = maths
+    assert hm._gemm_splits(M, N, K) > 1
+    a, b = rnd(M, K, seed=70), rnd(K, N, seed=71)
+    bias, c0 = rnd(N, seed=72), rnd(M, N, seed=73)
+    ref = a.double() @ b.double()
+    c = torch.empty(M, N, device=dev.torch_device)
+    hm.gemm(1.0, g(a, dev), g(b, dev), 0.0, c)
+    np.testing.assert_allclose(c.cpu().numpy(), ref.numpy(), atol=2e-4)
+    c = g(c0, dev).clone()
+    hm.gemm(0.5, g(a.t().contiguous(), dev).t(), g(b, dev), 2.0, c,
+            bias=g(bias, dev), act=1)
+    want = torch.relu(0.5 * ref + 2.0 * c0.double() + bias.double())
+    np.testing.assert_allclose(c.cpu().numpy(), want.numpy(), atol=3e-4)

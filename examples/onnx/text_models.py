@@ -211,7 +211,12 @@ def main(argv=None):
     args = ap.parse_args(argv)
     dev = create_device()
     if args.task == "self-test":
-        return self_test(dev)
+        err = self_test(dev)
+        print("self-test: max abs difference to the numpy reference %.3g" % err)
+        return err
+    if args.model is None or args.vocab is None:
+        ap.error("%s needs --model (an .onnx file) and --vocab (tokenizer "
+                 "files); this build never downloads them" % args.task)
     if args.task == "gpt2":
         out = gpt2_generate(args.model, args.vocab, args.text, args.length,
                             dev)

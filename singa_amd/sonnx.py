@@ -716,6 +716,31 @@ class SingaFrontend(object):
         return names
 
     @classmethod
+    def _expand_batchnorm_act(cls, op, nodes, initializers):
+        """The fused normalisation operator has no ONNX counterpart: it is
+        written as BatchNormalization [-> Add] -> Relu, which is also what an
+        importer turns back into separate operators."""
+        ins = cls._input_names(op)          # x, scale, bias[, residual]
+        for suffix, raw in (("mean", op.running_mean),
+                            ("var", op.running_var)):
+            nm = "%s_%s" % (op.name, suffix)
+            initializers.append(numpy_helper.from_array(
+                tensor.to_numpy(tensor.from_raw_tensor(raw)), nm))
+            ins.insert(3 + (suffix == "var"), nm)
+        out = op.output_name(0)
+        bn_out = out + "_bn"
+        nodes.append(helper.make_node(
+            'BatchNormalization', ins[:5], [bn_out], name=op.name + "_bn",
+            momentum=float(op.handle.factor), epsilon=1e-5))
+        if len(ins) > 5:                    # residual branch
+            nodes.append(helper.make_node('Add', [bn_out, ins[5]],
+                                          [out + "_sum"],
+                                          name=op.name + "_add"))
+            bn_out = out + "_sum"
+        nodes.append(helper.make_node('Relu', [bn_out], [out],
+                                      name=op.name + "_relu"))
+
+    @classmethod
     def singa_to_onnx_graph(cls, inputs, y, model_name="sonnx"):
         """GraphProto of the computation that produced ``y`` (a Tensor or a
         list of Tensors) from ``inputs`` (list of Tensors)."""
@@ -731,6 +756,9 @@ class SingaFrontend(object):
                 if id(op) in done:
                     continue
                 done.add(id(op))
+                if type(op).__name__ == '_BatchNormAct2d':
+                    cls._expand_batchnorm_act(op, nodes, initializers)
+                    continue
                 op_type, attrs, extra = cls._attrs_and_extra(op)
                 in_names = cls._input_names(op)
                 for suffix, arr in extra:

@@ -1,0 +1,35 @@
+#!/bin/bash
+# Smoke-run the example programs on the GPU with tiny budgets.  Each step has
+# its own time limit; the script stops at the first failure.
+set -o pipefail
+cd "$(dirname "$0")/.."
+OUT=gpurun_out/examples_gpu
+mkdir -p $OUT
+run() {
+  name=$1; shift
+  echo "== $name: $*"
+  timeout -k 10 170 "$@" > $OUT/$name.log 2>&1
+  rc=$?
+  tail -2 $OUT/$name.log
+  if [ $rc -ne 0 ]; then echo "FAILED $name rc=$rc"; exit $rc; fi
+}
+run cnn_mnist python examples/cnn/train_cnn.py cnn mnist -m 1 --max-batches 20
+run cnn_mnist_fp16 python examples/cnn/train_cnn.py cnn mnist -p float16 -m 1 --max-batches 20
+run resnet_cifar python examples/cnn/train_cnn.py resnet cifar10 -m 1 -b 16 --max-batches 4
+run alexnet_cifar python examples/cnn/train_cnn.py alexnet cifar10 -m 1 -b 8 --max-batches 3
+run xception_cifar python examples/cnn/train_cnn.py xceptionnet cifar10 -m 1 -b 4 --max-batches 2
+run mlp_model python examples/mlp/model.py -m 101
+run mlp_native python examples/mlp/native.py -m 101
+run benchmark python examples/cnn/benchmark.py --iters 10
+run char_rnn python examples/rnn/char_rnn.py -m 1 -b 16 -l 32 -d 64
+run imdb python examples/rnn/imdb_train.py -m 1 -b 32
+run qabot python examples/qabot/qabot_train.py -m 1 -b 16
+run gan python examples/gan/vanilla.py --use_gpu --iterations 40 --interval 20
+run lsgan python examples/gan/lsgan.py --use_gpu --iterations 40 --interval 20
+run rbm python examples/rbm/train.py --use_gpu -m 1 --hdim 64
+run onnx_train python examples/onnx/training/train.py --self-export -m 1 -b 8 --max-batches 3
+run onnx_selftest python examples/onnx/text_models.py self-test
+run largedata python examples/largedataset_cnn/train_largedata.py cnn --synthetic -m 1 -b 16
+run hfl python examples/hfl/run_local.py
+run cpp_cnn singa_amd/bin/singa_cnn -epoch 1
+echo ALL-EXAMPLES-OK

@@ -351,10 +351,17 @@ class CpuMath(object):
 
     # ---- fused optimiser step --------------------------------------------------------------------------
     def sgd_update_multi(self, ps, gs, bufs, lr, momentum, dampening,
-                         weight_decay, nesterov, scale):
+                         weight_decay, nesterov, scale, masters=None):
         for i, (p, g) in enumerate(zip(ps, gs)):
-            self.sgd_update(p, g, bufs[i] if bufs else None, lr, momentum,
-                            dampening, weight_decay, nesterov, scale)
+            if masters:
+                m = masters[i]
+                self.sgd_update(m, g.to(m.dtype), bufs[i] if bufs else None,
+                                lr, momentum, dampening, weight_decay,
+                                nesterov, scale)
+                p.copy_(m)
+            else:
+                self.sgd_update(p, g, bufs[i] if bufs else None, lr, momentum,
+                                dampening, weight_decay, nesterov, scale)
 
     def sgd_update(self, p, g, buf, lr, momentum, dampening, weight_decay,
                    nesterov, scale):

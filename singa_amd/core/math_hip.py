@@ -570,11 +570,13 @@ class HipMath(object):
     def bn_fwd_infer(self, x, scale, bias, rmean, rvar, eps, y, act=0,
                      residual=None):
         N, C, HW = self._nchw(x)
-        self.k.bn_fwd_infer_act(_code(x), x.data_ptr(),
-                                self._f32(scale).data_ptr(),
-                                self._f32(bias).data_ptr(),
-                                self._f32(rmean).data_ptr(),
-                                self._f32(rvar).data_ptr(), float(eps),
+        # converted copies must stay referenced until the launch is issued:
+        # a freed temporary's storage is handed to the next one
+        sc, bi = self._f32(scale), self._f32(bias)
+        rm, rv = self._f32(rmean), self._f32(rvar)
+        self.k.bn_fwd_infer_act(_code(x), x.data_ptr(), sc.data_ptr(),
+                                bi.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                float(eps),
                                 y.data_ptr(), N, C, HW, int(act),
                                 residual.data_ptr() if residual is not None
                                 else 0, self._s())
@@ -588,11 +590,13 @@ class HipMath(object):
         work = self._tmp(self.k.bn_workspace(N, C, HW))
         ds = dscale if dscale.dtype == torch.float32 else self._tmp(C)
         db = dbias if dbias.dtype == torch.float32 else self._tmp(C)
+        sc = self._f32(scale)
+        bi = self._f32(bias) if bias is not None else None
         self.k.bn_bwd_act(_code(x), dy.data_ptr(), x.data_ptr(),
                           y.data_ptr() if y is not None else 0,
-                          self._f32(scale).data_ptr(),
-                          self._f32(bias).data_ptr() if bias is not None
-                          else 0, mean.data_ptr(), invstd.data_ptr(),
+                          sc.data_ptr(),
+                          bi.data_ptr() if bi is not None else 0,
+                          mean.data_ptr(), invstd.data_ptr(),
                           dx.data_ptr(),
                           dres.data_ptr() if dres is not None else 0,
                           ds.data_ptr(), db.data_ptr(), N, C, HW,
@@ -722,31 +726,38 @@ class HipMath(object):
         g = self._contig(g)
         if g.dtype != p.dtype:
             g = self._cast(g, p.dtype)
+        # keep the float copies of 16-bit hyper-parameters alive until launch
+        hyper = [self._f32(t) for t in (lr, momentum, dampening, weight_decay)]
         self.k.sgd_update(_code(p), p.data_ptr(), g.data_ptr(),
                           buf.data_ptr() if buf is not None else 0,
-                          self._f32(lr).data_ptr(),
-                          self._f32(momentum).data_ptr(),
-                          self._f32(dampening).data_ptr(),
-                          self._f32(weight_decay).data_ptr(),
+                          hyper[0].data_ptr(), hyper[1].data_ptr(),
+                          hyper[2].data_ptr(), hyper[3].data_ptr(),
                           1 if nesterov else 0, float(scale), p.numel(),
                           self._s())
 
     def sgd_update_multi(self, ps, gs, bufs, lr, momentum, dampening,
-                         weight_decay, nesterov, scale):
-        """One launch per 48 tensors; all tensors share the dtype of ps[0]."""
+                         weight_decay, nesterov, scale, masters=None):
+        """One launch per 48 tensors; all tensors share the dtype of ps[0].
+        With ``masters`` (float copies of 16-bit parameters) the step is
+        taken in float -- ``bufs`` are float then -- and rounded into ps."""
+        if masters:
+            assert all(m.dtype == torch.float32 for m in masters)
+            assert not bufs or all(b.dtype == torch.float32 for b in bufs)
         gg = []
         for p, g in zip(ps, gs):
             g = self._contig(g)
             if g.dtype != p.dtype:
                 g = self._cast(g, p.dtype)
             gg.append(g)
+        # keep the float copies of 16-bit hyper-parameters alive until launch
+        hyper = [self._f32(t) for t in (lr, momentum, dampening, weight_decay)]
         self.k.sgd_update_multi(
             _code(ps[0]), [p.data_ptr() for p in ps],
             [g.data_ptr() for g in gg],
             [b.data_ptr() for b in bufs] if bufs else [],
-            [p.numel() for p in ps], self._f32(lr).data_ptr(),
-            self._f32(momentum).data_ptr(), self._f32(dampening).data_ptr(),
-            self._f32(weight_decay).data_ptr(), 1 if nesterov else 0,
+            [m.data_ptr() for m in masters] if masters else [],
+            [p.numel() for p in ps], hyper[0].data_ptr(), hyper[1].data_ptr(),
+            hyper[2].data_ptr(), hyper[3].data_ptr(), 1 if nesterov else 0,
             float(scale), self._s())
 
     # ---- recurrent cells ---------------------------------------------------------------------------------------------

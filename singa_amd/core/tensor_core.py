@@ -1234,34 +1234,39 @@ def SGDUpdate(p, g, buf, lr, momentum, dampening, weight_decay, nesterov,
 
 
 def SGDUpdateMulti(params, grads, bufs, lr, momentum, dampening, weight_decay,
-                   nesterov, scale=1.0):
+                   nesterov, scale=1.0, masters=None):
     """The fused SGD step for a whole list of parameters as ONE graph node
     (and one kernel launch per 48 tensors).  ``bufs`` is a list of momentum
-    buffers or None.  All tensors must live on one device and share a dtype;
-    callers group by dtype."""
+    buffers or None; ``masters`` a list of float32 copies of 16-bit parameters
+    (the step is then taken on the copies, with float32 ``bufs``) or None.
+    All tensors must live on one device and share a dtype; callers group by
+    dtype."""
     nesterov = bool(nesterov)
     scale = float(scale)
     n = len(params)
     assert n == len(grads) and n > 0
     has_buf = bufs is not None
     bufs = list(bufs) if has_buf else []
+    has_master = masters is not None
+    masters = list(masters) if has_master else []
 
     def body(*args):
-        ps_in = args[0:n]
         gs = args[n:2 * n]
-        off = 2 * n + (n if has_buf else 0)
+        off = 2 * n + len(bufs) + len(masters)
         l, m, d, w = args[off:off + 4]
         outs = args[off + 4:]
         ps = outs[0:n]
         bs = outs[n:2 * n] if has_buf else None
+        ms = outs[n + len(bufs):n + len(bufs) + n] if has_master else None
         ps[0]._dev.math.sgd_update_multi(
             [t.view() for t in ps], [t.view() for t in gs],
             [t.view() for t in bs] if has_buf else None, l.flat(), m.flat(),
-            d.flat(), w.flat(), nesterov, scale)
+            d.flat(), w.flat(), nesterov, scale,
+            [t.view() for t in ms] if has_master else None)
 
-    reads = list(params) + list(grads) + bufs + [lr, momentum, dampening,
-                                                 weight_decay]
-    writes = list(params) + bufs
+    reads = list(params) + list(grads) + bufs + masters + [
+        lr, momentum, dampening, weight_decay]
+    writes = list(params) + bufs + masters
     _submit(params[0]._dev, "SGDUpdateMulti", body, reads, writes)
     return params
 

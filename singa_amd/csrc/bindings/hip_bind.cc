@@ -318,17 +318,22 @@ PYBIND11_MODULE(_hip, m) {
   m.def("sgd_update_multi", [](int dt, std::vector<uintptr_t> p,
                                std::vector<uintptr_t> g,
                                std::vector<uintptr_t> buf,
+                               std::vector<uintptr_t> master,
                                std::vector<int64_t> n, uintptr_t lr,
                                uintptr_t mom, uintptr_t damp, uintptr_t wd,
                                int nesterov, float scale, uintptr_t s) {
     if (p.size() != g.size() || p.size() != n.size() ||
-        (!buf.empty() && buf.size() != p.size()))
+        (!buf.empty() && buf.size() != p.size()) ||
+        (!master.empty() && master.size() != p.size()))
       throw std::invalid_argument("sgd_update_multi: list lengths differ");
     check(sa_sgd_update_multi(
               dt, (int)p.size(), reinterpret_cast<void *const *>(p.data()),
               reinterpret_cast<const void *const *>(g.data()),
               buf.empty() ? nullptr
                           : reinterpret_cast<void *const *>(buf.data()),
+              master.empty()
+                  ? nullptr
+                  : reinterpret_cast<float *const *>(master.data()),
               n.data(), (const float *)CP(lr), (const float *)CP(mom),
               (const float *)CP(damp), (const float *)CP(wd), nesterov, scale,
               S(s)),

@@ -198,13 +198,18 @@ struct SgdBatch {
   void *p[kSgdMaxTensors];
   const void *g[kSgdMaxTensors];
   void *buf[kSgdMaxTensors];
+  // mixed precision: float copy of a 16-bit parameter (buf is float then too)
+  float *master[kSgdMaxTensors];
   int64_t n[kSgdMaxTensors];
   int chunk_start[kSgdMaxTensors + 1];
   int count;
 };
 }  // namespace sa
+// master (null, or one float tensor per parameter): the step is taken on the
+// float copy, with float momentum buffers, and rounded into the parameter
 int sa_sgd_update_multi(int dtype, int count, void *const *p,
                         const void *const *g, void *const *buf,
+                        float *const *master,
                         const int64_t *n, const float *lr,
                         const float *momentum, const float *dampening,
                         const float *weight_decay, int nesterov, float scale,

@@ -76,7 +76,7 @@ __global__ void sgd_multi_kernel(SgdBatch batch, const float *__restrict__ lr_p,
   T *__restrict__ buf =
       batch.buf[t] ? static_cast<T *>(batch.buf[t]) + base : nullptr;
   const int64_t len = n - base < kSgdChunk ? n - base : kSgdChunk;
-  const bool has_buf = buf != nullptr;
+  const bool has_buf = batch.buf[t] != nullptr;
   auto upd = [&](float pv, float gv, float &bv) {
     gv = gv * scale + wd * pv;
     if (has_buf) {
@@ -85,6 +85,21 @@ __global__ void sgd_multi_kernel(SgdBatch batch, const float *__restrict__ lr_p,
     }
     return pv - lr * gv;
   };
+  if (batch.master[t]) {
+    // 16-bit parameter with a float master copy and float momentum: steps
+    // smaller than the parameter's rounding unit still accumulate
+    float *__restrict__ mp = batch.master[t] + base;
+    float *__restrict__ fb =
+        has_buf ? static_cast<float *>(batch.buf[t]) + base : nullptr;
+    for (int64_t i = threadIdx.x; i < len; i += blockDim.x) {
+      float b = has_buf ? fb[i] : 0.f;
+      const float v = upd(mp[i], to_f<T>(g[i]), b);
+      mp[i] = v;
+      p[i] = from_f<T>(v);
+      if (has_buf) fb[i] = b;
+    }
+    return;
+  }
   constexpr int VEC = 16 / sizeof(T);
   struct alignas(16) V { T v[VEC]; };
   const bool aligned =
@@ -119,6 +134,7 @@ using namespace sa;
 
 int sa_sgd_update_multi(int dtype, int count, void *const *p,
                         const void *const *g, void *const *buf,
+                        float *const *master,
                         const int64_t *n, const float *lr,
                         const float *momentum, const float *dampening,
                         const float *weight_decay, int nesterov, float scale,
@@ -131,6 +147,7 @@ int sa_sgd_update_multi(int dtype, int count, void *const *p,
       b.p[i] = p[first + i];
       b.g[i] = g[first + i];
       b.buf[i] = buf ? buf[first + i] : nullptr;
+      b.master[i] = master ? master[first + i] : nullptr;
       b.n[i] = n[first + i];
       b.chunk_start[i] = chunks;
       chunks += (int)((n[first + i] + kSgdChunk - 1) / kSgdChunk);

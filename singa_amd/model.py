@@ -194,6 +194,14 @@ class Model(layer.Layer, metaclass=ModelMeta):
                 aux_states[k] = tensor.from_numpy(tensor_dict[k])
         tensor_dict.close()
         self.set_states(model_states)
+        # float32 master copies held by the optimizer describe the old values
+        forget = getattr(getattr(self, "optimizer", None), "forget_masters",
+                         None)
+        if forget is None:
+            forget = getattr(getattr(getattr(self, "optimizer", None), "opt",
+                                     None), "forget_masters", None)
+        if forget is not None:
+            forget()
         os.remove(tensor_dict_fp)
         os.remove(states_attr_fp)
         os.rmdir(tmp_dir)

@@ -146,11 +146,20 @@ class Optimizer(object):
         """Deprecated spelling of ``__call__``."""
         self.__call__(loss)
 
-    def _new_state(self, like):
+    def _new_state(self, like, copy=False, dtype=None):
+        """A state tensor shaped like ``like`` (zeros, or a copy of it),
+        created immediately even while a graph is being recorded."""
         dev = like.device
         flag = dev.graph_enabled()
         dev.EnableGraph(False)
-        t = tensor.zeros_like(like)
+        if copy:
+            t = like.as_type(dtype) if dtype not in (None, like.dtype) \
+                else like.clone()
+        elif dtype in (None, like.dtype):
+            t = tensor.zeros_like(like)
+        else:
+            t = tensor.Tensor(like.shape, dev, dtype)
+            t.set_value(0.0)
         dev.EnableGraph(flag)
         return t
 
@@ -166,8 +175,14 @@ class SGD(Optimizer):
     """
 
     def __init__(self, lr=0.1, momentum=0, dampening=0, weight_decay=0,
-                 nesterov=False, dtype=tensor.float32):
+                 nesterov=False, dtype=tensor.float32, master_weights=True):
         super(SGD, self).__init__(lr, dtype)
+        # 16-bit parameters updated through ``apply_many`` keep a float32
+        # master copy and float32 momentum (the reference steps the half
+        # tensors directly, python/singa/opt.py:259-310, and loses updates
+        # below half a unit in the last place)
+        self.master_weights = master_weights
+        self.masters = dict()
         self.momentum = _as_scheduler(momentum, "momentum", True)
         self.mom_value = self.momentum(self.step_counter).as_type(self.dtype)
         self.dampening = _as_scheduler(dampening, "dampening")
@@ -218,19 +233,29 @@ class SGD(Optimizer):
             self.device_check(items[0][0], self.step_counter, self.lr_value,
                               self.mom_value, self.dam_value,
                               self.decay_value)
-            bufs = None
+            mixed = self.master_weights and dt != tensor.float32
+            bufs, masters = None, None
+            if mixed:
+                masters = []
+                for p, _ in items:
+                    key = self._state_key(p.name, p)
+                    if key not in self.masters:
+                        self.masters[key] = self._new_state(p, copy=True,
+                                                            dtype=tensor.float32)
+                    masters.append(self.masters[key].data)
             if use_mom:
                 bufs = []
                 for p, _ in items:
                     key = self._state_key(p.name, p)
                     if key not in self.moments:
-                        self.moments[key] = self._new_state(p)
+                        self.moments[key] = self._new_state(
+                            p, dtype=tensor.float32 if mixed else None)
                     bufs.append(self.moments[key].data)
             singa.SGDUpdateMulti([p.data for p, _ in items],
                                  [g.data for _, g in items], bufs,
                                  self.lr_value.data, self.mom_value.data,
                                  self.dam_value.data, self.decay_value.data,
-                                 self.nesterov, scale)
+                                 self.nesterov, scale, masters)
 
     def call(self, loss):
         """Back-propagate, then update all parameters in one fused step."""
@@ -249,6 +274,8 @@ class SGD(Optimizer):
         states = super().get_states()
         if self.momentum.init_value > 0:
             states['moments'] = self.moments
+        if self.masters:
+            states['masters'] = self.masters
         return states
 
     def set_states(self, states):
@@ -256,6 +283,14 @@ class SGD(Optimizer):
         if 'moments' in states:
             self.moments = states['moments']
             self.mom_value = self.momentum(self.step_counter)
+        if 'masters' in states:
+            self.masters = states['masters']
+
+    def forget_masters(self):
+        """Drop the float32 master copies: the next step re-creates them from
+        the current parameter values.  Call after parameters were overwritten
+        from outside the optimizer (loading a checkpoint)."""
+        self.masters = dict()
 
 
 class RMSProp(Optimizer):

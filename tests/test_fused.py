@@ -196,3 +196,76 @@ def test_conv_bwd_data_acc_kernel_matches_reference():
         err = (dx.double().cpu() - ref).abs().max().item()
         assert err < 2e-3 * max(1.0, ref.abs().max().item()), \
             ((N, C, H, W, K, R, st, pd), err)
+
+
+def _half_sgd_drift(dev, master):
+    """200 steps with a gradient whose step (lr * g = 1e-4) is far below the
+    rounding unit of fp16 around 1.0 (2^-10): without a master copy nothing
+    moves, with it the parameter follows the exact trajectory."""
+    import numpy as np
+    from singa_amd import opt, tensor
+    p = tensor.from_numpy(np.ones((64, 33), dtype=np.float16), dev)
+    g = tensor.from_numpy(np.full((64, 33), 1e-2, dtype=np.float16), dev)
+    p.name = "w"
+    sgd = opt.SGD(lr=0.01, momentum=0.0, master_weights=master)
+    for _ in range(200):
+        sgd.apply_many([(p, g)])
+        sgd.step()
+    return float(tensor.to_numpy(p).astype(np.float32).mean())
+
+
+def test_sgd_master_weights_accumulate_small_steps_cpu():
+    from singa_amd import device
+    dev = device.get_default_device()
+    assert abs(_half_sgd_drift(dev, True) - (1.0 - 200 * 1e-4)) < 2e-3
+    assert _half_sgd_drift(dev, False) == 1.0
+
+
+@pytest.mark.gpu
+def test_sgd_master_weights_accumulate_small_steps_gpu():
+    from singa_amd import device
+    dev = device.create_cuda_gpu()
+    assert abs(_half_sgd_drift(dev, True) - (1.0 - 200 * 1e-4)) < 2e-3
+    assert _half_sgd_drift(dev, False) == 1.0
+
+
+def _sgd16_vs_fp32(dev, master):
+    """Ten momentum steps on 16-bit parameters with 16-bit hyper-parameter
+    tensors (lr, momentum, dampening, weight decay are converted on the fly);
+    distance to the float32 trajectory on the host."""
+    import numpy as np
+    from singa_amd import device, opt, tensor
+
+    def run(d, dt, master_weights):
+        rng = np.random.RandomState(0)
+        npdt = np.float16 if dt == tensor.float16 else np.float32
+        ps = []
+        for i, shp in enumerate([(50, 20, 5, 5), (500,), (80, 50), (7,)]):
+            p = tensor.from_numpy((rng.randn(*shp) * 0.1).astype(npdt), d)
+            p.name = "p%d" % i
+            ps.append(p)
+        sgd = opt.SGD(lr=0.005, momentum=0.9, weight_decay=1e-5, dtype=dt,
+                      master_weights=master_weights)
+        for _ in range(10):
+            gs = [tensor.from_numpy(
+                (rng.randn(*p.shape) * 0.05).astype(npdt), d) for p in ps]
+            sgd.apply_many(list(zip(ps, gs)))
+            sgd.step()
+        return [tensor.to_numpy(p).astype(np.float32) for p in ps]
+
+    ref = run(device.get_default_device(), tensor.float32, False)
+    out = run(dev, tensor.float16, master)
+    return max(float(np.abs(a - b).max()) for a, b in zip(out, ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("master", [False, True])
+def test_sgd_16bit_hyper_parameters_gpu(master):
+    from singa_amd import device
+    assert _sgd16_vs_fp32(device.create_cuda_gpu(), master) < 2e-3
+
+
+@pytest.mark.parametrize("master", [False, True])
+def test_sgd_16bit_hyper_parameters_cpu(master):
+    from singa_amd import device
+    assert _sgd16_vs_fp32(device.get_default_device(), master) < 2e-3

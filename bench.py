@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16"])
+    ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "bf16"])
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--bucket", type=int, default=8 * 1024 * 1024,
@@ -64,10 +64,17 @@ def main():
     rs = np.random.RandomState(1234 + rank)
     x = rs.randn(B, 3, S, S).astype(np.float32)
     y = rs.randint(0, 1000, B).astype(np.int32)
-    dt = tensor.float32 if args.dtype == "fp32" else tensor.float16
-    tx = tensor.Tensor((B, 3, S, S), dev, dt)
+    dt = {"fp32": tensor.float32, "fp16": tensor.float16,
+          "bf16": tensor.bfloat16}[args.dtype]
     ty = tensor.Tensor((B,), dev, tensor.int32)
-    tx.copy_from_numpy(x.astype(np.float16) if dt == tensor.float16 else x)
+    if dt == tensor.bfloat16:      # numpy has no bfloat16: convert on device
+        tx = tensor.Tensor((B, 3, S, S), dev, tensor.float32)
+        tx.copy_from_numpy(x)
+        tx = tx.as_type(dt)
+    else:
+        tx = tensor.Tensor((B, 3, S, S), dev, dt)
+        tx.copy_from_numpy(x.astype(np.float16) if dt == tensor.float16
+                           else x)
     ty.copy_from_numpy(y)
 
     model = getattr(resnet, args.model)(num_channels=3, num_classes=1000)
@@ -95,7 +102,8 @@ def main():
                          dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_val = float(tensor.to_numpy(loss).reshape(-1)[0])
+    loss_val = float(tensor.to_numpy(loss.as_type(tensor.float32))
+                     .reshape(-1)[0])
     if rank == 0:
         value = args.steps * B * world / elapsed
         base = BASELINE_IMG_S.get(world)

@@ -99,3 +99,31 @@ def test_half_precision_training_step():
     dev.ResetGraph()
     assert np.all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_bfloat16_training_step():
+    """bf16 activations / weights (an addition over the reference's fp16 mode):
+    bf16 MFMA convolutions and GEMMs with float accumulation, float32
+    BatchNorm parameters, float32 master weights in the optimizer."""
+    from singa_amd import device
+    dev = device.create_cuda_gpu()
+    rs = np.random.RandomState(0)
+    x = rs.randn(4, 3, 224, 224).astype(np.float32)
+    y = rs.randint(0, 10, 4).astype(np.int32)
+    tx = tensor.Tensor(device=dev, data=x).as_type(tensor.bfloat16)
+    ty = tensor.Tensor(device=dev, data=y)
+    assert tx.dtype == tensor.bfloat16
+    m = models.create("resnet18", num_classes=10)
+    m.set_optimizer(opt.SGD(lr=0.01, momentum=0.9))
+    m.compile([tx], is_train=True, use_graph=True, sequential=False)
+    losses = []
+    for _ in range(4):
+        out, loss = m(tx, ty, 'plain', None)
+        assert out.dtype == tensor.bfloat16
+        losses.append(float(tensor.to_numpy(loss.as_type(tensor.float32))
+                            .reshape(-1)[0]))
+    dev.EnableGraph(False)
+    dev.ResetGraph()
+    assert np.all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses

@@ -56,7 +56,10 @@ def main():
     sgd = opt.DistOpt(opt.SGD(lr=0.1, momentum=0.9, weight_decay=1e-5))
     sgd.threshold = args.bucket
     local_rank = sgd.local_rank
-    dev = device.create_cuda_gpu_on(local_rank)
+    # one rank per GPU; the modulo only matters for rehearsals that put
+    # several gloo ranks on one device (SINGA_DIST_BACKEND=gloo)
+    dev = device.create_cuda_gpu_on(
+        local_rank % max(1, torch.cuda.device_count()))
     dev.SetVerbosity(args.verbosity)
     dev.SetSkipIteration(5)
 

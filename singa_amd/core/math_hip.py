@@ -665,24 +665,21 @@ class HipMath(object):
 
     # ---- collectives support (reference src/io/communicator.cc) ----------------------------
     def pack_plan(self, views):
-        """Device table of (pointer, offset, count) rows for the multi-tensor
-        pack / unpack kernels."""
-        rows, off = [], 0
-        for v in views:
-            rows.append([v.data_ptr(), off, v.numel()])
-            off += v.numel()
-        table = torch.tensor(rows, dtype=torch.int64).to(self.dev.torch_device)
-        return (table, len(rows), off)
+        """(pointers, element counts, total) of the tensors of one bucket, in
+        bucket order.  Host data only: the kernels receive the entries in
+        their argument block."""
+        return ([v.data_ptr() for v in views], [v.numel() for v in views],
+                sum(v.numel() for v in views))
 
     def pack(self, plan, views, bucket):
-        table, n, total = plan
-        self.k.pack(_code(views[0]), _code(bucket), table.data_ptr(), n,
-                    bucket.data_ptr(), total, self._s())
+        ptrs, counts, _ = plan
+        self.k.pack(_code(views[0]), _code(bucket), ptrs, counts,
+                    bucket.data_ptr(), self._s())
 
     def unpack(self, plan, bucket, views, scale):
-        table, n, total = plan
-        self.k.unpack(_code(bucket), _code(views[0]), table.data_ptr(), n,
-                      bucket.data_ptr(), total, float(scale), self._s())
+        ptrs, counts, _ = plan
+        self.k.unpack(_code(bucket), _code(views[0]), ptrs, counts,
+                      bucket.data_ptr(), float(scale), self._s())
 
     def sparsify_threshold(self, x, thr):
         """(values, indices, count) of the entries with |x| >= thr, compacted

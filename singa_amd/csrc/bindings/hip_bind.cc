@@ -374,18 +374,23 @@ PYBIND11_MODULE(_hip, m) {
   });
 
   // ---- communication helpers ----------------------------------------------------------------------------
-  m.def("pack_entry_size", []() { return sizeof(PackEntry); });
-  m.def("pack", [](int src_dt, int dst_dt, uintptr_t table, int n,
-                   uintptr_t bucket, int64_t total, uintptr_t s) {
-    check(sa_pack(src_dt, dst_dt, (const PackEntry *)CP(table), n, P(bucket),
-                  total, S(s)),
+  m.def("pack", [](int src_dt, int dst_dt, std::vector<uintptr_t> ptrs,
+                   std::vector<int64_t> counts, uintptr_t bucket, uintptr_t s) {
+    if (ptrs.size() != counts.size())
+      throw std::invalid_argument("pack: list lengths differ");
+    check(sa_pack(src_dt, dst_dt, (int)ptrs.size(),
+                  reinterpret_cast<void *const *>(ptrs.data()), counts.data(),
+                  P(bucket), S(s)),
           "pack");
   });
-  m.def("unpack", [](int src_dt, int dst_dt, uintptr_t table, int n,
-                     uintptr_t bucket, int64_t total, float scale,
+  m.def("unpack", [](int src_dt, int dst_dt, std::vector<uintptr_t> ptrs,
+                     std::vector<int64_t> counts, uintptr_t bucket, float scale,
                      uintptr_t s) {
-    check(sa_unpack(src_dt, dst_dt, (const PackEntry *)CP(table), n, CP(bucket),
-                    total, scale, S(s)),
+    if (ptrs.size() != counts.size())
+      throw std::invalid_argument("unpack: list lengths differ");
+    check(sa_unpack(src_dt, dst_dt, (int)ptrs.size(),
+                    reinterpret_cast<void *const *>(ptrs.data()),
+                    counts.data(), CP(bucket), scale, S(s)),
           "unpack");
   });
   m.def("sparsify_threshold", [](uintptr_t x, float thr, uintptr_t vals,

@@ -13,27 +13,31 @@
 
 namespace sa {
 
-// grid.y = tensor index, grid.x strides over that tensor's elements
+// grid.y = tensor index, grid.x strides over that tensor's elements.  The
+// (pointer, offset, count) entries travel in the kernel argument block: no
+// device-side table whose lifetime would have to span the side streams, no
+// host-to-device copy, and a captured launch carries them with it.
 template <typename TS, typename TD>
-__global__ void pack_kernel(const PackEntry *__restrict__ table,
-                            TD *__restrict__ bucket) {
-  const PackEntry e = table[blockIdx.y];
-  const TS *src = (const TS *)e.ptr;
-  TD *dst = bucket + e.offset;
+__global__ void pack_kernel(PackBatch batch, TD *__restrict__ bucket) {
+  const int t = blockIdx.y;
+  const TS *src = (const TS *)batch.ptr[t];
+  TD *dst = bucket + batch.offset[t];
+  const int64_t n = batch.count[t];
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e.count;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += step)
     dst[i] = from_f<TD>(to_f<TS>(src[i]));
 }
 
 template <typename TS, typename TD>
-__global__ void unpack_kernel(const PackEntry *__restrict__ table,
-                              const TS *__restrict__ bucket, float scale) {
-  const PackEntry e = table[blockIdx.y];
-  TD *dst = (TD *)e.ptr;
-  const TS *src = bucket + e.offset;
+__global__ void unpack_kernel(PackBatch batch, const TS *__restrict__ bucket,
+                              float scale) {
+  const int t = blockIdx.y;
+  TD *dst = (TD *)batch.ptr[t];
+  const TS *src = bucket + batch.offset[t];
+  const int64_t n = batch.count[t];
   const int64_t step = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < e.count;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += step)
     dst[i] = from_f<TD>(to_f<TS>(src[i]) * scale);
 }
@@ -148,24 +152,42 @@ __global__ void scatter_add_sparse_kernel(const float *__restrict__ vals,
   }
 }
 
-template <typename TS, typename TD>
-int launch_pack(const PackEntry *table, int nt, void *bucket, int64_t total,
-                hipStream_t s) {
-  int64_t per = (total + nt - 1) / nt;
-  int gx = (int)i64min(i64max((per + 1023) / 1024, 1), 64);
-  hipLaunchKernelGGL((pack_kernel<TS, TD>), dim3(gx, nt), dim3(256), 0, s,
-                     table, (TD *)bucket);
+// one launch per kPackMax tensors; offsets are the running sum of the counts
+template <typename TS, typename TD, bool PACK>
+int launch_packing(int nt, void *const *ptrs, const int64_t *counts,
+                   void *bucket, float scale, hipStream_t s) {
+  int64_t off = 0;
+  for (int first = 0; first < nt; first += kPackMax) {
+    PackBatch b;
+    const int n = nt - first < kPackMax ? nt - first : kPackMax;
+    int64_t most = 1;
+    for (int i = 0; i < n; ++i) {
+      b.ptr[i] = ptrs[first + i];
+      b.offset[i] = off;
+      b.count[i] = counts[first + i];
+      off += counts[first + i];
+      most = i64max(most, counts[first + i]);
+    }
+    const int gx = (int)i64min((most + 1023) / 1024, 64);
+    if (PACK)
+      hipLaunchKernelGGL((pack_kernel<TS, TD>), dim3(gx, n), dim3(256), 0, s,
+                         b, (TD *)bucket);
+    else
+      hipLaunchKernelGGL((unpack_kernel<TS, TD>), dim3(gx, n), dim3(256), 0, s,
+                         b, (const TS *)bucket, scale);
+  }
   return 0;
 }
 
 template <typename TS, typename TD>
-int launch_unpack(const PackEntry *table, int nt, const void *bucket,
-                  int64_t total, float scale, hipStream_t s) {
-  int64_t per = (total + nt - 1) / nt;
-  int gx = (int)i64min(i64max((per + 1023) / 1024, 1), 64);
-  hipLaunchKernelGGL((unpack_kernel<TS, TD>), dim3(gx, nt), dim3(256), 0, s,
-                     table, (const TS *)bucket, scale);
-  return 0;
+int launch_pack(int nt, void *const *ptrs, const int64_t *counts, void *bucket,
+                float scale, hipStream_t s) {
+  return launch_packing<TS, TD, true>(nt, ptrs, counts, bucket, scale, s);
+}
+template <typename TS, typename TD>
+int launch_unpack(int nt, void *const *ptrs, const int64_t *counts,
+                  void *bucket, float scale, hipStream_t s) {
+  return launch_packing<TS, TD, false>(nt, ptrs, counts, bucket, scale, s);
 }
 
 }  // namespace sa
@@ -182,17 +204,18 @@ using namespace sa;
   if (src_dtype == kBF16 && dst_dtype == kBF16) return FN<__hip_bfloat16, __hip_bfloat16>(__VA_ARGS__); \
   return -1;
 
-int sa_pack(int src_dtype, int dst_dtype, const PackEntry *table,
-            int n_tensors, void *bucket, int64_t total, hipStream_t s) {
+int sa_pack(int src_dtype, int dst_dtype, int n_tensors, void *const *ptrs,
+            const int64_t *counts, void *bucket, hipStream_t s) {
   if (n_tensors <= 0) return 0;
-  PAIR_DISPATCH(launch_pack, table, n_tensors, bucket, total, s)
+  PAIR_DISPATCH(launch_pack, n_tensors, ptrs, counts, bucket, 1.f, s)
 }
 
-int sa_unpack(int src_dtype, int dst_dtype, const PackEntry *table,
-              int n_tensors, const void *bucket, int64_t total, float scale,
+int sa_unpack(int src_dtype, int dst_dtype, int n_tensors, void *const *ptrs,
+              const int64_t *counts, const void *bucket, float scale,
               hipStream_t s) {
   if (n_tensors <= 0) return 0;
-  PAIR_DISPATCH(launch_unpack, table, n_tensors, bucket, total, scale, s)
+  PAIR_DISPATCH(launch_unpack, n_tensors, ptrs, counts,
+                const_cast<void *>(bucket), scale, s)
 }
 
 int sa_sparsify_threshold(const float *x, float thr, float *vals, int *idx,

@@ -235,17 +235,21 @@ int sa_lstm_cell_bwd(int dtype, const void *dh, const void *dc_next,
                      int64_t hidden, hipStream_t s);
 
 // ---- comm.hip -------------------------------------------------------------------------------------------------------
-// many small tensors <-> one flat bucket in a single launch.  `table` is a
-// device array of n_tensors entries {ptr, offset, count}.
-struct PackEntry {
-  void *ptr;
-  int64_t offset;
-  int64_t count;
+// many small tensors <-> one flat bucket: tensor i (counts[i] elements at
+// ptrs[i]) occupies the bucket from the sum of the counts before it.  The
+// entries are passed in the kernel argument block, kPackMax per launch.
+namespace sa {
+constexpr int kPackMax = 64;
+struct PackBatch {
+  void *ptr[kPackMax];
+  int64_t offset[kPackMax];
+  int64_t count[kPackMax];
 };
-int sa_pack(int src_dtype, int dst_dtype, const PackEntry *table,
-            int n_tensors, void *bucket, int64_t total, hipStream_t s);
-int sa_unpack(int src_dtype, int dst_dtype, const PackEntry *table,
-              int n_tensors, const void *bucket, int64_t total, float scale,
+}  // namespace sa
+int sa_pack(int src_dtype, int dst_dtype, int n_tensors, void *const *ptrs,
+            const int64_t *counts, void *bucket, hipStream_t s);
+int sa_unpack(int src_dtype, int dst_dtype, int n_tensors, void *const *ptrs,
+              const int64_t *counts, const void *bucket, float scale,
               hipStream_t s);
 // threshold sparsification helpers
 // the k entries of largest magnitude of x[0..n), in no particular order;

@@ -57,6 +57,9 @@ class NcclIdHolder(object):
         return "tcp://%s:%d" % (self.addr, self.port)
 
 
+_DEBUG = os.environ.get("SINGA_DIST_DEBUG", "0") == "1"
+
+
 def _env_int(names, default):
     for n in names:
         v = os.environ.get(n)
@@ -100,14 +103,20 @@ class Communicator(object):
         force = os.environ.get("SINGA_DIST_FORCE", "0") == "1"
         if (self.world_size > 1 or force) and not dist.is_initialized():
             if self._gpu:
-                torch.cuda.set_device(self.local_rank)
+                # more ranks than devices only happens in rehearsals with
+                # SINGA_DIST_BACKEND=gloo (RCCL refuses two ranks per GPU)
+                torch.cuda.set_device(
+                    self.local_rank % torch.cuda.device_count())
+            backend = os.environ.get("SINGA_DIST_BACKEND") or (
+                "nccl" if self._gpu else "gloo")
             dist.init_process_group(
-                backend="nccl" if self._gpu else "gloo",
+                backend=backend,
                 init_method=init_method, rank=self.global_rank,
                 world_size=self.world_size)
             self._owns_group = True
         # without a process group a lone rank's all-reduce is the identity
         self._active = dist.is_initialized()
+        self._host_backend = self._active and dist.get_backend() != "nccl"
         self._dev = None          # device of the last synchronised tensors
         self._blocks = []         # their blocks: what wait() orders against
         self._buffers = {}        # (slot, dtype) -> flat bucket
@@ -146,10 +155,33 @@ class Communicator(object):
 
     def _all_reduce(self, flat):
         if self._active:
+            if _DEBUG:
+                # SINGA_DIST_DEBUG=1: drain the device first and log the
+                # sequence of collectives (to compare across ranks)
+                if flat.is_cuda:
+                    torch.cuda.synchronize(flat.device)
+                self._seq = getattr(self, "_seq", 0) + 1
+                before = float(flat.float().abs().sum())
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                print("  [rank %d] all_reduce #%d numel %d |x| %.6g -> %.6g" % (
+                    self.global_rank, self._seq, flat.numel(), before,
+                    float(flat.float().abs().sum())), flush=True)
+                return
+            self._drain_for_host_backend(flat)
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+    def _drain_for_host_backend(self, t):
+        """gloo moves device tensors through the host: finish what the
+        collective's stream has queued first, so the transfer never waits on
+        the device from inside the backend's worker thread (two ranks sharing
+        one GPU were seen to stall there).  RCCL collectives are stream
+        ordered and need nothing."""
+        if t.is_cuda and self._host_backend:
+            torch.cuda.current_stream(t.device).synchronize()
 
     def _all_gather(self, out_list, flat):
         if self._active:
+            self._drain_for_host_backend(flat)
             dist.all_gather(out_list, flat)
         else:
             out_list[0].copy_(flat)
@@ -168,6 +200,21 @@ class Communicator(object):
         if dev.lang() == 0:
             return None
         return dev.stream_pack, dev.stream_comm, dev.stream_unpack
+
+    @staticmethod
+    def _operand_views(dev, state, ts):
+        """Flat views of a collective's operands.  A recorded step is replayed
+        as captured hipGraphs around the collectives, which run eagerly: the
+        memory the captured kernels write is the storage the operands had
+        while the graph was being captured, so those views are kept and used
+        at every replay (by then the scheduler has released the blocks, and
+        asking them again would hand out fresh, unrelated storage)."""
+        if dev.phase == "replay" and "views" in state:
+            return state["views"]
+        views = [x.flat()[:x.Size()] for x in ts]
+        if dev.phase == "capture":
+            state["views"] = views
+        return views
 
     def _run_pipeline(self, dev, stages):
         """Run ``stages`` = [(which_stream, fn), ...] one after another, each
@@ -197,10 +244,12 @@ class Communicator(object):
         if not self._active:
             return
 
+        state = {}
+
         def body(x):
+            flat = self._operand_views(dev, state, [x])[0]
             if dev.phase == "capture":
                 return
-            flat = x.flat()[:x.Size()]
             self._run_pipeline(dev, [("comm", lambda: self._all_reduce(flat))])
 
         tc._submit(dev, "Dist_s_synch_allreduce", body, [], [t])
@@ -242,7 +291,7 @@ class Communicator(object):
         def body(*ts):
             tdt = dtypes.to_torch(ts[0].data_type())
             wdt = wire if wire is not None else tdt
-            views = [x.flat()[:x.Size()] for x in ts]
+            views = self._operand_views(dev, state, ts)
             key = tuple(v.data_ptr() for v in views)
             if state.get("key") != key:
                 # operand addresses are stable under graph replay: the
@@ -299,7 +348,9 @@ class Communicator(object):
                 a, ts = ts[-1], ts[:-1]
             else:
                 a = None
-            views = [x.flat()[:x.Size()] for x in ts]
+            bound = self._operand_views(
+                dev, state, list(ts) + ([a] if a is not None else []))
+            views = bound[:len(ts)]
             key = tuple(v.data_ptr() for v in views)
             if state.get("key") != key:
                 state["key"] = key
@@ -309,7 +360,7 @@ class Communicator(object):
             m = dev.math
             plan = state["plan"]
             send = self._bucket(dev, slot, total, torch.float32)
-            av = a.flat()[:total] if a is not None else None
+            av = bound[-1][:total] if a is not None else None
             box = {}
 
             def select():

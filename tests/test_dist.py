@@ -236,3 +236,23 @@ def test_distopt_partial_update_runs_and_syncs():
     res = _spawn(_dist_train, args=("partialUpdate", False, None))
     for k in res[0]:
         assert np.all(np.isfinite(res[0][k]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_two_ranks_share_one_gpu(graph):
+    """The production data-parallel path (DistOpt buckets, pack / unpack
+    kernels, side streams, hipGraph segments with eager collectives between
+    them) with two ranks on one GPU exchanging through gloo: with identical
+    batches the averaged gradient equals the single-process one, so the loss
+    trajectories must agree."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MR_GRAPH=graph)
+    out = subprocess.run(
+        [sys.executable, "-u", os.path.join(root, "tools",
+                                            "check_multirank_gpu.py")],
+        env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "MULTIRANK-OK" in out.stdout, (
+        out.stdout[-3000:] + out.stderr[-2000:])

@@ -640,3 +640,28 @@ def test_gemm_skinny_split_reduction(maths, M, N, K):
             bias=g(bias, dev), act=1)
     want = torch.relu(0.5 * ref + 2.0 * c0.double() + bias.double())
     np.testing.assert_allclose(c.cpu().numpy(), want.numpy(), atol=3e-4)
+
+
+@pytest.mark.parametrize("wire", [torch.float32, torch.float16])
+def test_pack_unpack_bucket(maths, wire):
+    """70 tensors (more than one launch's worth of entries) into one flat
+    bucket and back, with conversion to the wire type and scaling on return."""
+    hm, cm, dev = maths
+    r = np.random.RandomState(5)
+    sizes = [int(v) for v in r.randint(1, 5000, 70)]
+    host = [rnd(n, seed=100 + i) for i, n in enumerate(sizes)]
+    views = [g(t, dev) for t in host]
+    total = sum(sizes)
+    bucket = torch.full((total + 16,), 7.0, dtype=wire, device=dev.torch_device)
+    plan = hm.pack_plan(views)
+    assert plan[2] == total
+    hm.pack(plan, views, bucket[:total])
+    flat = torch.cat(host).to(wire)
+    assert torch.equal(bucket[:total].cpu(), flat)
+    assert torch.all(bucket[total:].cpu() == 7.0)
+    outs = [torch.zeros_like(v) for v in views]
+    hm.unpack(hm.pack_plan(outs), bucket[:total], outs, 0.5)
+    for o, t in zip(outs, host):
+        np.testing.assert_allclose(o.cpu().numpy(),
+                                   (t.to(wire).float() * 0.5).numpy(),
+                                   rtol=1e-6, atol=1e-7)

@@ -220,7 +220,7 @@ int sa_unpack(int src_dtype, int dst_dtype, int n_tensors, void *const *ptrs,
 
 int sa_sparsify_threshold(const float *x, float thr, float *vals, int *idx,
                           int *count, int64_t n, int64_t cap, hipStream_t s) {
-  hipMemsetAsync(count, 0, sizeof(int), s);
+  zero_async(count, sizeof(int), s);
   if (n <= 0) return 0;
   hipLaunchKernelGGL(sparsify_threshold_kernel, dim3(grid_for(n, 256, 4)),
                      dim3(256), 0, s, x, thr, vals, idx, count, n, cap);
@@ -233,7 +233,7 @@ int sa_topk_abs(const float *x, int64_t n, int64_t k, float *vals, int *idx,
                 unsigned *work, hipStream_t s) {
   if (k <= 0) return 0;
   if (k > n || n >= ((int64_t)1 << 31)) return -2;
-  (void)hipMemsetAsync(work, 0, (kTopkState + 4) * sizeof(unsigned), s);
+  zero_async(work, (kTopkState + 4) * sizeof(unsigned), s);
   const dim3 grid(grid_for(n, 256, 8)), block(256);
   for (int pass = 0; pass < 4; ++pass) {
     hipLaunchKernelGGL(topk_hist_kernel, grid, block, 0, s, x, n, pass, work);

@@ -76,6 +76,68 @@ inline int grid_for(int64_t n, int block, int per_thread = 1) {
   return static_cast<int>(b);
 }
 
+// Zero-fill and device-to-device copy as ordinary kernels.  Inside a captured
+// hipGraph a memset / memcpy node is not reliably ordered against the kernel
+// nodes around it (a zero-fill was seen to land after the atomics it was meant
+// to precede once the device was idle at launch); a kernel node is.
+__global__ static void zero_words_kernel(uint32_t *__restrict__ p, int64_t words,
+                                         uint8_t *__restrict__ tail,
+                                         int tail_bytes) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0)
+    for (int b = 0; b < tail_bytes; ++b) tail[b] = 0;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    uint4 *p4 = reinterpret_cast<uint4 *>(p);
+    const int64_t n4 = words >> 2;
+    for (int64_t j = i; j < n4; j += step) p4[j] = make_uint4(0, 0, 0, 0);
+    for (int64_t j = (n4 << 2) + i; j < words; j += step) p[j] = 0;
+  } else {
+    for (; i < words; i += step) p[i] = 0;
+  }
+}
+
+__global__ static void copy_words_kernel(uint32_t *__restrict__ d,
+                                         const uint32_t *__restrict__ s,
+                                         int64_t words,
+                                         uint8_t *__restrict__ dtail,
+                                         const uint8_t *__restrict__ stail,
+                                         int tail_bytes) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0)
+    for (int b = 0; b < tail_bytes; ++b) dtail[b] = stail[b];
+  if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) &
+       15) == 0) {
+    uint4 *d4 = reinterpret_cast<uint4 *>(d);
+    const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
+    const int64_t n4 = words >> 2;
+    for (int64_t j = i; j < n4; j += step) d4[j] = s4[j];
+    for (int64_t j = (n4 << 2) + i; j < words; j += step) d[j] = s[j];
+  } else {
+    for (; i < words; i += step) d[i] = s[i];
+  }
+}
+
+// p must be 4-byte aligned (every tensor here is)
+inline void zero_async(void *p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return;
+  const int64_t words = (int64_t)(bytes >> 2);
+  hipLaunchKernelGGL(zero_words_kernel, dim3(grid_for(words, 256, 16)),
+                     dim3(256), 0, s, (uint32_t *)p, words,
+                     (uint8_t *)p + (words << 2), (int)(bytes & 3));
+}
+
+inline void copy_async(void *dst, const void *src, size_t bytes,
+                       hipStream_t s) {
+  if (bytes == 0) return;
+  const int64_t words = (int64_t)(bytes >> 2);
+  hipLaunchKernelGGL(copy_words_kernel, dim3(grid_for(words, 256, 16)),
+                     dim3(256), 0, s, (uint32_t *)dst, (const uint32_t *)src,
+                     words, (uint8_t *)dst + (words << 2),
+                     (const uint8_t *)src + (words << 2), (int)(bytes & 3));
+}
+
 }  // namespace sa
 
 #define SA_DISPATCH_FLOAT(dtype, T, ...)                                   \

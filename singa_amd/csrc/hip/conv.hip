@@ -834,14 +834,14 @@ void launch_conv(ConvArgs &a, int64_t out_elems, bool clear, hipStream_t s,
   const bool staged = a.splits > 1 && !kFloatOut;
   if (staged) {
     a.out = g.scratch;
-    (void)hipMemsetAsync(g.scratch, 0, (size_t)out_elems * sizeof(float), s);
+    zero_async(g.scratch, (size_t)out_elems * sizeof(float), s);
   } else if (a.splits > 1 && clear) {
     // partial sums land with atomics: start from the addend, or from zero
     const size_t bytes = (size_t)out_elems * sizeof(float);
     if (MODE == CONV_BWD_DATA && a.addend && a.addend != a.out)
-      (void)hipMemcpyAsync(a.out, a.addend, bytes, hipMemcpyDeviceToDevice, s);
+      copy_async(a.out, a.addend, bytes, s);
     else
-      (void)hipMemsetAsync(a.out, 0, bytes, s);
+      zero_async(a.out, bytes, s);
   }
   bool v1 = false;
   if (MODE != CONV_BWD_WEIGHT)
@@ -956,9 +956,9 @@ int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
   bool zeroed = false;  // dx holds its starting value (zero or the addend)
   if (untouched || classes.empty()) {
     if (addend)
-      (void)hipMemcpyAsync(dx, addend, bytes, hipMemcpyDeviceToDevice, s);
+      copy_async(dx, addend, bytes, s);
     else
-      (void)hipMemsetAsync(dx, 0, bytes, s);
+      zero_async(dx, bytes, s);
     zeroed = true;
   }
   for (size_t first = 0; first < classes.size(); first += 4) {

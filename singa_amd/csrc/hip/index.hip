@@ -67,7 +67,7 @@ int sa_index_add(int dtype, const void *dy, const int *idx, void *out,
                  hipStream_t s) {
   const int64_t total = outer * n_out * inner;
   if (dtype != kF32) return -3;
-  hipMemsetAsync(out, 0, (size_t)(outer * n_in * inner) * sizeof(float), s);
+  zero_async(out, (size_t)(outer * n_in * inner) * sizeof(float), s);
   if (total <= 0) return 0;
   hipLaunchKernelGGL((index_add_kernel<float>), dim3(grid_for(total, 256)),
                      dim3(256), 0, s, (const float *)dy, idx, (float *)out,

@@ -209,7 +209,7 @@ int sa_reduce_cols(int dtype, const void *x, void *out, int64_t rows,
   const int64_t rpb = (rows + splits - 1) / splits;
   splits = (rows + rpb - 1) / rpb;
   if (dtype == kF32) {
-    if (splits > 1) hipMemsetAsync(out, 0, cols * sizeof(float), s);
+    if (splits > 1) zero_async(out, cols * sizeof(float), s);
     hipLaunchKernelGGL((reduce_cols_kernel<float>),
                        dim3((unsigned)col_blocks, (unsigned)splits), dim3(256),
                        0, s, (const float *)x, (float *)out, rows, cols, rpb);

@@ -286,7 +286,7 @@ int sa_softmax_ce_fused_fwd(int dtype, const void *x, const void *t,
                             int64_t rows, int64_t cols, hipStream_t s) {
   if (rows <= 0) return 0;
   if (dtype != kF32) return -3;  // the loss word doubles as float accumulator
-  hipMemsetAsync(loss, 0, sizeof(float), s);
+  zero_async(loss, sizeof(float), s);
   TARGET_SWITCH(TT, {
     hipLaunchKernelGGL((softmax_ce_fused_fwd_kernel<float, TT>),
                        dim3(wave_grid(rows)), dim3(256), 0, s,

@@ -58,6 +58,10 @@ class NcclIdHolder(object):
 
 
 _DEBUG = os.environ.get("SINGA_DIST_DEBUG", "0") == "1"
+# diagnosis: bit 0 drains the device before a collective's pipeline starts,
+# bit 1 after the compute stream has been joined with the side streams, bit 2
+# skips the collective itself.  Results must not depend on any of them.
+_STRICT = int(os.environ.get("SINGA_DIST_STRICT", "0"))
 
 
 def _env_int(names, default):
@@ -154,37 +158,52 @@ class Communicator(object):
                 seen.add(id(t.block()))
 
     def _all_reduce(self, flat):
-        if self._active:
-            if _DEBUG:
-                # SINGA_DIST_DEBUG=1: drain the device first and log the
-                # sequence of collectives (to compare across ranks)
-                if flat.is_cuda:
-                    torch.cuda.synchronize(flat.device)
-                self._seq = getattr(self, "_seq", 0) + 1
-                before = float(flat.float().abs().sum())
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                print("  [rank %d] all_reduce #%d numel %d |x| %.6g -> %.6g" % (
-                    self.global_rank, self._seq, flat.numel(), before,
-                    float(flat.float().abs().sum())), flush=True)
-                return
-            self._drain_for_host_backend(flat)
+        if not self._active:
+            return
+        if _DEBUG:
+            # SINGA_DIST_DEBUG=1: log the sequence of collectives (to compare
+            # across ranks) with a checksum before and after
+            if flat.is_cuda:
+                torch.cuda.synchronize(flat.device)
+            self._seq = getattr(self, "_seq", 0) + 1
+            before = float(flat.float().abs().sum())
+        if self._staged(flat):
+            host = self._to_host(flat)
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        if _DEBUG:
+            print("  [rank %d] all_reduce #%d numel %d |x| %.6g -> %.6g" % (
+                self.global_rank, self._seq, flat.numel(), before,
+                float(flat.float().abs().sum())), flush=True)
 
-    def _drain_for_host_backend(self, t):
-        """gloo moves device tensors through the host: finish what the
-        collective's stream has queued first, so the transfer never waits on
-        the device from inside the backend's worker thread (two ranks sharing
-        one GPU were seen to stall there).  RCCL collectives are stream
-        ordered and need nothing."""
-        if t.is_cuda and self._host_backend:
-            torch.cuda.current_stream(t.device).synchronize()
+    def _staged(self, t):
+        """Device tensors with a host backend (gloo; used to rehearse the
+        multi-rank path on machines where RCCL cannot run, e.g. several ranks
+        on one GPU) go through host memory explicitly: the device is drained,
+        the collective runs on a host copy, the result is copied back on the
+        current stream.  (gloo's own device-tensor path waits for the device
+        from its worker thread, which was seen to stall with two ranks on one
+        GPU.)  RCCL collectives are stream ordered and take the tensor as is."""
+        return t.is_cuda and self._host_backend
+
+    @staticmethod
+    def _to_host(t):
+        torch.cuda.synchronize(t.device)
+        return t.cpu()
 
     def _all_gather(self, out_list, flat):
-        if self._active:
-            self._drain_for_host_backend(flat)
-            dist.all_gather(out_list, flat)
-        else:
+        if not self._active:
             out_list[0].copy_(flat)
+        elif self._staged(flat):
+            host = self._to_host(flat)
+            outs = [torch.empty_like(host) for _ in out_list]
+            dist.all_gather(outs, host)
+            for o, h in zip(out_list, outs):
+                o.copy_(h)
+        else:
+            dist.all_gather(out_list, flat)
 
     @staticmethod
     def _share(*tensors):
@@ -226,7 +245,11 @@ class Communicator(object):
                 fn()
             return
         names = {"pack": st[0], "comm": st[1], "unpack": st[2]}
+        if _STRICT & 1:
+            torch.cuda.synchronize(dev.torch_device)
         main = torch.cuda.current_stream(dev.torch_device)
+        if _STRICT & 4:
+            return          # skip the collective: graph segments + drains only
         prev = main
         for which, fn in stages:
             s = names[which]
@@ -437,5 +460,7 @@ class Communicator(object):
             main = torch.cuda.current_stream(dev.torch_device)
             for s in st:
                 main.wait_stream(s)
+            if _STRICT & 2:
+                torch.cuda.synchronize(dev.torch_device)
 
         dev.Exec(join, blocks, blocks, "Dist_wait")

@@ -239,8 +239,10 @@ def test_distopt_partial_update_runs_and_syncs():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("graph", ["1", "0"])
-def test_two_ranks_share_one_gpu(graph):
+@pytest.mark.parametrize("graph,option", [
+    ("1", "plain"), ("0", "plain"), ("1", "half"), ("1", "partialUpdate"),
+    ("1", "sparseTopK"), ("1", "sparseThreshold")])
+def test_two_ranks_share_one_gpu(graph, option):
     """The production data-parallel path (DistOpt buckets, pack / unpack
     kernels, side streams, hipGraph segments with eager collectives between
     them) with two ranks on one GPU exchanging through gloo: with identical
@@ -249,7 +251,7 @@ def test_two_ranks_share_one_gpu(graph):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MR_GRAPH=graph)
+    env = dict(os.environ, MR_GRAPH=graph, MR_OPTION=option)
     out = subprocess.run(
         [sys.executable, "-u", os.path.join(root, "tools",
                                             "check_multirank_gpu.py")],

@@ -16,6 +16,8 @@ import sys
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# plain | half | partialUpdate | sparseTopK | sparseThreshold
+OPTION = os.environ.get("MR_OPTION", "plain")
 sys.path.insert(0, ROOT)
 
 
@@ -43,7 +45,8 @@ def train(dist, steps=6):
             # a step stuck for a minute prints where, then the rank exits
             faulthandler.cancel_dump_traceback_later()
             faulthandler.dump_traceback_later(60, exit=True)
-        _, loss = m(tx, ty, "plain", None)
+        _, loss = m(tx, ty, OPTION if dist else "plain",
+                    0.05 if OPTION.startswith("sparse") else None)
         losses.append(float(tensor.to_numpy(loss).reshape(-1)[0]))
         print("  [%s] step %d loss %.5f" % (os.environ.get("RANK", "-"), i,
                                            losses[-1]), flush=True)
@@ -81,7 +84,15 @@ def main():
     ref = train(False)
     print("single", " ".join("%.5f" % v for v in ref))
     for r in ranks:
-        np.testing.assert_allclose(r, ref, rtol=2e-3, atol=2e-3)
+        if OPTION == "plain":
+            np.testing.assert_allclose(r, ref, rtol=2e-3, atol=2e-3)
+        elif OPTION == "half":      # fp16 on the wire
+            np.testing.assert_allclose(r, ref, rtol=5e-2, atol=5e-3)
+        else:                       # different algorithms: must still train
+            assert np.all(np.isfinite(r)) and r[-1] < r[0], r
+        if OPTION != "partialUpdate":   # (there ranks drift apart by design)
+            # split reductions use float atomics: ranks agree to rounding only
+            np.testing.assert_allclose(r, ranks[0], rtol=2e-2, atol=1e-3)
     print("MULTIRANK-OK")
     return 0
 

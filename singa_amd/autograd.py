@@ -1173,6 +1173,55 @@ def softmax(x, axis=1):
     return SoftMax(axis)(x)[0]
 
 
+class LayerNorm(Operator):
+    """y = (x - mean) / sqrt(var + eps) * scale + bias over the last
+    dimension, one kernel per direction.  The reference has no such operator:
+    models imported from ONNX run the exported chain of nine elementwise /
+    reduction nodes (python/singa/sonnx.py); the importer here maps that chain
+    (and the ONNX LayerNormalization node) onto this operator."""
+
+    def __init__(self, eps=1e-5):
+        super(LayerNorm, self).__init__()
+        self.eps = float(eps)
+
+    def forward(self, x, scale=None, bias=None):
+        y, mean, rstd = singa.LayerNormForward(x, scale, bias, self.eps)
+        if training:
+            self.cache = (x, scale, mean, rstd, bias is not None)
+        return y
+
+    def backward(self, dy):
+        x, scale, mean, rstd, has_bias = self.cache
+        dx, ds, db = singa.LayerNormBackward(dy, x, scale, mean, rstd,
+                                             scale is not None)
+        if scale is None:
+            return dx
+        return (dx, ds, db) if has_bias else (dx, ds)
+
+
+def layer_norm(x, scale=None, bias=None, eps=1e-5):
+    args = [x] + [t for t in (scale, bias) if t is not None]
+    assert bias is None or scale is not None, "a bias needs a scale"
+    return LayerNorm(eps)(*args)[0]
+
+
+class Gelu(Operator):
+    """x * Phi(x) with the exact (erf) normal CDF, one kernel per direction
+    (exported by transformer models as Div, Erf, Add, Mul, Mul)."""
+
+    def forward(self, x):
+        if training:
+            self.input = x
+        return singa.GeluForward(x)
+
+    def backward(self, dy):
+        return singa.GeluBackward(dy, self.input)
+
+
+def gelu(x):
+    return Gelu()(x)[0]
+
+
 class BinaryCrossEntropy(Operator):
     """-mean_batch sum(t log(x + eps) + (1 - t) log(1 - x + eps))."""
     takes_scalar_dy = True

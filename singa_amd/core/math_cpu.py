@@ -349,6 +349,44 @@ class CpuMath(object):
         c = vals.numel() if cnt is None else min(int(cnt.item()), vals.numel())
         dense.index_add_(0, idx[:c].long(), -vals[:c])
 
+    # ---- layer norm / gelu ------------------------------------------------------
+    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, eps):
+        xf = x.float()
+        D = x.shape[-1]
+        m = xf.mean(dim=-1, keepdim=True)
+        v = ((xf - m) ** 2).mean(dim=-1, keepdim=True)
+        rs = torch.rsqrt(v + eps)
+        out = (xf - m) * rs
+        if gamma is not None:
+            out = out * gamma.float()
+        if beta is not None:
+            out = out + beta.float()
+        y.copy_(out)
+        mean.copy_(m.reshape(-1))
+        rstd.copy_(rs.reshape(-1))
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta):
+        D = x.shape[-1]
+        xf, df = x.float().reshape(-1, D), dy.float().reshape(-1, D)
+        xh = (xf - mean.reshape(-1, 1)) * rstd.reshape(-1, 1)
+        gd = df * gamma.float().reshape(1, D) if gamma is not None else df
+        s1 = gd.mean(dim=1, keepdim=True)
+        s2 = (gd * xh).mean(dim=1, keepdim=True)
+        dx.copy_((rstd.reshape(-1, 1) * (gd - s1 - xh * s2)).reshape(x.shape))
+        if dgamma is not None:
+            dgamma.copy_((df * xh).sum(dim=0))
+            dbeta.copy_(df.sum(dim=0))
+
+    def gelu_fwd(self, x, y):
+        xf = x.float()
+        y.copy_(0.5 * xf * (1.0 + torch.erf(xf * 0.7071067811865476)))
+
+    def gelu_bwd(self, dy, x, dx):
+        xf = x.float()
+        cdf = 0.5 * (1.0 + torch.erf(xf * 0.7071067811865476))
+        pdf = 0.3989422804014327 * torch.exp(-0.5 * xf * xf)
+        dx.copy_(dy.float() * (cdf + xf * pdf))
+
     # ---- fused optimiser step --------------------------------------------------------------------------
     def sgd_update_multi(self, ps, gs, bufs, lr, momentum, dampening,
                          weight_decay, nesterov, scale, masters=None):

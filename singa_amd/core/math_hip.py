@@ -757,6 +757,50 @@ class HipMath(object):
             hyper[2].data_ptr(), hyper[3].data_ptr(), 1 if nesterov else 0,
             float(scale), self._s())
 
+    # ---- layer norm / gelu ------------------------------------------------------
+    def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, eps):
+        """Rows = all leading dimensions, normalised over the last one."""
+        D = x.shape[-1]
+        rows = x.numel() // D
+        x = self._contig(x)
+        g = self._contig(gamma) if gamma is not None else None
+        b = self._contig(beta) if beta is not None else None
+        self.k.layernorm_fwd(_code(x), x.data_ptr(),
+                             g.data_ptr() if g is not None else 0,
+                             b.data_ptr() if b is not None else 0,
+                             y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                             rows, D, float(eps), self._s())
+
+    def layernorm_bwd(self, dy, x, gamma, mean, rstd, dx, dgamma, dbeta):
+        D = x.shape[-1]
+        rows = x.numel() // D
+        dy, x = self._contig(dy), self._contig(x)
+        g = self._contig(gamma) if gamma is not None else None
+        want = dgamma is not None
+        # the parameter gradients are accumulated in float
+        fg = fb = None
+        if want:
+            fg = dgamma if dgamma.dtype == torch.float32 else self._tmp(D)
+            fb = dbeta if dbeta.dtype == torch.float32 else self._tmp(D)
+        self.k.layernorm_bwd(_code(x), dy.data_ptr(), x.data_ptr(),
+                             g.data_ptr() if g is not None else 0,
+                             mean.data_ptr(), rstd.data_ptr(), dx.data_ptr(),
+                             fg.data_ptr() if want else 0,
+                             fb.data_ptr() if want else 0, rows, D, self._s())
+        if want and fg is not dgamma:
+            self.copy(fg, dgamma)
+            self.copy(fb, dbeta)
+
+    def gelu_fwd(self, x, y):
+        x = self._contig(x)
+        self.k.gelu_fwd(_code(x), x.data_ptr(), y.data_ptr(), x.numel(),
+                        self._s())
+
+    def gelu_bwd(self, dy, x, dx):
+        dy, x = self._contig(dy), self._contig(x)
+        self.k.gelu_bwd(_code(x), dy.data_ptr(), x.data_ptr(), dx.data_ptr(),
+                        x.numel(), self._s())
+
     # ---- recurrent cells ---------------------------------------------------------------------------------------------
     def lstm_cell_fwd(self, gates, c_prev, c, h, acts):
         self.k.lstm_cell_fwd(_code(gates), gates.data_ptr(), c_prev.data_ptr(),

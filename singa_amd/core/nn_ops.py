@@ -309,3 +309,82 @@ def PoolingBackward(ph, dy, x, y):
 
 GpuPoolingForward = CpuPoolingForward = PoolingForward
 GpuPoolingBackward = CpuPoolingBackward = PoolingBackward
+
+
+# ---------------------------------------------------------------------------
+# layer normalisation over the last dimension, erf-form GELU
+# ---------------------------------------------------------------------------
+def LayerNormForward(x, gamma, beta, eps=1e-5):
+    """-> (y, mean, rstd); mean / rstd are float32 vectors with one entry per
+    row (all leading dimensions flattened), kept for the backward pass."""
+    xs = _contig(x)
+    dev = x.device()
+    D = x.shape()[-1]
+    rows = max(1, x.Size() // max(D, 1))
+    y = Tensor(x.shape(), dev, x.data_type())
+    mean = Tensor([rows], dev, dtypes.kFloat32)
+    rstd = Tensor([rows], dev, dtypes.kFloat32)
+    eps = float(eps)
+    ins = [xs] + [t for t in (gamma, beta) if t is not None]
+    has_g, has_b = gamma is not None, beta is not None
+
+    def body(*a):
+        xx = a[0]
+        k = 1
+        g = a[k].view() if has_g else None
+        k += has_g
+        b = a[k].view() if has_b else None
+        k += has_b
+        o, m, r = a[k:k + 3]
+        xx._dev.math.layernorm_fwd(xx.view(), g, b, o.view(), m.view(),
+                                   r.view(), eps)
+
+    _submit(dev, "LayerNormForward", body, ins, [y, mean, rstd])
+    return y, mean, rstd
+
+
+def LayerNormBackward(dy, x, gamma, mean, rstd, with_params=True):
+    """-> [dx, dgamma, dbeta] (the last two None unless ``with_params``)."""
+    d, xs = _contig(dy), _contig(x)
+    dev = x.device()
+    D = x.shape()[-1]
+    dx = Tensor(x.shape(), dev, x.data_type())
+    pdt = gamma.data_type() if gamma is not None else x.data_type()
+    outs = [dx]
+    dgamma = dbeta = None
+    if with_params:
+        dgamma = Tensor([D], dev, pdt)
+        dbeta = Tensor([D], dev, pdt)
+        outs += [dgamma, dbeta]
+    has_g = gamma is not None
+    ins = [d, xs] + ([gamma] if has_g else []) + [mean, rstd]
+
+    def body(*a):
+        dd, xx = a[0], a[1]
+        g = a[2].view() if has_g else None
+        m, r = a[2 + has_g], a[3 + has_g]
+        o = a[4 + has_g:]
+        xx._dev.math.layernorm_bwd(
+            dd.view(), xx.view(), g, m.view(), r.view(), o[0].view(),
+            o[1].view() if with_params else None,
+            o[2].view() if with_params else None)
+
+    _submit(dev, "LayerNormBackward", body, ins, outs)
+    return [dx, dgamma, dbeta]
+
+
+def GeluForward(x):
+    xs = _contig(x)
+    y = Tensor(x.shape(), x.device(), x.data_type())
+    _submit(x.device(), "GeluForward",
+            lambda a, o: a._dev.math.gelu_fwd(a.view(), o.view()), [xs], [y])
+    return y
+
+
+def GeluBackward(dy, x):
+    d, xs = _contig(dy), _contig(x)
+    dx = Tensor(x.shape(), x.device(), x.data_type())
+    _submit(x.device(), "GeluBackward",
+            lambda a, b, o: a._dev.math.gelu_bwd(a.view(), b.view(), o.view()),
+            [d, xs], [dx])
+    return dx

@@ -180,6 +180,34 @@ PYBIND11_MODULE(_hip, m) {
           "gemm_splitk_reduce");
   });
 
+  // ---- layer norm / gelu ------------------------------------------------------
+  m.def("layernorm_fwd", [](int dt, uintptr_t x, uintptr_t gamma, uintptr_t beta,
+                            uintptr_t y, uintptr_t mean, uintptr_t rstd,
+                            int64_t rows, int D, float eps, uintptr_t s) {
+    check(sa_layernorm_fwd(dt, CP(x), CP(gamma), CP(beta), P(y),
+                           (float *)P(mean), (float *)P(rstd), rows, D, eps,
+                           S(s)),
+          "layernorm_fwd");
+  });
+  m.def("layernorm_bwd", [](int dt, uintptr_t dy, uintptr_t x, uintptr_t gamma,
+                            uintptr_t mean, uintptr_t rstd, uintptr_t dx,
+                            uintptr_t dgamma, uintptr_t dbeta, int64_t rows,
+                            int D, uintptr_t s) {
+    check(sa_layernorm_bwd(dt, CP(dy), CP(x), CP(gamma),
+                           (const float *)CP(mean), (const float *)CP(rstd),
+                           P(dx), (float *)P(dgamma), (float *)P(dbeta), rows,
+                           D, S(s)),
+          "layernorm_bwd");
+  });
+  m.def("gelu_fwd", [](int dt, uintptr_t x, uintptr_t y, int64_t n,
+                       uintptr_t s) {
+    check(sa_gelu_fwd(dt, CP(x), P(y), n, S(s)), "gelu_fwd");
+  });
+  m.def("gelu_bwd", [](int dt, uintptr_t dy, uintptr_t x, uintptr_t dx,
+                       int64_t n, uintptr_t s) {
+    check(sa_gelu_bwd(dt, CP(dy), CP(x), P(dx), n, S(s)), "gelu_bwd");
+  });
+
   // ---- convolution -----------------------------------------------------------------
   py::class_<ConvGeom>(m, "ConvGeom")
       .def(py::init([](int N, int C, int H, int W, int K, int R, int Sw, int P_,

@@ -106,6 +106,19 @@ int sa_gemm_splitk_reduce(int dtype, const float *part, int splits, int64_t M,
                           int64_t ldc, const void *bias, int act,
                           hipStream_t s);
 
+// ---- layernorm.hip ------------------------------------------------------------------------
+// x, y, gamma, beta share dtype; gamma / beta may be null; mean / rstd: float[rows]
+int sa_layernorm_fwd(int dtype, const void *x, const void *gamma,
+                     const void *beta, void *y, float *mean, float *rstd,
+                     int64_t rows, int D, float eps, hipStream_t s);
+int sa_layernorm_bwd(int dtype, const void *dy, const void *x,
+                     const void *gamma, const float *mean, const float *rstd,
+                     void *dx, float *dgamma, float *dbeta, int64_t rows, int D,
+                     hipStream_t s);
+int sa_gelu_fwd(int dtype, const void *x, void *y, int64_t n, hipStream_t s);
+int sa_gelu_bwd(int dtype, const void *dy, const void *x, void *dx, int64_t n,
+                hipStream_t s);
+
 // ---- conv.hip ---------------------------------------------------------------------------------
 struct ConvGeom {
   int N, C, H, W;      // input

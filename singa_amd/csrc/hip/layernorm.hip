@@ -1,0 +1,253 @@
+// Layer normalisation over the last dimension and the erf-form GELU, each as
+// one pass over HBM per direction.
+//
+//   y = (x - mean(x)) * rsqrt(var(x) + eps) * gamma + beta        per row
+//
+// The reference has neither operator: its ONNX importer runs the exported
+// decomposition (ReduceMean, Sub, Pow, ReduceMean, Add, Sqrt, Div, Mul, Add:
+// nine kernels and eight intermediate tensors per layer norm, five for GELU;
+// python/singa/sonnx.py).  Here the importer recognises both chains and the
+// operators are also available directly (autograd.LayerNorm, autograd.Gelu).
+//
+// forward: one workgroup per row; the row is read once into registers when
+// it has at most 8 * blockDim elements (two-pass statistics on the
+// registers), otherwise it is re-read from L2.  mean and 1/std are kept in
+// float for the backward pass.
+// backward: dx per row with two row reductions; dgamma / dbeta are column
+// sums over all rows, done by a second kernel that strides rows with a
+// [8 row-lanes][32 columns] workgroup and reduces through LDS.
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sa {
+
+constexpr int kLnCache = 8;  // row elements a thread can keep in registers
+
+template <typename T>
+__global__ void layernorm_fwd_kernel(const T *__restrict__ x,
+                                     const T *__restrict__ gamma,
+                                     const T *__restrict__ beta,
+                                     T *__restrict__ y,
+                                     float *__restrict__ mean_out,
+                                     float *__restrict__ rstd_out, int64_t rows,
+                                     int D, float eps) {
+  __shared__ float smem[32];
+  const int64_t r = blockIdx.x;
+  const T *xr = x + r * D;
+  T *yr = y + r * D;
+  const bool cached = D <= kLnCache * (int)blockDim.x;
+  float v[kLnCache];
+  float sum = 0.f;
+  if (cached) {
+#pragma unroll
+    for (int k = 0; k < kLnCache; ++k) {
+      const int i = threadIdx.x + k * blockDim.x;
+      v[k] = i < D ? to_f<T>(xr[i]) : 0.f;
+      sum += v[k];
+    }
+  } else {
+    for (int i = threadIdx.x; i < D; i += blockDim.x) sum += to_f<T>(xr[i]);
+  }
+  const float mean = block_sum(sum, smem) / (float)D;
+  float sq = 0.f;
+  if (cached) {
+#pragma unroll
+    for (int k = 0; k < kLnCache; ++k) {
+      const int i = threadIdx.x + k * blockDim.x;
+      const float d = i < D ? v[k] - mean : 0.f;
+      sq += d * d;
+    }
+  } else {
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+      const float d = to_f<T>(xr[i]) - mean;
+      sq += d * d;
+    }
+  }
+  const float rstd = rsqrtf(block_sum(sq, smem) / (float)D + eps);
+  if (threadIdx.x == 0) {
+    mean_out[r] = mean;
+    rstd_out[r] = rstd;
+  }
+  if (cached) {
+#pragma unroll
+    for (int k = 0; k < kLnCache; ++k) {
+      const int i = threadIdx.x + k * blockDim.x;
+      if (i < D) {
+        const float g = gamma ? to_f<T>(gamma[i]) : 1.f;
+        const float b = beta ? to_f<T>(beta[i]) : 0.f;
+        yr[i] = from_f<T>((v[k] - mean) * rstd * g + b);
+      }
+    }
+  } else {
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+      const float g = gamma ? to_f<T>(gamma[i]) : 1.f;
+      const float b = beta ? to_f<T>(beta[i]) : 0.f;
+      yr[i] = from_f<T>((to_f<T>(xr[i]) - mean) * rstd * g + b);
+    }
+  }
+}
+
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat))
+template <typename T>
+__global__ void layernorm_bwd_dx_kernel(const T *__restrict__ dy,
+                                        const T *__restrict__ x,
+                                        const T *__restrict__ gamma,
+                                        const float *__restrict__ mean,
+                                        const float *__restrict__ rstd,
+                                        T *__restrict__ dx, int64_t rows,
+                                        int D) {
+  __shared__ float smem[32];
+  const int64_t r = blockIdx.x;
+  const T *xr = x + r * D, *dr = dy + r * D;
+  T *or_ = dx + r * D;
+  const float m = mean[r], rs = rstd[r];
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    const float g = gamma ? to_f<T>(gamma[i]) : 1.f;
+    const float gd = g * to_f<T>(dr[i]);
+    const float xh = (to_f<T>(xr[i]) - m) * rs;
+    s1 += gd;
+    s2 += gd * xh;
+  }
+  s1 = block_sum(s1, smem) / (float)D;
+  s2 = block_sum(s2, smem) / (float)D;
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    const float g = gamma ? to_f<T>(gamma[i]) : 1.f;
+    const float gd = g * to_f<T>(dr[i]);
+    const float xh = (to_f<T>(xr[i]) - m) * rs;
+    or_[i] = from_f<T>(rs * (gd - s1 - xh * s2));
+  }
+}
+
+// dgamma[c] = sum_r dy[r,c] * xhat[r,c], dbeta[c] = sum_r dy[r,c]
+// block = 32 columns x 8 row-lanes; grid.x tiles the columns, grid.y splits
+// the rows (partials combined with float atomics on zeroed outputs).
+template <typename T>
+__global__ void layernorm_bwd_param_kernel(const T *__restrict__ dy,
+                                           const T *__restrict__ x,
+                                           const float *__restrict__ mean,
+                                           const float *__restrict__ rstd,
+                                           float *__restrict__ dgamma,
+                                           float *__restrict__ dbeta,
+                                           int64_t rows, int D) {
+  __shared__ float sg[8][33], sb[8][33];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  float ag = 0.f, ab = 0.f;
+  if (c < D) {
+    for (int64_t r = (int64_t)blockIdx.y * 8 + ry; r < rows;
+         r += (int64_t)gridDim.y * 8) {
+      const float d = to_f<T>(dy[r * D + c]);
+      ag += d * (to_f<T>(x[r * D + c]) - mean[r]) * rstd[r];
+      ab += d;
+    }
+  }
+  sg[ry][cx] = ag;
+  sb[ry][cx] = ab;
+  __syncthreads();
+  if (ry == 0 && c < D) {
+    float tg = 0.f, tb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      tg += sg[k][cx];
+      tb += sb[k][cx];
+    }
+    atomicAdd(dgamma + c, tg);
+    atomicAdd(dbeta + c, tb);
+  }
+}
+
+__device__ __forceinline__ float gelu_f(float v) {
+  return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
+}
+__device__ __forceinline__ float gelu_grad_f(float v) {
+  const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752f));
+  const float pdf = 0.3989422804014327f * __expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+template <typename T>
+__global__ void gelu_fwd_kernel(const T *__restrict__ x, T *__restrict__ y,
+                                int64_t n) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += step)
+    y[i] = from_f<T>(gelu_f(to_f<T>(x[i])));
+}
+
+template <typename T>
+__global__ void gelu_bwd_kernel(const T *__restrict__ dy,
+                                const T *__restrict__ x, T *__restrict__ dx,
+                                int64_t n) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += step)
+    dx[i] = from_f<T>(to_f<T>(dy[i]) * gelu_grad_f(to_f<T>(x[i])));
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+static inline int ln_block(int D) {
+  return D >= 2048 ? 512 : (D >= 512 ? 256 : (D > 64 ? 128 : 64));
+}
+
+int sa_layernorm_fwd(int dtype, const void *x, const void *gamma,
+                     const void *beta, void *y, float *mean, float *rstd,
+                     int64_t rows, int D, float eps, hipStream_t s) {
+  if (rows <= 0 || D <= 0) return 0;
+  if (rows >= ((int64_t)1 << 31)) return -2;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3((unsigned)rows),
+                       dim3(ln_block(D)), 0, s, (const T *)x, (const T *)gamma,
+                       (const T *)beta, (T *)y, mean, rstd, rows, D, eps);
+  });
+  return 0;
+}
+
+// dgamma / dbeta: float buffers of D elements (zeroed here), or null
+int sa_layernorm_bwd(int dtype, const void *dy, const void *x,
+                     const void *gamma, const float *mean, const float *rstd,
+                     void *dx, float *dgamma, float *dbeta, int64_t rows, int D,
+                     hipStream_t s) {
+  if (rows <= 0 || D <= 0) return 0;
+  if (rows >= ((int64_t)1 << 31)) return -2;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return -5;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((layernorm_bwd_dx_kernel<T>), dim3((unsigned)rows),
+                       dim3(ln_block(D)), 0, s, (const T *)dy, (const T *)x,
+                       (const T *)gamma, mean, rstd, (T *)dx, rows, D);
+    if (dgamma) {
+      zero_async(dgamma, (size_t)D * sizeof(float), s);
+      zero_async(dbeta, (size_t)D * sizeof(float), s);
+      const int gx = (D + 31) / 32;
+      int gy = (int)i64min(i64max(1024 / gx, 1), (rows + 63) / 64);
+      if (gy < 1) gy = 1;
+      hipLaunchKernelGGL((layernorm_bwd_param_kernel<T>), dim3(gx, gy),
+                         dim3(256), 0, s, (const T *)dy, (const T *)x, mean,
+                         rstd, dgamma, dbeta, rows, D);
+    }
+  });
+  return 0;
+}
+
+int sa_gelu_fwd(int dtype, const void *x, void *y, int64_t n, hipStream_t s) {
+  if (n <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((gelu_fwd_kernel<T>), dim3(grid_for(n, 256, 4)),
+                       dim3(256), 0, s, (const T *)x, (T *)y, n);
+  });
+  return 0;
+}
+
+int sa_gelu_bwd(int dtype, const void *dy, const void *x, void *dx, int64_t n,
+                hipStream_t s) {
+  if (n <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3(grid_for(n, 256, 4)),
+                       dim3(256), 0, s, (const T *)dy, (const T *)x, (T *)dx,
+                       n);
+  });
+  return 0;
+}

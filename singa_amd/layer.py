@@ -823,6 +823,42 @@ class LSTM(RNN_Base):
 
 
 # ---- layers without parameters --------------------------------------------
+class LayerNorm(Layer):
+    """Normalisation over the last dimension with a learned scale and bias
+    (an addition over the reference's layer set; one fused kernel per
+    direction)."""
+
+    def __init__(self, eps=1e-5):
+        super(LayerNorm, self).__init__()
+        self.eps = eps
+
+    def initialize(self, x):
+        d = x.shape[-1]
+        self.scale = Tensor(shape=(d,), requires_grad=True, stores_grad=True,
+                            device=x.device, dtype=x.dtype)
+        self.scale.set_value(1.0)
+        self.bias = Tensor(shape=(d,), requires_grad=True, stores_grad=True,
+                           device=x.device, dtype=x.dtype)
+        self.bias.set_value(0.0)
+
+    def forward(self, x):
+        self.device_check(x, self.scale, self.bias)
+        return autograd.layer_norm(x, self.scale, self.bias, self.eps)
+
+    def get_params(self):
+        return {self.scale.name: self.scale, self.bias.name: self.bias}
+
+    def set_params(self, parameters):
+        self.scale.copy_from(parameters[self.scale.name])
+        self.bias.copy_from(parameters[self.bias.name])
+
+
+class Gelu(Layer):
+
+    def forward(self, x):
+        return autograd.gelu(x)
+
+
 class ReLU(Layer):
 
     def forward(self, x):

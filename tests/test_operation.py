@@ -405,3 +405,78 @@ def test_graph_keys_survive_garbage_collection():
     loss = autograd.add(autograd.mse_loss(y, tensor.Tensor(y.shape)),
                         autograd.mse_loss(z, tensor.Tensor(z.shape)))
     assert len(list(autograd.backward(loss))) == 5
+
+
+def _layernorm_ref(x, g, b, eps):
+    m = x.mean(-1, keepdims=True)
+    v = ((x - m) ** 2).mean(-1, keepdims=True)
+    return (x - m) / np.sqrt(v + eps) * g + b
+
+
+@pytest.mark.parametrize("shape", [(4, 7, 48), (3, 1000), (2, 5, 3000)])
+def test_layer_norm_forward_backward(dev, shape):
+    autograd.training = True
+    rng = np.random.RandomState(1)
+    x = rng.randn(*shape).astype(np.float32) * 2 + 0.5
+    g = rng.rand(shape[-1]).astype(np.float32) + 0.5
+    b = rng.randn(shape[-1]).astype(np.float32)
+    w = rng.randn(*shape).astype(np.float32)
+    tx = tensor.from_numpy(x, dev)
+    tx.requires_grad = True
+    tx.stores_grad = True
+    tg, tb = tensor.from_numpy(g, dev), tensor.from_numpy(b, dev)
+    for t in (tg, tb):
+        t.requires_grad = True
+        t.stores_grad = True
+    y = autograd.layer_norm(tx, tg, tb, 1e-5)
+    np.testing.assert_allclose(tensor.to_numpy(y), _layernorm_ref(x, g, b, 1e-5),
+                               rtol=1e-4, atol=1e-4)
+    loss = autograd.reduce_sum(autograd.mul(y, tensor.from_numpy(w, dev)))
+    grads = {id(p): tensor.to_numpy(gr) for p, gr in autograd.backward(loss)}
+    import torch
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    gt = torch.tensor(g, dtype=torch.float64, requires_grad=True)
+    bt = torch.tensor(b, dtype=torch.float64, requires_grad=True)
+    yt = torch.nn.functional.layer_norm(xt, (shape[-1],), gt, bt, 1e-5)
+    (yt * torch.tensor(w, dtype=torch.float64)).sum().backward()
+    np.testing.assert_allclose(grads[id(tx)], xt.grad.numpy(), rtol=2e-3,
+                               atol=2e-4)
+    np.testing.assert_allclose(grads[id(tg)], gt.grad.numpy(), rtol=2e-3,
+                               atol=2e-3)
+    np.testing.assert_allclose(grads[id(tb)], bt.grad.numpy(), rtol=2e-3,
+                               atol=2e-3)
+
+
+def test_gelu_forward_backward(dev):
+    autograd.training = True
+    import torch
+    x = np.linspace(-4, 4, 1001).astype(np.float32).reshape(7, 143)
+    tx = tensor.from_numpy(x, dev)
+    tx.requires_grad = True
+    tx.stores_grad = True
+    y = autograd.gelu(tx)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yt = torch.nn.functional.gelu(xt)
+    np.testing.assert_allclose(tensor.to_numpy(y), yt.detach().numpy(),
+                               rtol=1e-5, atol=1e-6)
+    loss = autograd.reduce_sum(y)
+    (dx,) = [tensor.to_numpy(g) for _, g in autograd.backward(loss)]
+    yt.sum().backward()
+    np.testing.assert_allclose(dx, xt.grad.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_layer_norm_layer_trains(dev):
+    from singa_amd import layer, opt
+    autograd.training = True
+    rng = np.random.RandomState(2)
+    x = tensor.from_numpy(rng.randn(16, 32).astype(np.float32), dev)
+    t = tensor.from_numpy(rng.randn(16, 32).astype(np.float32), dev)
+    ln, fc, act = layer.LayerNorm(), layer.Linear(32), layer.Gelu()
+    sgd = opt.SGD(lr=0.1)
+    losses = []
+    for _ in range(60):
+        loss = autograd.mse_loss(fc(act(ln(x))), t)
+        sgd(loss)
+        losses.append(float(tensor.to_numpy(loss).reshape(-1)[0]))
+    assert losses[-1] < 0.95 * losses[0], losses
+    assert set(ln.get_params()) == {ln.scale.name, ln.bias.name}

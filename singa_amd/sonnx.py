@@ -110,7 +110,8 @@ class SingaBackend(object):
         'And': 'And', 'Or': 'Or', 'Xor': 'Xor', 'Not': 'Not',
         'Neg': 'Negative', 'Reciprocal': 'Reciprocal', 'NonZero': 'NonZero',
         'Ceil': 'Ceil', 'Floor': 'Floor', 'Abs': 'Abs', 'Exp': 'Exp',
-        'Round': 'Rounde', 'Erf': 'Erf',
+        'Round': 'Rounde', 'Erf': 'Erf', 'LayerNormalization': 'LayerNorm',
+        'Gelu': 'Gelu',
         'Unsqueeze': 'Unsqueeze', 'ScatterElements': 'ScatterElements',
         'Cast': 'Cast', 'Split': 'Split', 'Squeeze': 'Squeeze',
         'GlobalAveragePool': 'GlobalAveragePool', 'LeakyRelu': 'LeakyRelu',
@@ -142,6 +143,13 @@ class SingaBackend(object):
         g = n.getattr
         if t in ('DepthToSpace', 'SpaceToDepth'):
             return op(g("blocksize"), _s(g("mode", "DCR")))
+        if t == 'LayerNormalization':
+            assert g("axis", -1) == -1, \
+                "LayerNormalization is supported over the last axis only"
+            return op(g("epsilon", 1e-5))
+        if t == 'Gelu':
+            assert _s(g("approximate", "none")) == "none"
+            return op()
         if t == 'Where':
             n.set_attr_inputs(n.inputs[0], 'condition')
             return op(None)
@@ -329,13 +337,18 @@ class SingaBackend(object):
                                 [d.dim_value for d in tt.shape.dim]))
         return inputs, outputs
 
+    # replace exported layer-norm / GELU chains by the fused operators
+    fuse_patterns = True
+
     @classmethod
     def _onnx_model_to_singa_ops(cls, graph, opset_version=_OPSET):
         params = cls._parse_graph_params(graph)
         inputs, outputs = cls._parse_graph_inputs_outputs(graph, params)
         operators = []
         op_tuple = namedtuple('operator_tuple', ['node', 'operator'])
-        for node in graph.node:
+        nodes = _fuse_transformer_patterns(graph) if cls.fuse_patterns \
+            else graph.node
+        for node in nodes:
             if not node.name:
                 node.name = "%s_%d" % (str(node.op_type), len(operators))
             n = OnnxNode(node)
@@ -396,6 +409,194 @@ def _init_layer(op, node, inputs, states):
     op.set_states(named)
 
 
+# ---------------------------------------------------------------------------
+# pattern fusion on the imported node list
+# ---------------------------------------------------------------------------
+def _fuse_transformer_patterns(graph):
+    """Exporters write layer normalisation and GELU as chains of elementwise
+    and reduction nodes:
+
+        ReduceMean -> Sub -> Pow(2) -> ReduceMean -> Add(eps) -> Sqrt -> Div
+                   -> Mul(gamma) -> Add(beta)
+        Div(sqrt 2) | Mul(1 / sqrt 2) -> Erf -> Add(1) -> Mul(x) -> Mul(0.5)
+
+    Each chain whose intermediate tensors have no other consumer is replaced
+    by one LayerNormalization / Gelu node (one kernel instead of nine / five,
+    no intermediate tensors).  Returns the new node list."""
+    nodes = list(graph.node)
+    consts = {t.name: numpy_helper.to_array(t) for t in graph.initializer}
+    for n in nodes:
+        if n.op_type == 'Constant':
+            for a in n.attribute:
+                if a.name == 'value':
+                    consts[n.output[0]] = numpy_helper.to_array(a.t)
+    outputs = set(o.name for o in graph.output)
+    producer, consumers = {}, {}
+    for i, n in enumerate(nodes):
+        for o in n.output:
+            producer[o] = i
+        for x in n.input:
+            consumers.setdefault(x, []).append(i)
+
+    def scalar(name):
+        v = consts.get(name)
+        if v is None or v.size != 1:
+            return None
+        return float(v.reshape(-1)[0])
+
+    def only(name, count=1):
+        """indices of the consumers if the tensor has exactly ``count`` of
+        them and is not a graph output"""
+        c = consumers.get(name, [])
+        if len(c) != count or name in outputs:
+            return None
+        return c
+
+    def other(node, name):
+        ins = list(node.input)
+        if len(ins) != 2 or name not in ins:
+            return None
+        return ins[1 - ins.index(name)] if ins[0] != ins[1] else None
+
+    def attr(node, key, default=None):
+        for a in node.attribute:
+            if a.name == key:
+                return helper.get_attribute_value(a)
+        return default
+
+    def last_axis_mean(node):
+        if node.op_type != 'ReduceMean' or attr(node, 'keepdims', 1) != 1:
+            return False
+        axes = attr(node, 'axes')
+        if axes is None and len(node.input) > 1:
+            v = consts.get(node.input[1])
+            axes = None if v is None else [int(a) for a in v.reshape(-1)]
+        return axes is not None and list(axes) == [-1]
+
+    dead, replace = set(), {}
+
+    # ---- layer normalisation ------------------------------------------------
+    for i, n in enumerate(nodes):
+        if i in dead or not last_axis_mean(n):
+            continue
+        x = n.input[0]
+        c = only(n.output[0])
+        if not c or nodes[c[0]].op_type != 'Sub' or \
+                list(nodes[c[0]].input) != [x, n.output[0]]:
+            continue
+        sub = c[0]
+        d = nodes[sub].output[0]
+        c = only(d, 2)
+        if not c:
+            continue
+        kinds = sorted(nodes[k].op_type for k in c)
+        if kinds != ['Div', 'Pow']:
+            continue
+        pw = [k for k in c if nodes[k].op_type == 'Pow'][0]
+        dv = [k for k in c if nodes[k].op_type == 'Div'][0]
+        if nodes[pw].input[0] != d or scalar(nodes[pw].input[1]) != 2.0:
+            continue
+        c = only(nodes[pw].output[0])
+        if not c or not last_axis_mean(nodes[c[0]]):
+            continue
+        mean2 = c[0]
+        c = only(nodes[mean2].output[0])
+        if not c or nodes[c[0]].op_type != 'Add':
+            continue
+        add_eps = c[0]
+        eps_name = other(nodes[add_eps], nodes[mean2].output[0])
+        eps = scalar(eps_name) if eps_name else None
+        if eps is None:
+            continue
+        c = only(nodes[add_eps].output[0])
+        if not c or nodes[c[0]].op_type != 'Sqrt':
+            continue
+        sq = c[0]
+        c = only(nodes[sq].output[0])
+        if not c or c[0] != dv or \
+                list(nodes[dv].input) != [d, nodes[sq].output[0]]:
+            continue
+        c = only(nodes[dv].output[0])
+        if not c or nodes[c[0]].op_type != 'Mul':
+            continue
+        mul = c[0]
+        gamma = other(nodes[mul], nodes[dv].output[0])
+        if gamma not in consts or consts[gamma].ndim != 1:
+            continue
+        c = only(nodes[mul].output[0])
+        if not c or nodes[c[0]].op_type != 'Add':
+            continue
+        addb = c[0]
+        beta = other(nodes[addb], nodes[mul].output[0])
+        if beta not in consts or consts[beta].shape != consts[gamma].shape:
+            continue
+        chain = [i, sub, pw, mean2, add_eps, sq, dv, mul, addb]
+        dead.update(chain)
+        replace[addb] = helper.make_node(
+            'LayerNormalization', [x, gamma, beta], [nodes[addb].output[0]],
+            name=(nodes[addb].name or "ln_%d" % addb) + "_fused", axis=-1,
+            epsilon=eps)
+
+    # ---- GELU ---------------------------------------------------------------
+    for i, n in enumerate(nodes):
+        if i in dead or n.op_type != 'Erf':
+            continue
+        p = producer.get(n.input[0])
+        if p is None or p in dead or only(n.input[0]) is None:
+            continue
+        pre = nodes[p]
+        x = None
+        if pre.op_type == 'Div' and scalar(pre.input[1]) is not None and \
+                abs(scalar(pre.input[1]) - 2 ** 0.5) < 1e-3:
+            x = pre.input[0]
+        elif pre.op_type == 'Mul':
+            for a, b in ((0, 1), (1, 0)):
+                v = scalar(pre.input[b])
+                if v is not None and abs(v - 0.5 ** 0.5) < 1e-3:
+                    x = pre.input[a]
+        if x is None:
+            continue
+        c = only(n.output[0])
+        if not c or nodes[c[0]].op_type != 'Add':
+            continue
+        add1 = c[0]
+        o = other(nodes[add1], n.output[0])
+        if o is None or scalar(o) != 1.0:
+            continue
+        c = only(nodes[add1].output[0])
+        if not c or nodes[c[0]].op_type != 'Mul':
+            continue
+        m1 = c[0]
+        o = other(nodes[m1], nodes[add1].output[0])
+        chain, last = None, None
+        if o == x:                                   # (x * (1 + erf)) * 0.5
+            c = only(nodes[m1].output[0])
+            if c and nodes[c[0]].op_type == 'Mul':
+                h = other(nodes[c[0]], nodes[m1].output[0])
+                if h is not None and scalar(h) == 0.5:
+                    chain, last = [p, i, add1, m1, c[0]], c[0]
+        elif o is not None and producer.get(o) is not None:  # (0.5 x) * (1 + erf)
+            q = producer[o]
+            if nodes[q].op_type == 'Mul' and q not in dead and only(o):
+                h = other(nodes[q], x)
+                if h is not None and scalar(h) == 0.5:
+                    chain, last = [p, i, add1, q, m1], m1
+        if chain is None:
+            continue
+        dead.update(chain)
+        replace[last] = helper.make_node(
+            'Gelu', [x], [nodes[last].output[0]],
+            name=(nodes[last].name or "gelu_%d" % last) + "_fused")
+
+    out = []
+    for i, n in enumerate(nodes):
+        if i in replace:
+            out.append(replace[i])
+        elif i not in dead:
+            out.append(n)
+    return out
+
+
 class SingaRep(object):
     """Interprets the imported graph in topological order.  ``run(x)`` takes
     numpy arrays (or Tensors when driven by ``SONNXModel``) and returns the
@@ -411,6 +612,7 @@ class SingaRep(object):
         self.tensor_count = {}
         self.has_initialized = False
         self.is_graph = False
+        self._const_cache = {}
 
     def initialize(self):
         self.outputs_info = {o.name: o for o in self.outputs}
@@ -485,8 +687,15 @@ class SingaRep(object):
                 if inp in tensor_dict:
                     inputs.append(tensor_dict[inp])
                 elif inp in self.states:
-                    val = np.atleast_1d(self.states[inp])
-                    inputs.append(tensor.Tensor(device=self.dev, data=val))
+                    # constants are uploaded once, not at every run
+                    key = (inp, id(self.dev))
+                    t = self._const_cache.get(key)
+                    if t is None:
+                        val = np.atleast_1d(self.states[inp])
+                        t = tensor.Tensor(device=self.dev, data=val)
+                        t.requires_grad = False
+                        self._const_cache[key] = t
+                    inputs.append(t)
                 else:
                     raise KeyError("Not found the input %s for operation %s" %
                                    (inp, node.name))
@@ -576,6 +785,7 @@ class SingaFrontend(object):
         'Negative': 'Neg', 'Reciprocal': 'Reciprocal', 'NonZero': 'NonZero',
         'Ceil': 'Ceil', 'Floor': 'Floor', 'Abs': 'Abs', 'Exp': 'Exp',
         'Rounde': 'Round', 'Erf': 'Erf', 'AddBias': 'Add',
+        'LayerNorm': 'LayerNormalization', 'Gelu': 'Gelu',
         'GlobalAveragePool': 'GlobalAveragePool',
     }
 
@@ -607,6 +817,9 @@ class SingaFrontend(object):
                     op.running_mean))),
                 ("var", tensor.to_numpy(tensor.from_raw_tensor(
                     op.running_var)))]
+        if n == 'LayerNorm':
+            return 'LayerNormalization', dict(axis=-1,
+                                              epsilon=float(op.eps)), []
         if n == 'Gemm':
             return 'Gemm', dict(alpha=float(op.alpha), beta=float(op.beta),
                                 transA=int(op.transA),

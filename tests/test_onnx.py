@@ -326,3 +326,98 @@ def test_export_fused_batchnorm_activation_round_trip():
     if isinstance(out, tensor.Tensor):
         out = tensor.to_numpy(out)
     np.testing.assert_allclose(out, tensor.to_numpy(y), rtol=1e-5, atol=1e-5)
+
+
+def _ln_gelu_chain_model(D=24, variant=0):
+    """x -> exported layer-norm chain -> exported GELU chain (two spellings)."""
+    from singa_amd.sonnx import helper, numpy_helper, TensorProto
+    rng = np.random.RandomState(3)
+    gamma = (rng.rand(D) + 0.5).astype(np.float32)
+    beta = rng.randn(D).astype(np.float32)
+    inits = [numpy_helper.from_array(gamma, "gamma"),
+             numpy_helper.from_array(beta, "beta"),
+             numpy_helper.from_array(np.array(2.0, np.float32), "two"),
+             numpy_helper.from_array(np.array(1e-5, np.float32), "eps"),
+             numpy_helper.from_array(np.array(2 ** 0.5, np.float32), "rt2"),
+             numpy_helper.from_array(np.array(1.0, np.float32), "one"),
+             numpy_helper.from_array(np.array(0.5, np.float32), "half")]
+    n = helper.make_node
+    nodes = [
+        n("ReduceMean", ["x"], ["m"], axes=[-1], keepdims=1),
+        n("Sub", ["x", "m"], ["d"]),
+        n("Pow", ["d", "two"], ["p"]),
+        n("ReduceMean", ["p"], ["v"], axes=[-1], keepdims=1),
+        n("Add", ["v", "eps"], ["ve"]),
+        n("Sqrt", ["ve"], ["s"]),
+        n("Div", ["d", "s"], ["q"]),
+        n("Mul", ["q", "gamma"], ["qg"]),
+        n("Add", ["qg", "beta"], ["ln"]),
+        n("Div", ["ln", "rt2"], ["t"]),
+        n("Erf", ["t"], ["e"]),
+        n("Add", ["e", "one"], ["e1"]),
+    ]
+    if variant == 0:
+        nodes += [n("Mul", ["ln", "e1"], ["xe"]), n("Mul", ["xe", "half"], ["y"])]
+    else:
+        nodes += [n("Mul", ["ln", "half"], ["xh"]), n("Mul", ["xh", "e1"], ["y"])]
+    g = helper.make_graph(
+        nodes, "ln_gelu",
+        [helper.make_tensor_value_info("x", TensorProto.FLOAT, [5, 7, D])],
+        [helper.make_tensor_value_info("y", TensorProto.FLOAT, [5, 7, D])],
+        inits)
+    m = helper.make_model(g, opset_imports=[helper.make_operatorsetid("", 11)])
+    return m, gamma, beta
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_import_fuses_layernorm_and_gelu_chains(dev, variant):
+    from math import erf
+    from singa_amd import sonnx
+    m, gamma, beta = _ln_gelu_chain_model(variant=variant)
+    x = np.random.RandomState(4).randn(5, 7, 24).astype(np.float32)
+    mu = x.mean(-1, keepdims=True)
+    ln = (x - mu) / np.sqrt(((x - mu) ** 2).mean(-1, keepdims=True) + 1e-5) \
+        * gamma + beta
+    want = 0.5 * ln * (1 + np.vectorize(erf)(ln / 2 ** 0.5))
+    rep = sonnx.prepare(m, device=dev)
+    kinds = [n.op_type for n, _ in rep.layers]
+    assert kinds == ["LayerNormalization", "Gelu"], kinds
+    np.testing.assert_allclose(rep.run([x])[0], want, rtol=1e-4, atol=1e-5)
+    sonnx.SingaBackend.fuse_patterns = False
+    try:
+        plain = sonnx.prepare(m, device=dev)
+        assert len(plain.layers) == 14
+        np.testing.assert_allclose(plain.run([x])[0], want, rtol=1e-4,
+                                   atol=1e-5)
+    finally:
+        sonnx.SingaBackend.fuse_patterns = True
+
+
+def test_layernorm_chain_with_second_consumer_is_left_alone(dev):
+    """The normalised difference feeding anything outside the chain blocks
+    the rewrite."""
+    from singa_amd import sonnx
+    from singa_amd.sonnx import helper, TensorProto
+    m, _, _ = _ln_gelu_chain_model()
+    m.graph.node.extend([helper.make_node("Identity", ["q"], ["q_out"])])
+    m.graph.output.extend(
+        [helper.make_tensor_value_info("q_out", TensorProto.FLOAT, [5, 7, 24])])
+    rep = sonnx.prepare(m, device=dev)
+    kinds = [n.op_type for n, _ in rep.layers]
+    assert "LayerNormalization" not in kinds and "Gelu" in kinds
+
+
+def test_export_layernorm_gelu_round_trip(dev):
+    from singa_amd import autograd, layer, sonnx, tensor
+    autograd.training = False
+    x = tensor.from_numpy(
+        np.random.RandomState(5).randn(3, 16).astype(np.float32), dev)
+    ln = layer.LayerNorm()
+    y = autograd.gelu(ln(x))
+    model = sonnx.to_onnx([x], [y])
+    assert [n.op_type for n in model.graph.node] == ["LayerNormalization",
+                                                     "Gelu"]
+    out = sonnx.prepare(model, device=dev).run([x])[0]
+    if isinstance(out, tensor.Tensor):
+        out = tensor.to_numpy(out)
+    np.testing.assert_allclose(out, tensor.to_numpy(y), rtol=1e-5, atol=1e-6)

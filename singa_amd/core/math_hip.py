@@ -346,16 +346,22 @@ class HipMath(object):
 
     @staticmethod
     def _gemm_splits(M, N, K):
-        """Number of equal reduction slices for a product with few 64 x 64
-        output tiles: the largest divisor of K that keeps slices at least 64
-        deep (and 4-aligned for the vector loads) and the launch within about
-        one workgroup per CU."""
-        tiles = -(-M // 64) * -(-N // 64)
-        if tiles > 64 or K < 512:
+        """Number of equal reduction slices for a product with too few output
+        tiles to occupy the chip: the largest divisor of K that keeps the
+        launch within about one workgroup per CU, with slices 4-aligned (for
+        the vector loads) and at least 64 deep for skinny products (counted
+        in 64 x 64 tiles) or 256 deep for mid-sized ones (128 x 128 tiles)."""
+        tiles64 = -(-M // 64) * -(-N // 64)
+        tiles128 = -(-M // 128) * -(-N // 128)
+        if tiles64 <= 64 and K >= 512:
+            most, depth = min(32, 256 // tiles64), 64
+        elif tiles128 <= 96 and K >= 1024 and M >= 96 and N >= 96:
+            most, depth = 256 // tiles128, 256
+        else:
             return 1
         best = 1
-        for d in range(2, min(32, 256 // tiles) + 1):
-            if K % d == 0 and (K // d) >= 64 and (K // d) % 4 == 0:
+        for d in range(2, most + 1):
+            if K % d == 0 and (K // d) >= depth and (K // d) % 4 == 0:
                 best = d
         return best
 

@@ -14,7 +14,7 @@ from singa_amd import device as sdevice  # noqa: E402
 from bench_conv import timeit  # noqa: E402
 
 SHAPES = [(4096, 4096, 4096), (8192, 8192, 8192), (8192, 8192, 1024),
-          (1024, 1024, 1024), (32, 1000, 2048),
+          (1024, 1024, 1024), (1024, 1024, 4096), (2048, 1024, 2048), (32, 1000, 2048),
           # BERT-base, 32 x 256 tokens: QKV / out projection, FFN
           (8192, 768, 768), (8192, 3072, 768), (8192, 768, 3072)]
 

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--verbosity", type=int, default=0)
     args = ap.parse_args()
 
+    # the host driver shares device memory between processes through dmabuf
+    # only; RCCL needs this before the HIP runtime starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -18,6 +18,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # plain | half | partialUpdate | sparseTopK | sparseThreshold
 OPTION = os.environ.get("MR_OPTION", "plain")
+NRANKS = int(os.environ.get("MR_RANKS", "2"))
 sys.path.insert(0, ROOT)
 
 
@@ -70,7 +71,7 @@ def main():
     with open(log, "w") as fd:
         rc = subprocess.run(
             [sys.executable, "-u", "-m", "torch.distributed.run", "--nnodes=1",
-             "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+             "--nproc-per-node=%d" % NRANKS, "--master-addr", "127.0.0.1",
              "--master-port", "29541", os.path.abspath(__file__)],
             env=env, stdout=fd, stderr=subprocess.STDOUT,
             timeout=200).returncode
@@ -80,7 +81,7 @@ def main():
         return 1
     ranks = [[float(v) for v in line.split()[2:]]
              for line in text.splitlines() if line.startswith("rank ")]
-    assert len(ranks) == 2, ranks
+    assert len(ranks) == NRANKS, ranks
     ref = train(False)
     print("single", " ".join("%.5f" % v for v in ref))
     for r in ranks:

@@ -1,9 +1,11 @@
 // Record encoders / decoders: turn (features, label) tensors into the byte
 // strings stored in record files and back.  CSV keeps one text line per
 // sample; the image codec stores 8-bit images as binary PPM / PGM with the
-// label in a comment line, so records remain viewable with ordinary tools
-// (no image library is linked; the reference's JPGEncoder/Decoder need
-// OpenCV).  API parity: reference include/singa/io/{encoder,decoder}.h.
+// label in a comment line; the JPG codec stores baseline JPEG files with the
+// label in a COM segment (own codec, io/jpeg.h: no image library is linked,
+// where the reference's JPGEncoder/Decoder need OpenCV).  Records of both
+// image codecs are ordinary image files.  API parity: reference
+// include/singa/io/{encoder,decoder}.h.
 #pragma once
 #include <string>
 #include <vector>
@@ -57,6 +59,29 @@ class ImageEncoder : public Encoder {
 };
 
 class ImageDecoder : public Decoder {
+ public:
+  void Setup(const DecoderConf &conf) override { order_ = conf.image_dim_order; }
+  /// -> {float32 image in the configured order, int label (if present)}
+  std::vector<Tensor> Decode(std::string value) override;
+
+ private:
+  std::string order_ = "CHW";
+};
+
+/// uint8 image tensor (HWC or CHW, 1 or 3 channels) <-> baseline JPEG bytes
+/// (reference JPGEncoder / JPGDecoder, src/io/jpg_{encoder,decoder}.cc).
+class JPGEncoder : public Encoder {
+ public:
+  void Setup(const EncoderConf &conf) override { order_ = conf.image_dim_order; }
+  std::string Encode(std::vector<Tensor> &data) override;
+  void set_quality(int q) { quality_ = q; }
+
+ private:
+  std::string order_ = "HWC";
+  int quality_ = 100;  // the reference encodes at quality 100
+};
+
+class JPGDecoder : public Decoder {
  public:
   void Setup(const DecoderConf &conf) override { order_ = conf.image_dim_order; }
   /// -> {float32 image in the configured order, int label (if present)}

@@ -4,6 +4,7 @@
 #include <sstream>
 
 #include "singa/io/encoder.h"
+#include "singa/io/jpeg.h"
 #include "singa/io/transformer.h"
 #include "singa/utils/string.h"
 
@@ -150,12 +151,74 @@ std::vector<Tensor> ImageDecoder::Decode(std::string value) {
   return out;
 }
 
+// ---- JPEG image records ------------------------------------------------------
+std::string JPGEncoder::Encode(std::vector<Tensor> &data) {
+  CHECK_GE(data.size(), 1u);
+  Tensor img = data[0].Clone(defaultDevice);
+  CHECK(img.nDim() == 2u || img.nDim() == 3u);
+  size_t H, W, C;
+  bool chw = order_ == "CHW" && img.nDim() == 3;
+  if (img.nDim() == 2) { H = img.shape(0); W = img.shape(1); C = 1; }
+  else if (chw) { C = img.shape(0); H = img.shape(1); W = img.shape(2); }
+  else { H = img.shape(0); W = img.shape(1); C = img.shape(2); }
+  CHECK(C == 1 || C == 3) << "1 or 3 channels";
+  std::vector<float> px;
+  if (img.data_type() == kFloat32) {
+    px = img.ToVector<float>();
+  } else {
+    auto v = img.ToVector<int>();
+    px.assign(v.begin(), v.end());
+  }
+  std::vector<uint8_t> hwc(H * W * C);
+  for (size_t h = 0; h < H; ++h)
+    for (size_t w = 0; w < W; ++w)
+      for (size_t c = 0; c < C; ++c) {
+        float v = chw ? px[(c * H + h) * W + w] : px[(h * W + w) * C + c];
+        hwc[(h * W + w) * C + c] = static_cast<uint8_t>(
+            std::min(255.f, std::max(0.f, std::round(v))));
+      }
+  std::string comment;
+  if (data.size() == 2)
+    comment = "label " + std::to_string(
+        data[1].Clone(defaultDevice).ToVector<int>().at(0));
+  return jpeg::Encode(hwc.data(), static_cast<int>(W), static_cast<int>(H),
+                      static_cast<int>(C), quality_, comment);
+}
+
+std::vector<Tensor> JPGDecoder::Decode(std::string value) {
+  std::vector<uint8_t> px8;
+  int W = 0, H = 0, C = 0;
+  std::string comment, error;
+  CHECK(jpeg::Decode(value, &px8, &W, &H, &C, &comment, &error))
+      << "JPEG record: " << error;
+  const bool chw = order_ == "CHW";
+  std::vector<float> px(px8.size());
+  for (int h = 0; h < H; ++h)
+    for (int w = 0; w < W; ++w)
+      for (int c = 0; c < C; ++c) {
+        const float v = px8[(static_cast<size_t>(h) * W + w) * C + c];
+        if (chw) px[(static_cast<size_t>(c) * H + h) * W + w] = v;
+        else px[(static_cast<size_t>(h) * W + w) * C + c] = v;
+      }
+  const size_t uC = C, uH = H, uW = W;
+  Tensor img(chw ? Shape{uC, uH, uW} : Shape{uH, uW, uC}, kFloat32);
+  img.CopyDataFromHostPtr(px.data(), px.size());
+  std::vector<Tensor> out{img};
+  if (comment.rfind("label ", 0) == 0) {
+    int label = std::atoi(comment.c_str() + 6);
+    Tensor lab(Shape{1}, kInt);
+    lab.CopyDataFromHostPtr(&label, 1);
+    out.push_back(lab);
+  }
+  return out;
+}
+
 std::shared_ptr<Encoder> CreateEncoder(const std::string &type) {
   std::string t = ToLowerCase(type);
   if (t == "csv") return std::make_shared<CSVEncoder>();
   if (t == "image" || t == "ppm") return std::make_shared<ImageEncoder>();
-  LOG(FATAL) << "Unknown encoder type " << type
-             << " (jpg needs an image library that is not linked)";
+  if (t == "jpg" || t == "jpeg") return std::make_shared<JPGEncoder>();
+  LOG(FATAL) << "Unknown encoder type " << type;
   return nullptr;
 }
 
@@ -163,6 +226,7 @@ std::shared_ptr<Decoder> CreateDecoder(const std::string &type) {
   std::string t = ToLowerCase(type);
   if (t == "csv") return std::make_shared<CSVDecoder>();
   if (t == "image" || t == "ppm") return std::make_shared<ImageDecoder>();
+  if (t == "jpg" || t == "jpeg") return std::make_shared<JPGDecoder>();
   LOG(FATAL) << "Unknown decoder type " << type;
   return nullptr;
 }

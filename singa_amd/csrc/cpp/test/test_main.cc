@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "singa/singa.h"
+#include "singa/io/jpeg.h"
 
 using namespace singa;
 
@@ -828,7 +829,111 @@ static void Run(const char *name, const std::function<void()> &fn) {
   std::fflush(stdout);
 }
 
+// JPEG record codec: a smooth colour image survives quality-100 coding within
+// a couple of grey levels, the label rides in the comment segment, grey
+// images and odd sizes work, and a damaged stream is refused.
+static void TestJpeg() {
+  const size_t H = 37, W = 53;
+  std::vector<float> px(H * W * 3);
+  for (size_t h = 0; h < H; ++h)
+    for (size_t w = 0; w < W; ++w) {
+      px[(h * W + w) * 3 + 0] = 255.f * w / (W - 1);
+      px[(h * W + w) * 3 + 1] = 255.f * h / (H - 1);
+      px[(h * W + w) * 3 + 2] = 128.f + 100.f * std::sin(0.2f * (h + w));
+    }
+  JPGEncoder enc;
+  JPGDecoder dec;
+  EncoderConf ec;
+  ec.image_dim_order = "HWC";
+  enc.Setup(ec);
+  DecoderConf dc;
+  dc.image_dim_order = "HWC";
+  dec.Setup(dc);
+  std::vector<Tensor> rec{FromVec(px, {H, W, 3}, defaultDevice),
+                          FromInts({7}, {1}, defaultDevice)};
+  std::string bytes = enc.Encode(rec);
+  EXPECT(bytes.size() > 100 && (unsigned char)bytes[0] == 0xff &&
+         (unsigned char)bytes[1] == 0xd8);
+  auto back = dec.Decode(bytes);
+  EXPECT(back.size() == 2 && back[1].ToVector<int>()[0] == 7);
+  EXPECT(back[0].shape() == (Shape{H, W, 3}));
+  auto got = ToVec(back[0]);
+  float worst = 0.f;
+  for (size_t i = 0; i < px.size(); ++i)
+    worst = std::max(worst, std::fabs(got[i] - std::round(px[i])));
+  EXPECT(worst <= 3.f);
+  // grey, CHW order, lower quality: smaller file, bounded error
+  std::vector<float> grey(H * W);
+  for (size_t i = 0; i < grey.size(); ++i) grey[i] = px[i * 3];
+  JPGEncoder genc;
+  genc.set_quality(75);
+  std::vector<Tensor> grec{FromVec(grey, {H, W}, defaultDevice)};
+  std::string gbytes = genc.Encode(grec);
+  EXPECT(gbytes.size() < bytes.size());
+  auto gback = JPGDecoder().Decode(gbytes);
+  EXPECT(gback.size() == 1 && gback[0].shape() == (Shape{1, H, W}));
+  auto gg = ToVec(gback[0]);
+  worst = 0.f;
+  for (size_t i = 0; i < grey.size(); ++i)
+    worst = std::max(worst, std::fabs(gg[i] - grey[i]));
+  EXPECT(worst <= 12.f);
+  // factory names and damaged input
+  EXPECT(CreateEncoder("jpg") != nullptr && CreateDecoder("JPEG") != nullptr);
+  std::vector<uint8_t> o;
+  int w = 0, h = 0, c = 0;
+  std::string err;
+  EXPECT(!jpeg::Decode(bytes.substr(0, bytes.size() / 2), &o, &w, &h, &c,
+                       nullptr, &err));
+  EXPECT(!err.empty());
+}
+
+// `--jpeg-decode in.jpg out.ppm` / `--jpeg-encode in.ppm out.jpg [quality]`:
+// file converters used to check the codec against an independent
+// implementation from the Python tests.
+static int JpegTool(int argc, char **argv) {
+  auto slurp = [](const char *path) {
+    std::string s;
+    if (FILE *f = std::fopen(path, "rb")) {
+      char buf[65536];
+      size_t n;
+      while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) s.append(buf, n);
+      std::fclose(f);
+    }
+    return s;
+  };
+  auto spill = [](const char *path, const std::string &s) {
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return false;
+    std::fwrite(s.data(), 1, s.size(), f);
+    std::fclose(f);
+    return true;
+  };
+  const std::string mode = argv[1];
+  if (argc < 4) return 2;
+  DecoderConf dc;
+  dc.image_dim_order = "HWC";
+  EncoderConf ec;
+  ec.image_dim_order = "HWC";
+  if (mode == "--jpeg-decode") {
+    JPGDecoder dec;
+    dec.Setup(dc);
+    auto t = dec.Decode(slurp(argv[2]));
+    ImageEncoder ppm;
+    ppm.Setup(ec);
+    return spill(argv[3], ppm.Encode(t)) ? 0 : 1;
+  }
+  ImageDecoder ppm;
+  ppm.Setup(dc);
+  auto t = ppm.Decode(slurp(argv[2]));
+  JPGEncoder enc;
+  enc.Setup(ec);
+  if (argc > 4) enc.set_quality(std::atoi(argv[4]));
+  return spill(argv[3], enc.Encode(t)) ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
+  if (argc > 1 && std::string(argv[1]).rfind("--jpeg-", 0) == 0)
+    return JpegTool(argc, argv);
   for (int i = 1; i < argc; ++i)
     if (std::string(argv[i]) == "--gpu") g_gpu = true;
   singa::LogToStderr();
@@ -844,6 +949,7 @@ int main(int argc, char **argv) {
   Run("LocalUpdater", TestLocalUpdater);
   if (!g_gpu) Run("Rnn/cpu", TestRnn);
   Run("Io", TestIo);
+  Run("Jpeg", TestJpeg);
   Run("EndPoint", TestEndPoint);
   if (g_gpu) {
     g_dev = Platform::CreateCudaGPUs(1)[0];

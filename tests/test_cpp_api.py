@@ -43,3 +43,81 @@ def test_cpp_api_gpu(exe):
                  "FeedForwardNet/gpu",
                  "FeedForwardNet/gpu-graph"):
         assert "[  OK  ] " + name in out
+
+
+def _jpeg_tool():
+    exe = os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "singa_amd", "bin", "singa_cpp_test")
+    if not os.path.exists(exe):
+        pytest.skip("C++ test program not built")
+    return exe
+
+
+def _test_image(h=61, w=83):
+    import numpy as np
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.stack([255 * xx / (w - 1), 255 * yy / (h - 1),
+                    128 + 100 * np.sin(0.15 * (xx + yy))], axis=-1)
+    return np.clip(np.round(img), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("subsampling,tol", [(0, 3), (1, 6), (2, 6)])
+def test_jpeg_decoder_against_pil(tmp_path, subsampling, tol):
+    """Files written by an independent encoder (PIL / libjpeg: optimised or
+    standard Huffman tables, 4:4:4 and 4:2:0 sampling) decode to the same
+    pixels as PIL's decoder, up to IDCT rounding (4:4:4) and the chroma
+    upsampling filter's rounding (4:2:2, 4:2:0)."""
+    import subprocess
+    import numpy as np
+    from PIL import Image
+    exe = _jpeg_tool()
+    img = _test_image()
+    for extra in ({}, {"optimize": True}):
+        jpg = str(tmp_path / "a.jpg")
+        Image.fromarray(img).save(jpg, quality=90, subsampling=subsampling,
+                                  **extra)
+        ppm = str(tmp_path / "a.ppm")
+        subprocess.run([exe, "--jpeg-decode", jpg, ppm], check=True,
+                       timeout=60)
+        mine = np.asarray(Image.open(ppm).convert("RGB")).astype(np.int32)
+        ref = np.asarray(Image.open(jpg).convert("RGB")).astype(np.int32)
+        assert mine.shape == ref.shape
+        assert np.abs(mine - ref).max() <= tol
+        assert np.abs(mine - ref).mean() < 1.5
+
+
+def test_jpeg_decoder_restart_markers_and_grey(tmp_path):
+    import subprocess
+    import numpy as np
+    from PIL import Image
+    exe = _jpeg_tool()
+    grey = _test_image()[:, :, 2]
+    jpg = str(tmp_path / "g.jpg")
+    Image.fromarray(grey).save(jpg, quality=85, restart_marker_blocks=3)
+    ppm = str(tmp_path / "g.pgm")
+    subprocess.run([exe, "--jpeg-decode", jpg, ppm], check=True, timeout=60)
+    mine = np.asarray(Image.open(ppm)).astype(np.int32)
+    ref = np.asarray(Image.open(jpg)).astype(np.int32)
+    assert mine.shape == ref.shape and np.abs(mine - ref).max() <= 2
+
+
+@pytest.mark.parametrize("quality", [100, 75])
+def test_jpeg_encoder_read_by_pil(tmp_path, quality):
+    """Files written by the encoder are valid baseline JPEGs for an
+    independent decoder and close to the source image."""
+    import subprocess
+    import numpy as np
+    from PIL import Image
+    exe = _jpeg_tool()
+    img = _test_image()
+    ppm = str(tmp_path / "b.ppm")
+    Image.fromarray(img).save(ppm)
+    jpg = str(tmp_path / "b.jpg")
+    subprocess.run([exe, "--jpeg-encode", ppm, jpg, str(quality)], check=True,
+                   timeout=60)
+    back = Image.open(jpg)
+    assert back.format == "JPEG" and back.size == (img.shape[1], img.shape[0])
+    err = np.abs(np.asarray(back.convert("RGB")).astype(np.int32) -
+                 img.astype(np.int32))
+    assert err.max() <= (4 if quality == 100 else 40)
+    assert err.mean() < (1.0 if quality == 100 else 4.0)

@@ -774,7 +774,7 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
     const int64_t lim = ((int64_t)1 << 30) - 1024;  // elements
     const int64_t a_ext = (M - 1) * a_rs + (K - 1) * a_cs;
     const int64_t b_ext = (K - 1) * b_rs + (N - 1) * b_cs;
-    if (a_ok && b_ok && K % 8 == 0 && K >= 64 && M >= 64 && N >= 64 &&
+    if (a_ok && b_ok && K % 8 == 0 && K >= 64 && M >= 8 && N >= 8 &&
         a_ext >= 0 && b_ext >= 0 && a_ext + 256 * a_rs < lim &&
         b_ext + 256 * b_cs < lim && M < lim && N < lim) {
       if (dtype == kF16) launch_h16_fast<__half>(g, a_kc, b_kc, batch, s);

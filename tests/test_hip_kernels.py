@@ -287,7 +287,8 @@ def test_gemm_half(maths, dt):
 @pytest.mark.parametrize("ta,tb", [(False, False), (False, True),
                                    (True, False), (True, True)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (200, 136, 72),
-                                   (128, 384, 1000), (64, 64, 64)])
+                                   (128, 384, 1000), (64, 64, 64),
+                                   (32, 1000, 256), (8, 24, 64)])
 def test_gemm_16bit_tile_path(maths, dt, ta, tb, M, N, K):
     """128 x 128 x 64 kernel: every combination of row- / column-contiguous
     operands (16-byte row reads and transposing LDS reads), ragged M, N and

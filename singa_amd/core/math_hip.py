@@ -322,23 +322,36 @@ class HipMath(object):
         if c.stride()[-1] != 1:
             raise ValueError("GEMM output must be row-major")
         ldc = c.stride()[-2] if c.dim() >= 2 else N
-        splits = self._gemm_splits(M, N, K) if (
-            batch == 1 and c.dtype == torch.float32) else 1
+        splits = self._gemm_splits(M, N, K) if batch == 1 and c.dtype in (
+            torch.float32, torch.float16, torch.bfloat16) else 1
+        if splits > 1 and c.dtype != torch.float32 and (K // splits) % 64:
+            splits = 1          # the 16-bit tiles are 64 deep
         if splits > 1:
-            # skinny product: too few output tiles to occupy the chip, so the
-            # reduction is cut into `splits` equal slices computed as a batch
-            # of partial products, summed by one epilogue kernel
+            # too few output tiles to occupy the chip: the reduction is cut
+            # into `splits` equal slices computed as a batch of float partial
+            # products, summed (and scaled / biased / activated) by one
+            # epilogue kernel
             kc = K // splits
             part = torch.empty(splits * M * N, dtype=torch.float32,
                                device=c.device)
-            self.k.gemm(0, M, N, kc, 1.0, a.data_ptr(), a_rs, a_cs, kc * a_cs,
-                        b.data_ptr(), b_rs, b_cs, kc * b_rs, 0.0,
-                        part.data_ptr(), N, M * N, splits, 0, 0, self._s())
-            self.k.gemm_splitk_reduce(
-                0, part.data_ptr(), splits, M, N, float(alpha), float(beta),
-                c.data_ptr(), ldc,
-                bias.data_ptr() if bias is not None else 0, act, self._s())
-            return
+            if c.dtype == torch.float32:
+                self.k.gemm(0, M, N, kc, 1.0, a.data_ptr(), a_rs, a_cs,
+                            kc * a_cs, b.data_ptr(), b_rs, b_cs, kc * b_rs,
+                            0.0, part.data_ptr(), N, M * N, splits, 0, 0,
+                            self._s())
+                done = True
+            else:
+                done = self.k.gemm_h16_partial(
+                    _code(c), M, N, kc, a.data_ptr(), a_rs, a_cs, kc * a_cs,
+                    b.data_ptr(), b_rs, b_cs, kc * b_rs, part.data_ptr(),
+                    splits, self._s()) == 0
+            if done:
+                self.k.gemm_splitk_reduce(
+                    _code(c), part.data_ptr(), splits, M, N, float(alpha),
+                    float(beta), c.data_ptr(), ldc,
+                    bias.data_ptr() if bias is not None else 0, act,
+                    self._s())
+                return
         self.k.gemm(_code(c), M, N, K, float(alpha), a.data_ptr(), a_rs, a_cs,
                     a_bs, b.data_ptr(), b_rs, b_cs, b_bs, float(beta),
                     c.data_ptr(), ldc, c_bs, batch,
@@ -350,13 +363,13 @@ class HipMath(object):
         tiles to occupy the chip: the largest divisor of K that keeps the
         launch within about one workgroup per CU, with slices 4-aligned (for
         the vector loads) and at least 64 deep for skinny products (counted
-        in 64 x 64 tiles) or 256 deep for mid-sized ones (128 x 128 tiles)."""
+        in 64 x 64 tiles) or 512 deep for mid-sized ones (128 x 128 tiles)."""
         tiles64 = -(-M // 64) * -(-N // 64)
         tiles128 = -(-M // 128) * -(-N // 128)
         if tiles64 <= 64 and K >= 512:
             most, depth = min(32, 256 // tiles64), 64
         elif tiles128 <= 96 and K >= 1024 and M >= 96 and N >= 96:
-            most, depth = 256 // tiles128, 256
+            most, depth = 256 // tiles128, 512
         else:
             return 1
         best = 1

@@ -171,6 +171,15 @@ PYBIND11_MODULE(_hip, m) {
           "gemm");
   });
 
+  // returns the status instead of raising: -3 = layout not eligible
+  m.def("gemm_h16_partial", [](int dt, int64_t M, int64_t N, int64_t K,
+                               uintptr_t A, int64_t a_rs, int64_t a_cs,
+                               int64_t a_bs, uintptr_t B, int64_t b_rs,
+                               int64_t b_cs, int64_t b_bs, uintptr_t part,
+                               int64_t batch, uintptr_t s) {
+    return sa_gemm_h16_partial(dt, M, N, K, CP(A), a_rs, a_cs, a_bs, CP(B),
+                               b_rs, b_cs, b_bs, (float *)P(part), batch, S(s));
+  });
   m.def("gemm_splitk_reduce", [](int dt, uintptr_t part, int splits, int64_t M,
                                  int64_t N, float alpha, float beta,
                                  uintptr_t C, int64_t ldc, uintptr_t bias,

@@ -39,6 +39,9 @@ struct GemmArgs {
   int64_t ldc, c_bs;
   const void *bias;
   int act;  // 0 none, 1 relu
+  // 16-bit tiled kernel only: C is a float buffer receiving the plain
+  // product (the partial products of a split reduction)
+  int c_float = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -610,6 +613,11 @@ gemm_h16_fast_kernel(GemmArgs g, int ntm, int ntn) {
         const int64_t row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) +
                             4 * (lane >> 5);
         if (row >= g.M) continue;
+        if (g.c_float) {
+          ((float *)g.C)[(int64_t)blockIdx.z * g.c_bs + row * g.ldc + col] =
+              acc[i][j][r];
+          continue;
+        }
         float v = g.alpha * acc[i][j][r] + bv;
         T *cp = C + row * g.ldc + col;
         if (g.beta != 0.f) v += g.beta * to_f<T>(*cp);
@@ -719,6 +727,27 @@ int sa_gemm_splitk_reduce(int dtype, const float *part, int splits, int64_t M,
   return 0;
 }
 
+// The tiled 16-bit kernel needs both operands readable in aligned 16-byte
+// pieces along their contiguous index and every byte offset within 31 bits.
+static bool h16_fast_ok(const GemmArgs &g) {
+  auto al16 = [](const void *p) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  };
+  const bool a_kc = g.a_cs == 1, b_kc = g.b_rs == 1;
+  const bool a_ok = al16(g.A) && g.a_bs % 8 == 0 &&
+                    (a_kc ? g.a_rs % 8 == 0
+                          : (g.a_rs == 1 && g.a_cs % 8 == 0));
+  const bool b_ok = al16(g.B) && g.b_bs % 8 == 0 &&
+                    (b_kc ? g.b_cs % 8 == 0
+                          : (g.b_cs == 1 && g.b_rs % 8 == 0));
+  const int64_t lim = ((int64_t)1 << 30) - 1024;  // elements
+  const int64_t a_ext = (g.M - 1) * g.a_rs + (g.K - 1) * g.a_cs;
+  const int64_t b_ext = (g.K - 1) * g.b_rs + (g.N - 1) * g.b_cs;
+  return a_ok && b_ok && g.K % 8 == 0 && g.K >= 64 && g.M >= 8 && g.N >= 8 &&
+         a_ext >= 0 && b_ext >= 0 && a_ext + 256 * g.a_rs < lim &&
+         b_ext + 256 * g.b_cs < lim && g.M < lim && g.N < lim;
+}
+
 int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
             const void *A, int64_t a_rs, int64_t a_cs, int64_t a_bs,
             const void *B, int64_t b_rs, int64_t b_cs, int64_t b_bs,
@@ -761,22 +790,8 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
     return 0;
   }
   if (dtype == kF16 || dtype == kBF16) {
-    // fast path: both operands readable in aligned 16-byte pieces along their
-    // contiguous index, every byte offset within 31 bits
-    auto al16 = [](const void *p) {
-      return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
-    };
-    const bool a_kc = a_cs == 1, b_kc = b_rs == 1;
-    const bool a_ok = al16(A) && a_bs % 8 == 0 &&
-                      (a_kc ? a_rs % 8 == 0 : (a_rs == 1 && a_cs % 8 == 0));
-    const bool b_ok = al16(B) && b_bs % 8 == 0 &&
-                      (b_kc ? b_cs % 8 == 0 : (b_cs == 1 && b_rs % 8 == 0));
-    const int64_t lim = ((int64_t)1 << 30) - 1024;  // elements
-    const int64_t a_ext = (M - 1) * a_rs + (K - 1) * a_cs;
-    const int64_t b_ext = (K - 1) * b_rs + (N - 1) * b_cs;
-    if (a_ok && b_ok && K % 8 == 0 && K >= 64 && M >= 8 && N >= 8 &&
-        a_ext >= 0 && b_ext >= 0 && a_ext + 256 * a_rs < lim &&
-        b_ext + 256 * b_cs < lim && M < lim && N < lim) {
+    if (h16_fast_ok(g)) {
+      const bool a_kc = a_cs == 1, b_kc = b_rs == 1;
       if (dtype == kF16) launch_h16_fast<__half>(g, a_kc, b_kc, batch, s);
       else launch_h16_fast<__hip_bfloat16>(g, a_kc, b_kc, batch, s);
       return 0;
@@ -803,4 +818,24 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
     return 0;
   }
   return -1;
+}
+
+// 16-bit operands, float output: part[b] = A[b] * B[b] for b < batch (the
+// slices of a split reduction).  Returns -3 when the operand layout does not
+// fit the tiled kernel (the caller then takes the unsplit path).
+int sa_gemm_h16_partial(int dtype, int64_t M, int64_t N, int64_t K,
+                        const void *A, int64_t a_rs, int64_t a_cs,
+                        int64_t a_bs, const void *B, int64_t b_rs,
+                        int64_t b_cs, int64_t b_bs, float *part, int64_t batch,
+                        hipStream_t s) {
+  if (dtype != kF16 && dtype != kBF16) return -1;
+  if (M <= 0 || N <= 0 || batch <= 0) return 0;
+  GemmArgs g{M, N, K, 1.f, 0.f, A, a_rs, a_cs, a_bs, B, b_rs, b_cs, b_bs,
+             part, N, M * N, nullptr, 0};
+  g.c_float = 1;
+  if (!h16_fast_ok(g)) return -3;
+  const bool a_kc = a_cs == 1, b_kc = b_rs == 1;
+  if (dtype == kF16) launch_h16_fast<__half>(g, a_kc, b_kc, batch, s);
+  else launch_h16_fast<__hip_bfloat16>(g, a_kc, b_kc, batch, s);
+  return 0;
 }

@@ -100,6 +100,13 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
             float beta, void *C, int64_t ldc, int64_t c_bs, int64_t batch,
             const void *bias, int act, hipStream_t s);
 
+// 16-bit A / B, float partial products part[b] = A[b] * B[b]; -3 when the
+// operand layout does not fit the tiled kernel
+int sa_gemm_h16_partial(int dtype, int64_t M, int64_t N, int64_t K,
+                        const void *A, int64_t a_rs, int64_t a_cs,
+                        int64_t a_bs, const void *B, int64_t b_rs,
+                        int64_t b_cs, int64_t b_bs, float *part, int64_t batch,
+                        hipStream_t s);
 // epilogue of a reduction split over `splits` partial products [splits][M][N]
 int sa_gemm_splitk_reduce(int dtype, const float *part, int splits, int64_t M,
                           int64_t N, float alpha, float beta, void *C,

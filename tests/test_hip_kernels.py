@@ -666,3 +666,26 @@ def test_pack_unpack_bucket(maths, wire):
         np.testing.assert_allclose(o.cpu().numpy(),
                                    (t.to(wire).float() * 0.5).numpy(),
                                    rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(32, 1000, 2048), (1024, 1024, 4096),
+                                   (256, 384, 1024)])
+def test_gemm_16bit_split_reduction(maths, dt, M, N, K):
+    """Few output tiles, long reduction, 16-bit operands: float partial
+    products per slice of K, one epilogue.  Integer-valued inputs keep the
+    float sums exact, so only the final rounding to 16 bits differs."""
+    hm, cm, dev = maths
+    assert hm._gemm_splits(M, N, K) > 1
+    r = np.random.RandomState(K)
+    a = torch.from_numpy(r.randint(-2, 3, (M, K)).astype(np.float32)).to(dt)
+    b = torch.from_numpy(r.randint(-2, 3, (K, N)).astype(np.float32)).to(dt)
+    bias = torch.from_numpy(r.randint(-2, 3, (N,)).astype(np.float32)).to(dt)
+    ref = a.float() @ b.float()
+    c = torch.empty(M, N, dtype=dt, device=dev.torch_device)
+    hm.gemm(1.0, g(a, dev), g(b, dev), 0.0, c)
+    assert torch.equal(c.float().cpu(), ref.to(dt).float())
+    hm.gemm(0.25, g(a, dev), g(b.t().contiguous(), dev).t(), 0.0, c,
+            bias=g(bias, dev), act=1)
+    want = torch.relu(0.25 * ref + bias.float()).to(dt).float()
+    assert torch.equal(c.float().cpu(), want)

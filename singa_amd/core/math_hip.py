@@ -109,7 +109,16 @@ class HipMath(object):
 
     def copy(self, src, dst):
         if src.dtype not in _CODE or dst.dtype not in _CODE:
-            dst.copy_(src)  # 8-bit / 64-bit types: data movement only
+            # 8-bit / 64-bit types: data movement only.  A plain byte copy runs
+            # as a kernel (a memcpy node inside a captured graph is not
+            # reliably ordered against the kernels around it)
+            if (src.dtype == dst.dtype and src.is_contiguous() and
+                    dst.is_contiguous() and src.shape == dst.shape and
+                    src.data_ptr() % 4 == 0 and dst.data_ptr() % 4 == 0):
+                self.k.copy_bytes(dst.data_ptr(), src.data_ptr(),
+                                  src.numel() * src.element_size(), self._s())
+            else:
+                dst.copy_(src)
             return
         self._unary(_U["copy"], src, dst)
 

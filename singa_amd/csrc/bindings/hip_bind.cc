@@ -189,6 +189,14 @@ PYBIND11_MODULE(_hip, m) {
           "gemm_splitk_reduce");
   });
 
+  m.def("copy_bytes", [](uintptr_t dst, uintptr_t src, int64_t bytes,
+                         uintptr_t s) {
+    check(sa_copy_bytes(P(dst), CP(src), bytes, S(s)), "copy_bytes");
+  });
+  m.def("zero_bytes", [](uintptr_t dst, int64_t bytes, uintptr_t s) {
+    check(sa_zero_bytes(P(dst), bytes, S(s)), "zero_bytes");
+  });
+
   // ---- layer norm / gelu ------------------------------------------------------
   m.def("layernorm_fwd", [](int dt, uintptr_t x, uintptr_t gamma, uintptr_t beta,
                             uintptr_t y, uintptr_t mean, uintptr_t rstd,

@@ -306,3 +306,18 @@ int sa_axpy(int dtype, const float *alpha_ptr, float alpha, const void *x,
   });
   return 0;
 }
+
+int sa_copy_bytes(void *dst, const void *src, int64_t bytes, hipStream_t s) {
+  if (bytes <= 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 3)
+    return -2;
+  sa::copy_async(dst, src, (size_t)bytes, s);
+  return 0;
+}
+
+int sa_zero_bytes(void *dst, int64_t bytes, hipStream_t s) {
+  if (bytes <= 0) return 0;
+  if (reinterpret_cast<uintptr_t>(dst) & 3) return -2;
+  sa::zero_async(dst, (size_t)bytes, s);
+  return 0;
+}

@@ -60,7 +60,21 @@ gemm_f32_kernel(GemmArgs g) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  // 1-d grid (padded to a multiple of 8): XCD x works through the x-th eighth
+  // of the tile list in bands of 8 tile rows, so that the workgroups resident
+  // on one XCD share A and B panels through its L2
+  int64_t m0, n0;
+  {
+    const int ntm = (int)((g.M + BM - 1) / BM), ntn = (int)((g.N + BN - 1) / BN);
+    const int w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (w >= ntm * ntn) return;
+    const int band = 8 * ntn;
+    const int first = (w / band) * 8;
+    const int rows = min(8, ntm - first);
+    const int in_band = w - (w / band) * band;
+    m0 = (int64_t)(first + in_band % rows) * BM;
+    n0 = (int64_t)(in_band / rows) * BN;
+  }
   const float *A = (const float *)g.A + (int64_t)blockIdx.z * g.a_bs;
   const float *B = (const float *)g.B + (int64_t)blockIdx.z * g.b_bs;
   float *C = (float *)g.C + (int64_t)blockIdx.z * g.c_bs;
@@ -779,11 +793,11 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
     if (amode == LD_GENERIC || bmode == LD_GENERIC)
       amode = bmode = LD_GENERIC;
     if (big) {
-      dim3 grid((unsigned)((N + 127) / 128), (unsigned)((M + 127) / 128),
-                (unsigned)batch);
+      dim3 grid((unsigned)((((N + 127) / 128) * ((M + 127) / 128) + 7) / 8 * 8),
+                1, (unsigned)batch);
       launch_f32<128, 128>(g, amode, bmode, grid, s);
     } else {
-      dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64),
+      dim3 grid((unsigned)((((N + 63) / 64) * ((M + 63) / 64) + 7) / 8 * 8), 1,
                 (unsigned)batch);
       launch_f32<64, 64>(g, amode, bmode, grid, s);
     }

@@ -113,6 +113,10 @@ int sa_gemm_splitk_reduce(int dtype, const float *part, int splits, int64_t M,
                           int64_t ldc, const void *bias, int act,
                           hipStream_t s);
 
+// device-to-device copy / zero-fill as kernels (4-byte aligned pointers)
+int sa_copy_bytes(void *dst, const void *src, int64_t bytes, hipStream_t s);
+int sa_zero_bytes(void *dst, int64_t bytes, hipStream_t s);
+
 // ---- layernorm.hip ------------------------------------------------------------------------
 // x, y, gamma, beta share dtype; gamma / beta may be null; mean / rstd: float[rows]
 int sa_layernorm_fwd(int dtype, const void *x, const void *gamma,

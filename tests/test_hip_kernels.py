@@ -689,3 +689,14 @@ def test_gemm_16bit_split_reduction(maths, dt, M, N, K):
             bias=g(bias, dev), act=1)
     want = torch.relu(0.25 * ref + bias.float()).to(dt).float()
     assert torch.equal(c.float().cpu(), want)
+
+
+def test_byte_copy_of_unsupported_dtypes(maths):
+    """uint8 / int64 tensors have no arithmetic kernels; copies go through the
+    byte-copy kernel (odd sizes exercise the tail)."""
+    hm, cm, dev = maths
+    for dt, n in ((torch.uint8, 1003), (torch.int64, 77), (torch.uint8, 4096)):
+        src = torch.randint(0, 200, (n,), dtype=dt).to(dev.torch_device)
+        dst = torch.zeros_like(src)
+        hm.copy(src, dst)
+        assert torch.equal(src.cpu(), dst.cpu())

@@ -55,7 +55,10 @@ def update(sgd, loss, dist_option, spars):
         sgd.backward_and_sparse_update(loss, topK=False, spars=spars)
 
 
-def main(argv=None):
+def main(argv=None, nccl_id=None, local_rank=None, world_size=None):
+    """``nccl_id`` / ``local_rank`` / ``world_size`` are given by a parent that
+    starts the ranks itself (mnist_multiprocess.py); under a launcher they
+    come from the environment."""
     ap = argparse.ArgumentParser()
     ap.add_argument("-m", "--max-epoch", type=int, default=2)
     ap.add_argument("-b", "--batch-size", type=int, default=64)
@@ -70,8 +73,9 @@ def main(argv=None):
 
     sgd = opt.SGD(lr=args.lr, momentum=0.9, weight_decay=1e-5)
     rank, world, local = 0, 1, 0
-    if args.dist:
-        sgd = opt.DistOpt(sgd)
+    if args.dist or nccl_id is not None:
+        sgd = opt.DistOpt(sgd, nccl_id=nccl_id, local_rank=local_rank,
+                          world_size=world_size)
         rank, world, local = sgd.global_rank, sgd.world_size, sgd.local_rank
     dev = device.create_cuda_gpu_on(local) if device.get_num_gpus() else \
         device.get_default_device()

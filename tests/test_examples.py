@@ -112,6 +112,22 @@ def test_raw_autograd_mnist_with_name_clashes():
     assert acc > 0.5
 
 
+def test_raw_autograd_resnet_helpers():
+    """The image helpers of the raw-autograd ResNet script: bilinear
+    enlargement keeps constants and means, augmentation keeps shape."""
+    mod = _import(os.path.join("cnn", "autograd"), "resnet_cifar10")
+    rng = np.random.RandomState(0)
+    x = rng.rand(3, 2, 8, 8).astype(np.float32)
+    big = mod.enlarge(x, 32)
+    assert big.shape == (3, 2, 32, 32)
+    np.testing.assert_allclose(big.mean((2, 3)), x.mean((2, 3)), atol=0.03)
+    np.testing.assert_allclose(mod.enlarge(np.ones_like(x), 20), 1.0,
+                               rtol=1e-6)
+    assert np.array_equal(mod.enlarge(x, 8), x)
+    aug = mod.augment(x, rng)
+    assert aug.shape == x.shape and np.isfinite(aug).all()
+
+
 def test_folder_dataset_with_prefetch(tmp_path, monkeypatch):
     monkeypatch.setattr("tempfile.tempdir", str(tmp_path))
     mod = _import("largedataset_cnn", "train_largedata")

@@ -1,0 +1,64 @@
+// Record writers of the C++ API: (key, value) tuples to a binary record file
+// or one value per line to a text file.  The file formats are those of the
+// runtime's record files (runtime/binfile.h, runtime/textfile.h).
+// API parity: reference include/singa/io/writer.h (Writer, BinFileWriter,
+// TextFileWriter; the LMDB writer needs a library this build does not have).
+#pragma once
+#include <string>
+
+#include "../../../../runtime/binfile.h"
+#include "../../../../runtime/textfile.h"
+
+namespace singa {
+namespace io {
+
+enum Mode { kCreate, kAppend };
+
+class Writer {
+ public:
+  virtual ~Writer() {}
+  virtual bool Open(const std::string &path, Mode mode) = 0;
+  virtual void Close() = 0;
+  /// false when the tuple is rejected (empty value)
+  virtual bool Write(const std::string &key, const std::string &value) = 0;
+  virtual void Flush() = 0;
+};
+
+class BinFileWriter : public Writer {
+ public:
+  ~BinFileWriter() override { Close(); }
+  bool Open(const std::string &path, Mode mode) override {
+    return impl_.Open(path, mode == kAppend);
+  }
+  /// `capacity` bytes are buffered between writes to the file
+  bool Open(const std::string &path, Mode mode, int capacity) {
+    return impl_.Open(path, mode == kAppend, capacity);
+  }
+  void Close() override { impl_.Close(); }
+  bool Write(const std::string &key, const std::string &value) override {
+    return impl_.Write(key, value);
+  }
+  void Flush() override { impl_.Flush(); }
+
+ private:
+  ::singa_amd::BinFileWriter impl_;
+};
+
+class TextFileWriter : public Writer {
+ public:
+  ~TextFileWriter() override { Close(); }
+  bool Open(const std::string &path, Mode mode) override {
+    return impl_.Open(path, mode == kAppend);
+  }
+  void Close() override { impl_.Close(); }
+  bool Write(const std::string &key, const std::string &value) override {
+    return impl_.Write(key, value);
+  }
+  void Flush() override { impl_.Flush(); }
+
+ private:
+  ::singa_amd::TextFileWriter impl_;
+};
+
+}  // namespace io
+}  // namespace singa

@@ -267,10 +267,9 @@ const std::pair<Tensor, std::vector<Tensor>> BatchNorm::Backward(
   Tensor dscale, dbias;
   Tensor dx = BatchNormBackward(grad, x, bnScale_, mean, invstd, &dscale,
                                 &dbias);
-  Tensor zm(Shape{channels_}, grad.device()), zv(Shape{channels_}, grad.device());
-  zm.SetValue(0.f);
-  zv.SetValue(0.f);
-  return {dx, {dscale, dbias, zm, zv}};
+  // the running statistics are state, not trained: their gradient slots stay
+  // empty, and the training loop leaves such parameters to the layer
+  return {dx, {dscale, dbias, Tensor(), Tensor()}};
 }
 
 // ---- Dropout -----------------------------------------------------------------------

@@ -425,7 +425,8 @@ const std::pair<float, float> FeedForwardNet::TrainOnBatch(int epoch,
   auto values = GetParamValues();
   CHECK_EQ(grads.size(), values.size());
   for (size_t k = 0; k < grads.size(); ++k)
-    updater_->Apply(epoch, names[k], grads[k], values[k]);
+    if (!grads[k].empty())  // e.g. running statistics of BatchNorm
+      updater_->Apply(epoch, names[k], grads[k], values[k]);
   return {loss, metric};
 }
 

@@ -198,7 +198,8 @@ static LayerResult RunLayer(const std::string &type, const LayerConf &base,
   LayerResult r;
   r.y = ToVec(y);
   r.dx = ToVec(ret.first);
-  for (auto &g : ret.second) r.dp.push_back(ToVec(g));
+  for (auto &g : ret.second)
+    r.dp.push_back(g.empty() ? std::vector<float>() : ToVec(g));
   return r;
 }
 
@@ -417,7 +418,8 @@ static RnnResult RunRnn(const std::string &mode, std::shared_ptr<Device> dev,
   if (backward) {
     auto ret = layer->Backward(kTrain, grads);
     for (auto &g : ret.first) r.dx.push_back(ToVec(g));
-    for (auto &g : ret.second) r.dp.push_back(ToVec(g));
+    for (auto &g : ret.second)
+    r.dp.push_back(g.empty() ? std::vector<float>() : ToVec(g));
   } else {
     layer->Backward(kTrain, grads);
   }

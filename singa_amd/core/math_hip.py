@@ -464,6 +464,8 @@ class HipMath(object):
     def _tuned(self, mode, g, key, launch):
         """Set g.tile / g.split_target for this launch.  ``launch(g)`` runs the
         convolution once (it only overwrites the output)."""
+        if key[4] > 1 and key[4] == key[0][1] == key[1][0]:
+            return  # depthwise kernels have no launch plan to choose
         plan = self._conv_plans.get((mode,) + key)
         if plan is None:
             if not _CONV_AUTOTUNE or torch.cuda.is_current_stream_capturing():

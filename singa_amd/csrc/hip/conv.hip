@@ -888,6 +888,7 @@ static bool window_ok(int64_t image_elems, int64_t span, int64_t filter_elems,
 int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                 const void *bias, void *y, hipStream_t s) {
   if (!geom_ok(g)) return -2;
+  if (sa_dwconv_applies(g)) return sa_dwconv_fwd(dtype, g, x, w, bias, y, s);
   ConvArgs a = make_args(*g, CONV_FWD);
   a.a = w; a.b = x; a.out = y; a.bias = bias;
   a.a_elems = (int64_t)g->K * a.Cg * a.RS;
@@ -914,6 +915,8 @@ int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
                          hipStream_t s) {
   if (!geom_ok(g)) return -2;
   if (addend == dx) return -2;
+  if (sa_dwconv_applies(g))
+    return sa_dwconv_bwd_data(dtype, g, dy, w, addend, dx, s);
   ConvArgs base = make_args(*g, CONV_BWD_DATA);
   base.a = w; base.b = dy; base.out = dx;
   base.a_elems = (int64_t)g->K * base.Cg * base.RS;
@@ -989,6 +992,8 @@ int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
 int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
                        const void *x, void *dw, hipStream_t s) {
   if (!geom_ok(g)) return -2;
+  if (sa_dwconv_bwd_weight_applies(g))
+    return sa_dwconv_bwd_weight(dtype, g, dy, x, dw, s);
   ConvArgs a = make_args(*g, CONV_BWD_WEIGHT);
   a.a = dy; a.b = x; a.out = dw;
   a.a_elems = (int64_t)g->N * g->K * a.PQ;

@@ -1,0 +1,193 @@
+// Depthwise convolution (groups == C == K: every output channel filters one
+// input channel).  As an implicit GEMM each group would be a 1 x (R*S) x (N*P*Q)
+// product that fills 1/64 of an MFMA tile, so these layers get kernels of
+// their own: they are bound by memory traffic, one thread per output element
+// with the filter taps of a channel coming out of the scalar / L1 path, and
+// the filter gradient is a per-channel block reduction.
+// Role parity: the grouped cuDNN convolution the reference uses for
+// SeparableConv2d (src/model/operation/convolution.cc:230-330 with
+// group == channels).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sa {
+
+struct DwArgs {
+  int N, C, H, W, R, S, P, Q;
+  int sh, sw, ph, pw;
+};
+
+static DwArgs dw_args(const ConvGeom &g) {
+  return DwArgs{g.N, g.C, g.H, g.W, g.R, g.S, g.P, g.Q,
+                g.stride_h, g.stride_w, g.pad_h, g.pad_w};
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+dw_fwd_kernel(const T *__restrict__ x, const T *__restrict__ w,
+              const T *__restrict__ bias, T *__restrict__ y, DwArgs a,
+              int total) {
+  const int step = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    const int q = i % a.Q;
+    int t = i / a.Q;
+    const int p = t % a.P;
+    const int nc = t / a.P;
+    const int c = nc % a.C;
+    const T *xp = x + (int64_t)nc * a.H * a.W;
+    const T *wp = w + c * a.R * a.S;
+    const int h0 = p * a.sh - a.ph, w0 = q * a.sw - a.pw;
+    float acc = bias ? to_f(bias[c]) : 0.f;
+    for (int r = 0; r < a.R; ++r) {
+      const int h = h0 + r;
+      if (h < 0 || h >= a.H) continue;
+      for (int s = 0; s < a.S; ++s) {
+        const int ww = w0 + s;
+        if (ww < 0 || ww >= a.W) continue;
+        acc += to_f(xp[h * a.W + ww]) * to_f(wp[r * a.S + s]);
+      }
+    }
+    y[i] = from_f<T>(acc);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+dw_bwd_data_kernel(const T *__restrict__ dy, const T *__restrict__ w,
+                   const T *__restrict__ addend, T *__restrict__ dx, DwArgs a,
+                   int total) {
+  const int step = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += step) {
+    const int ww = i % a.W;
+    int t = i / a.W;
+    const int h = t % a.H;
+    const int nc = t / a.H;
+    const int c = nc % a.C;
+    const T *dyp = dy + (int64_t)nc * a.P * a.Q;
+    const T *wp = w + c * a.R * a.S;
+    float acc = addend ? to_f(addend[i]) : 0.f;
+    for (int r = 0; r < a.R; ++r) {
+      const int hh = h + a.ph - r;
+      if (hh < 0 || hh % a.sh) continue;
+      const int p = hh / a.sh;
+      if (p >= a.P) continue;
+      for (int s = 0; s < a.S; ++s) {
+        const int wq = ww + a.pw - s;
+        if (wq < 0 || wq % a.sw) continue;
+        const int q = wq / a.sw;
+        if (q >= a.Q) continue;
+        acc += to_f(dyp[p * a.Q + q]) * to_f(wp[r * a.S + s]);
+      }
+    }
+    dx[i] = from_f<T>(acc);
+  }
+}
+
+// grid (C, nsplit): block (c, j) reduces images j, j + nsplit, ... of channel
+// c; with nsplit > 1 the partial sums meet in dw through atomics (dw zeroed by
+// the launcher).
+template <typename T, int R, int S>
+__global__ void __launch_bounds__(256)
+dw_bwd_weight_kernel(const T *__restrict__ dy, const T *__restrict__ x,
+                     float *__restrict__ dw, DwArgs a) {
+  __shared__ float red[17];
+  const int c = blockIdx.x;
+  float acc[R * S];
+#pragma unroll
+  for (int k = 0; k < R * S; ++k) acc[k] = 0.f;
+  const int PQ = a.P * a.Q;
+  for (int n = blockIdx.y; n < a.N; n += gridDim.y) {
+    const T *dyp = dy + ((int64_t)n * a.C + c) * PQ;
+    const T *xp = x + ((int64_t)n * a.C + c) * a.H * a.W;
+    for (int i = threadIdx.x; i < PQ; i += blockDim.x) {
+      const int p = i / a.Q, q = i - p * a.Q;
+      const float g = to_f(dyp[i]);
+      const int h0 = p * a.sh - a.ph, w0 = q * a.sw - a.pw;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const int h = h0 + r;
+        const bool hin = h >= 0 && h < a.H;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          const int ww = w0 + s;
+          if (hin && ww >= 0 && ww < a.W)
+            acc[r * S + s] += g * to_f(xp[h * a.W + ww]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R * S; ++k) {
+    const float v = block_sum(acc[k], red);
+    if (threadIdx.x == 0) {
+      if (gridDim.y > 1)
+        atomicAdd(dw + c * R * S + k, v);
+      else
+        dw[c * R * S + k] = v;
+    }
+  }
+}
+
+template <typename T, int R, int S>
+static void launch_dw_bwd_weight(const ConvGeom &g, const void *dy,
+                                 const void *x, float *dw, hipStream_t s) {
+  // enough blocks to cover the chip several times over, never more than N
+  int nsplit = 1;
+  while (g.C * nsplit < 1024 && nsplit * 2 <= g.N) nsplit *= 2;
+  if (nsplit > 1) zero_async(dw, sizeof(float) * g.C * R * S, s);
+  hipLaunchKernelGGL((dw_bwd_weight_kernel<T, R, S>), dim3(g.C, nsplit),
+                     dim3(256), 0, s, (const T *)dy, (const T *)x, dw,
+                     dw_args(g));
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+bool sa_dwconv_applies(const ConvGeom *g) {
+  return g->groups > 1 && g->groups == g->C && g->K == g->C;
+}
+
+bool sa_dwconv_bwd_weight_applies(const ConvGeom *g) {
+  return sa_dwconv_applies(g) && g->R == g->S &&
+         (g->R == 3 || g->R == 5 || g->R == 7);
+}
+
+int sa_dwconv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
+                  const void *bias, void *y, hipStream_t s) {
+  const int64_t total = (int64_t)g->N * g->C * g->P * g->Q;
+  if (total == 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((dw_fwd_kernel<T>), dim3(grid_for(total, 256, 2)),
+                       dim3(256), 0, s, (const T *)x, (const T *)w,
+                       (const T *)bias, (T *)y, dw_args(*g), (int)total);
+  });
+  return 0;
+}
+
+int sa_dwconv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
+                       const void *w, const void *addend, void *dx,
+                       hipStream_t s) {
+  const int64_t total = (int64_t)g->N * g->C * g->H * g->W;
+  if (total == 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((dw_bwd_data_kernel<T>), dim3(grid_for(total, 256, 2)),
+                       dim3(256), 0, s, (const T *)dy, (const T *)w,
+                       (const T *)addend, (T *)dx, dw_args(*g), (int)total);
+  });
+  return 0;
+}
+
+int sa_dwconv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
+                         const void *x, void *dw, hipStream_t s) {
+  if (!sa_dwconv_bwd_weight_applies(g)) return -2;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    if (g->R == 3)
+      launch_dw_bwd_weight<T, 3, 3>(*g, dy, x, (float *)dw, s);
+    else if (g->R == 5)
+      launch_dw_bwd_weight<T, 5, 5>(*g, dy, x, (float *)dw, s);
+    else
+      launch_dw_bwd_weight<T, 7, 7>(*g, dy, x, (float *)dw, s);
+  });
+  return 0;
+}

@@ -163,6 +163,19 @@ int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
 int sa_conv_bwd_bias(int dtype, const void *dy, void *db, int N, int K,
                      int PQ, hipStream_t s);
 
+// ---- depthwise.hip ----------------------------------------------------------------------------
+// groups == C == K.  The sa_conv_* entry points route such geometries here
+// themselves; the filter gradient has kernels for 3x3, 5x5 and 7x7 windows.
+bool sa_dwconv_applies(const ConvGeom *g);
+bool sa_dwconv_bwd_weight_applies(const ConvGeom *g);
+int sa_dwconv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
+                  const void *bias, void *y, hipStream_t s);
+int sa_dwconv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
+                       const void *w, const void *addend, void *dx,
+                       hipStream_t s);
+int sa_dwconv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
+                         const void *x, void *dw, hipStream_t s);
+
 // ---- batchnorm.hip ----------------------------------------------------------------------------------
 // x, y: (N, C, HW) contiguous; statistics and affine parameters are float32.
 int sa_bn_fwd_train(int dtype, const void *x, const float *scale,

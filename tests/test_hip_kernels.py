@@ -358,6 +358,15 @@ CONV_CASES = [
     (1, 3, 35, 35, 8, 11, 11, 4, 2, 1),
     # few tiles, long reduction: split across workgroups in every pass
     (2, 512, 7, 7, 512, 3, 3, 1, 1, 1),
+    # depthwise (groups == C == K): kernels of their own; the 4x4 filter
+    # gradient falls back to the grouped implicit GEMM
+    (4, 32, 19, 19, 32, 3, 3, 1, 1, 32),
+    (3, 24, 17, 15, 24, 3, 3, 2, 1, 24),
+    (2, 16, 14, 14, 16, 5, 5, 1, 2, 16),
+    (2, 12, 21, 21, 12, 7, 7, 2, 3, 12),
+    (2, 6, 10, 10, 6, 4, 4, 1, 1, 6),
+    (2, 1024, 5, 5, 1024, 3, 3, 1, 1, 1024),
+    (16, 728, 19, 19, 728, 3, 3, 1, 1, 728),
 ]
 
 

@@ -7,6 +7,8 @@
 // Role parity: the grouped cuDNN convolution the reference uses for
 // SeparableConv2d (src/model/operation/convolution.cc:230-330 with
 // group == channels).
+#include <algorithm>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -83,6 +85,91 @@ dw_bwd_data_kernel(const T *__restrict__ dy, const T *__restrict__ w,
   }
 }
 
+// Stride-1 planes through LDS: a block stages `ppb` whole input planes (small
+// images) or one band of rows of one plane (large images) into a zero-bordered
+// float tile, so the R*S taps of an output are unconditional LDS reads.  With
+// FLIP the filter is applied rotated by 180 degrees, which turns the same loop
+// into backward-data (in = dy, out = dx, pad = R-1-pad).
+template <typename T, int R, int S, bool FLIP>
+__global__ void __launch_bounds__(256)
+dw_plane_kernel(const T *__restrict__ in, const T *__restrict__ w,
+                const T *__restrict__ bias, const T *__restrict__ addend,
+                T *__restrict__ out, int planes, int C, int IH, int IW, int OH,
+                int OW, int padh, int padw, int ppb, int band, int nbands) {
+  extern __shared__ float lds[];
+  const int LW = OW + S - 1;
+  const int LH = band + R - 1;
+  float *taps = lds + ppb * LH * LW;
+  const int blk = blockIdx.x / nbands;
+  const int p0 = (blockIdx.x - blk * nbands) * band;   // first output row
+  const int plane0 = blk * ppb;
+  const int np = min(ppb, planes - plane0);
+  const int rows = min(band, OH - p0);
+  for (int i = threadIdx.x; i < np * R * S; i += blockDim.x) {
+    const int j = i / (R * S), k = i - j * (R * S);
+    const int c = (plane0 + j) % C;
+    taps[i] = to_f(w[c * R * S + (FLIP ? R * S - 1 - k : k)]);
+  }
+  const int fill = np * LH * LW;
+  for (int i = threadIdx.x; i < fill; i += blockDim.x) {
+    const int j = i / (LH * LW);
+    const int rem = i - j * (LH * LW);
+    const int lr = rem / LW, lc = rem - lr * LW;
+    const int ir = p0 + lr - padh, ic = lc - padw;
+    float v = 0.f;
+    if (ir >= 0 && ir < IH && ic >= 0 && ic < IW)
+      v = to_f(in[((int64_t)(plane0 + j) * IH + ir) * IW + ic]);
+    lds[i] = v;
+  }
+  __syncthreads();
+  const int work = np * rows * OW;
+  for (int i = threadIdx.x; i < work; i += blockDim.x) {
+    const int j = i / (rows * OW);
+    const int rem = i - j * (rows * OW);
+    const int p = rem / OW, q = rem - p * OW;
+    const float *t = lds + j * LH * LW + p * LW + q;
+    const float *k = taps + j * R * S;
+    float acc = bias ? to_f(bias[(plane0 + j) % C]) : 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int s2 = 0; s2 < S; ++s2) acc += t[r * LW + s2] * k[r * S + s2];
+    const int64_t o = ((int64_t)(plane0 + j) * OH + p0 + p) * OW + q;
+    if (addend) acc += to_f(addend[o]);
+    out[o] = from_f<T>(acc);
+  }
+}
+
+// false when the geometry is outside what the LDS kernel covers
+template <typename T, int R, int S, bool FLIP>
+static bool launch_dw_plane(const void *in, const void *w, const void *bias,
+                            const void *addend, void *out, int planes, int C,
+                            int IH, int IW, int OH, int OW, int padh, int padw,
+                            hipStream_t s) {
+  if (padh < 0 || padw < 0 || padh > R - 1 || padw > S - 1) return false;
+  const int LW = OW + S - 1;
+  const int kLimit = 12 * 1024;  // floats of LDS per block: 3 blocks per CU
+  if ((R + 7) * LW > kLimit) return false;
+  int band = OH, nbands = 1, ppb = 1;
+  if ((OH + R - 1) * LW > kLimit) {
+    band = kLimit / LW - (R - 1);
+    nbands = (OH + band - 1) / band;
+    band = (OH + nbands - 1) / nbands;   // even bands
+  } else {
+    ppb = std::max(1, std::min(kLimit / ((OH + R - 1) * LW),
+                               2048 / std::max(1, OH * OW)));
+  }
+  const int64_t blocks = (int64_t)((planes + ppb - 1) / ppb) * nbands;
+  if (blocks > 0x7fffffff) return false;
+  const size_t bytes =
+      sizeof(float) * ((size_t)ppb * (band + R - 1) * LW + (size_t)ppb * R * S);
+  hipLaunchKernelGGL((dw_plane_kernel<T, R, S, FLIP>), dim3((unsigned)blocks),
+                     dim3(256), bytes, s, (const T *)in, (const T *)w,
+                     (const T *)bias, (const T *)addend, (T *)out, planes, C,
+                     IH, IW, OH, OW, padh, padw, ppb, band, nbands);
+  return true;
+}
+
 // grid (C, nsplit): block (c, j) reduces images j, j + nsplit, ... of channel
 // c; with nsplit > 1 the partial sums meet in dw through atomics (dw zeroed by
 // the launcher).
@@ -157,6 +244,15 @@ int sa_dwconv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                   const void *bias, void *y, hipStream_t s) {
   const int64_t total = (int64_t)g->N * g->C * g->P * g->Q;
   if (total == 0) return 0;
+  if (g->stride_h == 1 && g->stride_w == 1 && g->R == 3 && g->S == 3) {
+    bool done = false;
+    SA_DISPATCH_FLOAT(dtype, T, {
+      done = launch_dw_plane<T, 3, 3, false>(
+          x, w, bias, nullptr, y, g->N * g->C, g->C, g->H, g->W, g->P, g->Q,
+          g->pad_h, g->pad_w, s);
+    });
+    if (done) return 0;
+  }
   SA_DISPATCH_FLOAT(dtype, T, {
     hipLaunchKernelGGL((dw_fwd_kernel<T>), dim3(grid_for(total, 256, 2)),
                        dim3(256), 0, s, (const T *)x, (const T *)w,
@@ -170,6 +266,16 @@ int sa_dwconv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
                        hipStream_t s) {
   const int64_t total = (int64_t)g->N * g->C * g->H * g->W;
   if (total == 0) return 0;
+  if (g->stride_h == 1 && g->stride_w == 1 && g->R == 3 && g->S == 3 &&
+      g->P == g->H + 2 * g->pad_h - 2 && g->Q == g->W + 2 * g->pad_w - 2) {
+    bool done = false;
+    SA_DISPATCH_FLOAT(dtype, T, {
+      done = launch_dw_plane<T, 3, 3, true>(
+          dy, w, nullptr, addend, dx, g->N * g->C, g->C, g->P, g->Q, g->H,
+          g->W, 2 - g->pad_h, 2 - g->pad_w, s);
+    });
+    if (done) return 0;
+  }
   SA_DISPATCH_FLOAT(dtype, T, {
     hipLaunchKernelGGL((dw_bwd_data_kernel<T>), dim3(grid_for(total, 256, 2)),
                        dim3(256), 0, s, (const T *)dy, (const T *)w,

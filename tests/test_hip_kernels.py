@@ -367,6 +367,11 @@ CONV_CASES = [
     (2, 6, 10, 10, 6, 4, 4, 1, 1, 6),
     (2, 1024, 5, 5, 1024, 3, 3, 1, 1, 1024),
     (16, 728, 19, 19, 728, 3, 3, 1, 1, 728),
+    # stride-1 3x3 depthwise staged through LDS: row bands of a large plane,
+    # no padding, padding wider than "same"
+    (1, 4, 150, 150, 4, 3, 3, 1, 1, 4),
+    (2, 5, 40, 33, 5, 3, 3, 1, 0, 5),
+    (1, 3, 12, 12, 3, 3, 3, 1, 2, 3),
 ]
 
 

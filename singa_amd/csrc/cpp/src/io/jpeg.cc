@@ -1,4 +1,7 @@
 // Baseline JPEG codec, see include/singa/io/jpeg.h.
+// The transforms are written as short fixed-count loops over contiguous rows;
+// they only pay off once the compiler vectorises them.
+#pragma GCC optimize("O3")
 #include "singa/io/jpeg.h"
 
 #include <algorithm>
@@ -91,24 +94,47 @@ void Fdct(const float *in, float *out) {  // in[y*8+x] -> out[v*8+u]
     }
 }
 
-void Idct(const float *in, float *out) {  // in[v*8+u] -> out[y*8+x]
-  float tmp[64];
-  for (int v = 0; v < 8; ++v)
-    for (int x = 0; x < 8; ++x) {
-      float s = 0.f;
-      for (int u = 0; u < 8; ++u) s += in[v * 8 + u] * kDct.m[u][x];
-      tmp[v * 8 + x] = s;
+// Eight floats as one value: the compiler lowers the arithmetic below to the
+// widest vector unit the build targets (two SSE registers by default).
+typedef float V8 __attribute__((vector_size(32), aligned(4)));
+
+inline V8 Splat(float c) { return V8{c, c, c, c, c, c, c, c}; }
+
+// Row-column inverse transform on whole rows.  `rows` has bit v set when row
+// v of the coefficient block holds a nonzero value: after quantisation most
+// rows are empty and drop out of both passes.
+void Idct(const float *in, unsigned rows, float *out) {  // in[v*8+u] -> out[y*8+x]
+  V8 basis[8];
+  std::memcpy(basis, kDct.m, sizeof(basis));
+  V8 acc[8];
+  for (int y = 0; y < 8; ++y) acc[y] = Splat(0.f);
+  for (int v = 0; v < 8; ++v) {
+    if (!((rows >> v) & 1)) continue;
+    V8 t = Splat(0.f);
+    for (int u = 0; u < 8; ++u) {
+      const float c = in[v * 8 + u];
+      if (c != 0.f) t += Splat(c) * basis[u];
     }
-  for (int y = 0; y < 8; ++y)
-    for (int x = 0; x < 8; ++x) {
-      float s = 0.f;
-      for (int v = 0; v < 8; ++v) s += tmp[v * 8 + x] * kDct.m[v][y];
-      out[y * 8 + x] = s;
-    }
+    for (int y = 0; y < 8; ++y) acc[y] += Splat(kDct.m[v][y]) * t;
+  }
+  std::memcpy(out, acc, sizeof(acc));
 }
 
-inline uint8_t Clamp8(float v) {
-  return static_cast<uint8_t>(std::min(255.f, std::max(0.f, std::round(v))));
+// out[i] + 128 rounded and clamped to 0..255, a row of eight at a time
+inline void StoreRow8(const float *row, uint8_t *dst) {
+  typedef int I8 __attribute__((vector_size(32)));
+  V8 v;
+  std::memcpy(&v, row, sizeof(v));
+  v += Splat(128.5f);
+  const V8 lo = Splat(0.f), hi = Splat(255.5f);
+  v = v < lo ? lo : v;
+  v = v > hi ? hi : v;
+  const I8 iv = __builtin_convertvector(v, I8);
+  for (int x = 0; x < 8; ++x) dst[x] = static_cast<uint8_t>(iv[x]);
+}
+
+inline uint8_t Clamp8(float v) {  // round half up on the clamped value
+  return static_cast<uint8_t>(std::min(255.f, std::max(0.f, v)) + 0.5f);
 }
 
 // ---- Huffman code built from a (bits, vals) table specification ------------
@@ -134,13 +160,24 @@ struct HuffDec {
   // canonical decoding: per length the smallest code, its index, and count
   int mincode[17], maxcode[18], valptr[17];
   uint8_t vals[256];
+  // codes of up to kLook bits, indexed by the next kLook bits of the stream:
+  // (length << 8) | symbol, 0 = longer code
+  static constexpr int kLook = 9;
+  uint16_t look[1 << kLook];
   bool present = false;
   void Build(const uint8_t *bits, const uint8_t *v, int n) {
     std::memcpy(vals, v, n);
+    std::memset(look, 0, sizeof(look));
     int k = 0, c = 0;
     for (int l = 1; l <= 16; ++l) {
       valptr[l] = k;
       mincode[l] = c;
+      if (l <= kLook)
+        for (int i = 0; i < bits[l - 1] && k + i < n; ++i) {
+          const int first = (c + i) << (kLook - l);
+          for (int f = 0; f < (1 << (kLook - l)) && first + f < (1 << kLook); ++f)
+            look[first + f] = static_cast<uint16_t>((l << 8) | v[k + i]);
+        }
       c += bits[l - 1];
       k += bits[l - 1];
       maxcode[l] = bits[l - 1] ? c - 1 : -1;
@@ -324,60 +361,106 @@ struct Component {
   int pred = 0;
 };
 
+// Entropy-coded bytes go through a 64-bit window (stuffed zero bytes after
+// 0xff removed); the window is never filled past a marker, so at a restart
+// boundary pos() is the marker itself.
 class BitReader {
  public:
   BitReader(const uint8_t *p, size_t n) : p_(p), n_(n) {}
-  // returns -1 at a marker / end of data
-  int Bit() {
-    if (cnt_ == 0) {
-      if (pos_ >= n_) return -1;
-      uint8_t b = p_[pos_];
+  /// the next n <= 16 bits without consuming them, zero-padded at the end
+  int Peek(int n) {
+    if (cnt_ < n) Fill();
+    return static_cast<int>(buf_ >> (64 - n));
+  }
+  /// false when fewer than n bits are left before a marker / the end
+  bool Skip(int n) {
+    if (cnt_ < n) {
+      Fill();
+      if (cnt_ < n) return false;
+    }
+    buf_ <<= n;
+    cnt_ -= n;
+    return true;
+  }
+  /// n <= 16 bits as an unsigned number, -1 at a marker / end of data
+  int Bits(int n) {
+    if (n == 0) return 0;
+    const int v = Peek(n);
+    return Skip(n) ? v : -1;
+  }
+  // Unchecked variants for the coefficient loop: after Ensure() the window
+  // holds at least 32 bits (one code of up to 16 bits plus up to 15 value
+  // bits) unless the data ends, in which case the missing bits read as zero
+  // and Underflow() reports it afterwards.
+  void Ensure() { if (cnt_ < 32) Fill(); }
+  int PeekFast(int n) const { return static_cast<int>(buf_ >> (64 - n)); }
+  void SkipFast(int n) { buf_ <<= n; cnt_ -= n; }
+  bool Underflow() const { return cnt_ < 0; }
+  void Align() {
+    if (cnt_ < 0) cnt_ = 0;
+    const int d = cnt_ & 7;
+    buf_ <<= d;
+    cnt_ -= d;
+  }
+  size_t pos() const { return pos_; }
+  void set_pos(size_t p) { pos_ = p; cnt_ = 0; buf_ = 0; }
+
+ private:
+  void Fill() {
+    while (cnt_ <= 56 && pos_ < n_) {
+      const uint8_t b = p_[pos_];
       if (b == 0xff) {
-        if (pos_ + 1 >= n_) return -1;
-        if (p_[pos_ + 1] == 0) pos_ += 2;
-        else return -1;  // a marker: stop
+        if (pos_ + 1 >= n_ || p_[pos_ + 1] != 0) break;  // a marker: stop
+        pos_ += 2;
       } else {
         ++pos_;
       }
-      cur_ = b;
-      cnt_ = 8;
+      buf_ |= static_cast<uint64_t>(b) << (56 - cnt_);
+      cnt_ += 8;
     }
-    --cnt_;
-    return (cur_ >> cnt_) & 1;
   }
-  int Bits(int n) {
-    int v = 0;
-    for (int i = 0; i < n; ++i) {
-      const int b = Bit();
-      if (b < 0) return -1;
-      v = (v << 1) | b;
-    }
-    return v;
-  }
-  void Align() { cnt_ = 0; }
-  size_t pos() const { return pos_; }
-  void set_pos(size_t p) { pos_ = p; cnt_ = 0; }
-
- private:
   const uint8_t *p_;
   size_t n_, pos_ = 0;
   int cnt_ = 0;
-  uint8_t cur_ = 0;
+  uint64_t buf_ = 0;
 };
 
-int DecodeSymbol(BitReader *br, const HuffDec &h) {
-  int code = 0;
-  for (int l = 1; l <= 16; ++l) {
-    const int b = br->Bit();
-    if (b < 0) return -1;
-    code = (code << 1) | b;
-    if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l])
+// after br->Ensure(); -1 = no such code
+inline int DecodeSymbolFast(BitReader *br, const HuffDec &h) {
+  const int peek = br->PeekFast(16);
+  const int e = h.look[peek >> (16 - HuffDec::kLook)];
+  if (e) {
+    br->SkipFast(e >> 8);
+    return e & 255;
+  }
+  for (int l = HuffDec::kLook + 1; l <= 16; ++l) {
+    const int code = peek >> (16 - l);
+    if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) {
+      br->SkipFast(l);
       return h.vals[h.valptr[l] + code - h.mincode[l]];
+    }
   }
   return -1;
 }
 
-inline int Extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+int DecodeSymbol(BitReader *br, const HuffDec &h) {
+  const int peek = br->Peek(16);
+  const int e = h.look[peek >> (16 - HuffDec::kLook)];
+  if (e) return br->Skip(e >> 8) ? (e & 255) : -1;
+  for (int l = HuffDec::kLook + 1; l <= 16; ++l) {
+    const int code = peek >> (16 - l);
+    if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l])
+      return br->Skip(l) ? h.vals[h.valptr[l] + code - h.mincode[l]] : -1;
+  }
+  return -1;
+}
+
+// value of an s-bit field: fields below 2^(s-1) stand for negative numbers
+// (branch-free: the sign of v - 2^(s-1) selects the offset)
+inline int Extend(int v, int s) {
+  const int m = 1 << (s - 1);
+  return v + (((v - m) >> 31) & (1 - 2 * m));
+}
 
 bool Fail(std::string *error, const char *why) {
   if (error) *error = why;
@@ -490,6 +573,7 @@ bool Decode(const std::string &data, std::vector<uint8_t> *pixels, int *width,
       BitReader br(p + pos + len, n - pos - len);
       int until_restart = restart;
       float coef[64], out[64];
+      static const float kZero7[7] = {0, 0, 0, 0, 0, 0, 0};
       for (int j = 0; j < my; ++j)
         for (int i = 0; i < mx; ++i) {
           if (restart && until_restart == 0) {
@@ -510,6 +594,7 @@ bool Decode(const std::string &data, std::vector<uint8_t> *pixels, int *width,
             for (int by = 0; by < c.v; ++by)
               for (int bx = 0; bx < c.h; ++bx) {
                 std::memset(coef, 0, sizeof(coef));
+                unsigned rows = 1;  // the DC term sits in row 0
                 int t = DecodeSymbol(&br, hdc[c.td]);
                 if (t < 0 || t > 11) return Fail(error, "bad DC code");
                 int diff = 0;
@@ -521,8 +606,10 @@ bool Decode(const std::string &data, std::vector<uint8_t> *pixels, int *width,
                 c.pred += diff;
                 coef[0] = static_cast<float>(c.pred) * qt[c.tq][0];
                 for (int k = 1; k < 64;) {
-                  const int rs = DecodeSymbol(&br, hac[c.ta]);
-                  if (rs < 0) return Fail(error, "bad AC code");
+                  br.Ensure();
+                  const int rs = DecodeSymbolFast(&br, hac[c.ta]);
+                  if (rs < 0 || br.Underflow())
+                    return Fail(error, "bad AC code");
                   const int r = rs >> 4, sz = rs & 15;
                   if (sz == 0) {
                     if (r == 15) { k += 16; continue; }
@@ -530,19 +617,27 @@ bool Decode(const std::string &data, std::vector<uint8_t> *pixels, int *width,
                   }
                   k += r;
                   if (k > 63) return Fail(error, "AC run past block end");
-                  const int bits = br.Bits(sz);
-                  if (bits < 0) return Fail(error, "truncated scan");
+                  const int bits = br.PeekFast(sz);
+                  br.SkipFast(sz);
+                  if (br.Underflow()) return Fail(error, "truncated scan");
                   const int zp = kZigzag[k];
                   coef[zp] = static_cast<float>(Extend(bits, sz)) * qt[c.tq][zp];
+                  rows |= 1u << (zp >> 3);
                   ++k;
                 }
-                Idct(coef, out);
                 const int px0 = (i * c.h + bx) * 8, py0 = (j * c.v + by) * 8;
-                const int stride = c.bw * 8;
-                for (int y = 0; y < 8; ++y)
-                  for (int x = 0; x < 8; ++x)
-                    c.plane[static_cast<size_t>(py0 + y) * stride + px0 + x] =
-                        Clamp8(out[y * 8 + x] + 128.f);
+                const size_t stride = static_cast<size_t>(c.bw) * 8;
+                uint8_t *dst = c.plane.data() + py0 * stride + px0;
+                if (rows == 1 && !std::memcmp(coef + 1, kZero7, sizeof(kZero7))) {
+                  // only the DC term: a flat block
+                  const uint8_t flat = Clamp8(coef[0] * 0.125f + 128.f);
+                  for (int y = 0; y < 8; ++y, dst += stride)
+                    std::memset(dst, flat, 8);
+                } else {
+                  Idct(coef, rows, out);
+                  for (int y = 0; y < 8; ++y, dst += stride)
+                    StoreRow8(out + y * 8, dst);
+                }
               }
           if (restart) --until_restart;
         }
@@ -553,44 +648,64 @@ bool Decode(const std::string &data, std::vector<uint8_t> *pixels, int *width,
   if (!decoded) return Fail(error, "no scan found");
   const int C = static_cast<int>(comps.size());
   pixels->assign(static_cast<size_t>(W) * H * C, 0);
-  for (int y = 0; y < H; ++y)
-    for (int x = 0; x < W; ++x) {
-      float v[3] = {0.f, 128.f, 128.f};
-      for (int c = 0; c < C; ++c) {
-        const Component &cc = comps[c];
-        const int stride = cc.bw * 8;
-        if (cc.h == hmax && cc.v == vmax) {
-          v[c] = cc.plane[static_cast<size_t>(y) * stride + x];
-          continue;
-        }
-        // subsampled component: bilinear interpolation between sample
-        // centres (the 3/4 - 1/4 "triangle" filter for 2:1 sampling), edge
-        // samples replicated
-        const int cw = (W * cc.h + hmax - 1) / hmax;
-        const int ch = (H * cc.v + vmax - 1) / vmax;
-        const float fx = (x + 0.5f) * cc.h / hmax - 0.5f;
-        const float fy = (y + 0.5f) * cc.v / vmax - 0.5f;
-        const int x0 = static_cast<int>(std::floor(fx));
-        const int y0 = static_cast<int>(std::floor(fy));
-        const float wx = fx - x0, wy = fy - y0;
-        auto at = [&](int yy, int xx) {
-          yy = std::min(ch - 1, std::max(0, yy));
-          xx = std::min(cw - 1, std::max(0, xx));
-          return static_cast<float>(cc.plane[static_cast<size_t>(yy) * stride + xx]);
-        };
-        v[c] = (1 - wy) * ((1 - wx) * at(y0, x0) + wx * at(y0, x0 + 1)) +
-               wy * ((1 - wx) * at(y0 + 1, x0) + wx * at(y0 + 1, x0 + 1));
+  // Subsampled components: bilinear interpolation between sample centres (the
+  // 3/4 - 1/4 "triangle" filter for 2:1 sampling), edge samples replicated.
+  // The taps of a column depend on x only and are computed once.
+  struct Tap { int i0, i1; float w; };
+  auto taps = [](int n_out, int n_in, int num, int den) {
+    std::vector<Tap> t(n_out);
+    for (int o = 0; o < n_out; ++o) {
+      const float f = (o + 0.5f) * num / den - 0.5f;
+      const int i = static_cast<int>(std::floor(f));
+      t[o].w = f - i;
+      t[o].i0 = std::min(n_in - 1, std::max(0, i));
+      t[o].i1 = std::min(n_in - 1, std::max(0, i + 1));
+    }
+    return t;
+  };
+  std::vector<std::vector<Tap>> xt(C), yt(C);
+  std::vector<bool> full(C);
+  for (int c = 0; c < C; ++c) {
+    const Component &cc = comps[c];
+    full[c] = cc.h == hmax && cc.v == vmax;
+    if (full[c]) continue;
+    xt[c] = taps(W, (W * cc.h + hmax - 1) / hmax, cc.h, hmax);
+    yt[c] = taps(H, (H * cc.v + vmax - 1) / vmax, cc.v, vmax);
+  }
+  std::vector<float> row(static_cast<size_t>(W) * 3);
+  for (int y = 0; y < H; ++y) {
+    for (int c = 0; c < C; ++c) {
+      const Component &cc = comps[c];
+      const size_t stride = static_cast<size_t>(cc.bw) * 8;
+      float *r = row.data() + static_cast<size_t>(c) * W;
+      if (full[c]) {
+        const uint8_t *src = cc.plane.data() + y * stride;
+        for (int x = 0; x < W; ++x) r[x] = src[x];
+        continue;
       }
-      uint8_t *o = pixels->data() + (static_cast<size_t>(y) * W + x) * C;
-      if (C == 1) {
-        o[0] = Clamp8(v[0]);
-      } else {
-        const float cb = v[1] - 128.f, cr = v[2] - 128.f;
-        o[0] = Clamp8(v[0] + 1.402f * cr);
-        o[1] = Clamp8(v[0] - 0.344136f * cb - 0.714136f * cr);
-        o[2] = Clamp8(v[0] + 1.772f * cb);
+      const Tap &ty = yt[c][y];
+      const uint8_t *r0 = cc.plane.data() + ty.i0 * stride;
+      const uint8_t *r1 = cc.plane.data() + ty.i1 * stride;
+      const Tap *tx = xt[c].data();
+      for (int x = 0; x < W; ++x) {
+        const float a = r0[tx[x].i0] + tx[x].w * (r0[tx[x].i1] - r0[tx[x].i0]);
+        const float b = r1[tx[x].i0] + tx[x].w * (r1[tx[x].i1] - r1[tx[x].i0]);
+        r[x] = a + ty.w * (b - a);
       }
     }
+    uint8_t *o = pixels->data() + static_cast<size_t>(y) * W * C;
+    if (C == 1) {
+      for (int x = 0; x < W; ++x) o[x] = Clamp8(row[x]);
+    } else {
+      const float *Y = row.data(), *Cb = Y + W, *Cr = Cb + W;
+      for (int x = 0; x < W; ++x) {
+        const float cb = Cb[x] - 128.f, cr = Cr[x] - 128.f;
+        o[x * 3 + 0] = Clamp8(Y[x] + 1.402f * cr);
+        o[x * 3 + 1] = Clamp8(Y[x] - 0.344136f * cb - 0.714136f * cr);
+        o[x * 3 + 2] = Clamp8(Y[x] + 1.772f * cb);
+      }
+    }
+  }
   *width = W;
   *height = H;
   *channels = C;

@@ -4,6 +4,7 @@
 //                             with the host result of the same operation
 // Modelled on the reference's test/singa/test_*.cc suites (tensor math,
 // layers, optimizers, loss, metric, snapshot, feed-forward net, endpoint).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <functional>
@@ -889,8 +890,8 @@ static void TestJpeg() {
   EXPECT(!err.empty());
 }
 
-// `--jpeg-decode in.jpg out.ppm` / `--jpeg-encode in.ppm out.jpg [quality]`:
-// file converters used to check the codec against an independent
+// `--jpeg-decode in.jpg out.ppm` / `--jpeg-encode in.ppm out.jpg [quality]` /
+// `--jpeg-bench in.jpg repeats`: file converters and a decoder stopwatch used to check the codec against an independent
 // implementation from the Python tests.
 static int JpegTool(int argc, char **argv) {
   auto slurp = [](const char *path) {
@@ -916,6 +917,18 @@ static int JpegTool(int argc, char **argv) {
   dc.image_dim_order = "HWC";
   EncoderConf ec;
   ec.image_dim_order = "HWC";
+  if (mode == "--jpeg-bench") {  // --jpeg-bench in.jpg <repeats>
+    const std::string data = slurp(argv[2]);
+    const int reps = std::max(1, std::atoi(argv[3]));
+    std::vector<uint8_t> px;
+    int w = 0, h = 0, c = 0;
+    Timer t;
+    for (int i = 0; i < reps; ++i)
+      if (!jpeg::Decode(data, &px, &w, &h, &c)) return 1;
+    std::printf("%dx%dx%d, %zu bytes: %.3f ms per decode\n", w, h, c,
+                data.size(), t.Elapsed() / reps);
+    return 0;
+  }
   if (mode == "--jpeg-decode") {
     JPGDecoder dec;
     dec.Setup(dc);

@@ -17,6 +17,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <memory>
@@ -39,14 +40,6 @@ class ILSVRC {
     EncoderConf ec;
     ec.image_dim_order = "CHW";
     encoder_.Setup(ec);
-    DecoderConf dc;
-    dc.image_dim_order = "CHW";
-    decoder_.Setup(dc);
-    TransformerConf tc;
-    tc.crop_height = tc.crop_width = static_cast<int>(crop_size);
-    tc.image_dim_order = "CHW";
-    tc.horizontal_mirror = true;
-    transformer_.Setup(tc);
   }
 
   size_t image_size() const { return image_size_; }
@@ -281,25 +274,44 @@ class ILSVRC {
     mean_ = mean;
   }
 
-  // runs on the worker threads; touches only its own tensors
+  // Runs on the worker threads.  One pass from the decoder's HWC bytes to the
+  // CHW float crop: subtract the mean, cut the window (random position and
+  // random mirror when training, centred otherwise: the policy of
+  // ImageTransformer::Apply) and write straight into the batch.
   void DecodeTransform(int flag, const std::string &record, float *out,
                        int *label) {
-    std::vector<Tensor> rec = decoder_.Decode(record);
-    CHECK_EQ(rec.size(), 2u) << "record without a label";
-    std::vector<float> px = rec[0].ToVector<float>();
-    CHECK_EQ(px.size(), mean_.size());
-    for (size_t i = 0; i < px.size(); ++i) px[i] -= mean_[i];
-    rec[0].CopyDataFromHostPtr(px.data(), px.size());
-    Tensor crop = transformer_.Apply(flag, rec[0]);
-    crop.GetValue(out, crop.Size());
-    rec[1].GetValue(label, 1);
+    std::vector<uint8_t> px;
+    int w = 0, h = 0, c = 0;
+    std::string comment, err;
+    CHECK(jpeg::Decode(record, &px, &w, &h, &c, &comment, &err)) << err;
+    CHECK(size_t(w) == image_size_ && size_t(h) == image_size_ && c == 3)
+        << "record of another geometry";
+    CHECK_EQ(comment.rfind("label ", 0), 0u) << "record without a label";
+    *label = std::atoi(comment.c_str() + 6);
+    static thread_local std::mt19937 rng(std::random_device{}());
+    const size_t S = image_size_, K = crop_size_;
+    size_t oh = (S - K) / 2, ow = (S - K) / 2;
+    bool flip = false;
+    if (flag & kTrain) {
+      oh = std::uniform_int_distribution<size_t>(0, S - K)(rng);
+      ow = std::uniform_int_distribution<size_t>(0, S - K)(rng);
+      flip = rng() & 1;
+    }
+    for (size_t ch = 0; ch < 3; ++ch)
+      for (size_t y = 0; y < K; ++y) {
+        const uint8_t *src = px.data() + ((oh + y) * S + ow) * 3 + ch;
+        const float *m = mean_.data() + (ch * S + oh + y) * S + ow;
+        float *dst = out + (ch * K + y) * K;
+        if (flip)
+          for (size_t x = 0; x < K; ++x) dst[K - 1 - x] = src[x * 3] - m[x];
+        else
+          for (size_t x = 0; x < K; ++x) dst[x] = src[x * 3] - m[x];
+      }
   }
 
   size_t image_size_, crop_size_;
   std::vector<float> mean_;
   JPGEncoder encoder_;
-  JPGDecoder decoder_;
-  ImageTransformer transformer_;
   std::unique_ptr<io::BinFileReader> reader_;
   std::string open_file_;
 };

@@ -215,6 +215,75 @@ dw_bwd_weight_kernel(const T *__restrict__ dy, const T *__restrict__ x,
   }
 }
 
+// Stride-1 filter gradient through LDS: block (c, j) walks its images in
+// stages of `ipb` whole planes (small images) or one band of rows (large
+// images); a stage holds the zero-bordered x rows and the dy rows it needs, so
+// the R*S products of an output position are unconditional LDS reads.
+template <typename T, int R, int S>
+__global__ void __launch_bounds__(256)
+dw_bwd_weight_lds_kernel(const T *__restrict__ dy, const T *__restrict__ x,
+                         float *__restrict__ dw, DwArgs a, int ipb, int band,
+                         int nbands) {
+  extern __shared__ float lds[];
+  __shared__ float red[17];
+  const int c = blockIdx.x;
+  const int LW = a.Q + S - 1, LH = band + R - 1;
+  float *gl = lds + ipb * LH * LW;   // dy rows of the stage
+  float acc[R * S];
+#pragma unroll
+  for (int k = 0; k < R * S; ++k) acc[k] = 0.f;
+  // images of this block: blockIdx.y, blockIdx.y + gridDim.y, ...
+  const int mine = (a.N - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+  for (int first = 0; first < mine; first += ipb) {
+    const int ni = min(ipb, mine - first);
+    for (int b = 0; b < nbands; ++b) {
+      const int p0 = b * band;
+      const int rows = min(band, a.P - p0);
+      __syncthreads();
+      for (int i = threadIdx.x; i < ni * LH * LW; i += blockDim.x) {
+        const int j = i / (LH * LW);
+        const int rem = i - j * (LH * LW);
+        const int lr = rem / LW, lc = rem - lr * LW;
+        const int n = blockIdx.y + (first + j) * gridDim.y;
+        const int h = p0 + lr - a.ph, w = lc - a.pw;
+        float v = 0.f;
+        if (h >= 0 && h < a.H && w >= 0 && w < a.W)
+          v = to_f(x[(((int64_t)n * a.C + c) * a.H + h) * a.W + w]);
+        lds[i] = v;
+      }
+      for (int i = threadIdx.x; i < ni * rows * a.Q; i += blockDim.x) {
+        const int j = i / (rows * a.Q);
+        const int rem = i - j * (rows * a.Q);
+        const int n = blockIdx.y + (first + j) * gridDim.y;
+        gl[j * band * a.Q + rem] =
+            to_f(dy[(((int64_t)n * a.C + c) * a.P + p0) * a.Q + rem]);
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < ni * rows * a.Q; i += blockDim.x) {
+        const int j = i / (rows * a.Q);
+        const int rem = i - j * (rows * a.Q);
+        const int p = rem / a.Q, q = rem - p * a.Q;
+        const float g = gl[j * band * a.Q + rem];
+        const float *t = lds + j * LH * LW + p * LW + q;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int s2 = 0; s2 < S; ++s2) acc[r * S + s2] += g * t[r * LW + s2];
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < R * S; ++k) {
+    const float v = block_sum(acc[k], red);
+    if (threadIdx.x == 0) {
+      if (gridDim.y > 1)
+        atomicAdd(dw + c * R * S + k, v);
+      else
+        dw[c * R * S + k] = v;
+    }
+  }
+}
+
 template <typename T, int R, int S>
 static void launch_dw_bwd_weight(const ConvGeom &g, const void *dy,
                                  const void *x, float *dw, hipStream_t s) {
@@ -222,6 +291,29 @@ static void launch_dw_bwd_weight(const ConvGeom &g, const void *dy,
   int nsplit = 1;
   while (g.C * nsplit < 1024 && nsplit * 2 <= g.N) nsplit *= 2;
   if (nsplit > 1) zero_async(dw, sizeof(float) * g.C * R * S, s);
+  const int LW = g.Q + S - 1;
+  const int kLimit = 12 * 1024;  // floats of LDS per block
+  if (g.stride_h == 1 && g.stride_w == 1 && g.pad_h < R && g.pad_w < S &&
+      g.P == g.H + 2 * g.pad_h - R + 1 && g.Q == g.W + 2 * g.pad_w - S + 1 &&
+      (R + 7) * LW + 8 * g.Q <= kLimit) {
+    int band = g.P, nbands = 1, ipb = 1;
+    const int plane = (g.P + R - 1) * LW + g.P * g.Q;
+    if (plane > kLimit) {
+      band = (kLimit - (R - 1) * LW) / (LW + g.Q);
+      nbands = (g.P + band - 1) / band;
+      band = (g.P + nbands - 1) / nbands;
+    } else {
+      const int per_block = (g.N + nsplit - 1) / nsplit;
+      ipb = std::max(1, std::min({kLimit / plane, per_block,
+                                  4096 / std::max(1, g.P * g.Q) + 1}));
+    }
+    const size_t bytes =
+        sizeof(float) * (size_t)ipb * ((band + R - 1) * LW + band * g.Q);
+    hipLaunchKernelGGL((dw_bwd_weight_lds_kernel<T, R, S>), dim3(g.C, nsplit),
+                       dim3(256), bytes, s, (const T *)dy, (const T *)x, dw,
+                       dw_args(g), ipb, band, nbands);
+    return;
+  }
   hipLaunchKernelGGL((dw_bwd_weight_kernel<T, R, S>), dim3(g.C, nsplit),
                      dim3(256), 0, s, (const T *)dy, (const T *)x, dw,
                      dw_args(g));

@@ -716,6 +716,59 @@ static void TestIo() {
   EXPECT(r.ReadShape("a") == (Shape{2, 3}));
   EXPECT_NEAR(ToVec(r.Read("a"))[4], 5, 0);
   EXPECT(r.Read("b").ToVector<int>()[1] == 8);
+  // record files through the Reader / Writer interfaces
+  {
+    const std::string bin = "/tmp/singa_cpp_test_records.bin";
+    io::BinFileWriter bw;
+    io::Writer *w = &bw;
+    EXPECT(w->Open(bin, io::kCreate));
+    EXPECT(w->Write("k1", std::string("\0\1\2", 3)));
+    EXPECT(w->Write("", "no key"));
+    EXPECT(!w->Write("k3", ""));  // empty values are rejected
+    w->Close();
+    EXPECT(w->Open(bin, io::kAppend));
+    EXPECT(w->Write("k4", std::string(70000, 'x')));
+    w->Close();
+    io::BinFileReader br;
+    io::Reader *rd = &br;
+    EXPECT(rd->Open(bin));
+    EXPECT(rd->Count() == 3);
+    std::string k, v;
+    EXPECT(rd->Read(&k, &v) && k == "k1" && v == std::string("\0\1\2", 3));
+    EXPECT(rd->Read(&k, &v) && k.empty() && v == "no key");
+    EXPECT(rd->Read(&k, &v) && k == "k4" && v.size() == 70000);
+    EXPECT(!rd->Read(&k, &v));
+    rd->SeekToFirst();
+    EXPECT(rd->Read(&k, &v) && k == "k1");
+    rd->Close();
+    const std::string txt = "/tmp/singa_cpp_test_records.txt";
+    io::TextFileWriter tw;
+    EXPECT(tw.Open(txt, io::kCreate));
+    EXPECT(tw.Write("", "first") && tw.Write("", "second"));
+    tw.Close();
+    io::TextFileReader tr;
+    EXPECT(tr.Open(txt));
+    EXPECT(tr.Count() == 2);
+    EXPECT(tr.Read(&k, &v) && k == "0" && v == "first");
+    EXPECT(tr.Read(&k, &v) && k == "1" && v == "second");
+    EXPECT(!tr.Read(&k, &v));
+    tr.Close();
+  }
+  // channel to a file, stopwatch
+  {
+    SetChannelDirectory("/tmp");
+    Channel *ch = GetChannel("singa_cpp_test_channel");
+    ch->SetDestFilePath("/tmp/singa_cpp_test_channel.log");
+    std::remove("/tmp/singa_cpp_test_channel.log");
+    ch->Send("loss = 1.5");
+    ch->Send("loss = 1.25");
+    io::TextFileReader tr;
+    EXPECT(tr.Open("/tmp/singa_cpp_test_channel.log"));
+    EXPECT(tr.Count() == 2);
+    EXPECT(GetChannel("singa_cpp_test_channel") == ch);
+    Timer t;
+    EXPECT(t.Elapsed() >= 0.0 && t.Elapsed() < 1000.0);
+  }
   // csv
   CSVEncoder enc;
   CSVDecoder dec;

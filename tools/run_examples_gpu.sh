@@ -32,4 +32,12 @@ run onnx_selftest python examples/onnx/text_models.py self-test
 run largedata python examples/largedataset_cnn/train_largedata.py cnn --synthetic -m 1 -b 16
 run hfl python examples/hfl/run_local.py
 run cpp_cnn singa_amd/bin/singa_cnn -epoch 1
+run cpp_cnn_parallel singa_amd/bin/singa_cnn_parallel -epoch 1 -replicas 1
+run cpp_vgg_parallel singa_amd/bin/singa_vgg_parallel -epoch 3 -replicas 1 -dropout 0.5
+run cpp_alexnet singa_amd/bin/singa_alexnet -synthetic -data /tmp/singa_alexnet_gpu
+run autograd_mnist python examples/cnn/autograd/mnist_cnn.py -m 1 --max-batches 30
+run autograd_resnet_cifar python examples/cnn/autograd/resnet_cifar10.py -m 1 --max-batches 20
+run autograd_xception python examples/cnn/autograd/xceptionnet.py -n 10
+run autograd_resnet_dist python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29641 examples/cnn/autograd/resnet_dist.py -n 20
+run autograd_sparsification python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29642 examples/cnn/autograd/sparsification_mnist.py -m 1 --max-batches 20
 echo ALL-EXAMPLES-OK

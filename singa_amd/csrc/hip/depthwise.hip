@@ -324,7 +324,12 @@ static void launch_dw_bwd_weight(const ConvGeom &g, const void *dy,
 using namespace sa;
 
 bool sa_dwconv_applies(const ConvGeom *g) {
-  return g->groups > 1 && g->groups == g->C && g->K == g->C;
+  // the grid-stride loops index with 32-bit ints: leave one full stride of
+  // headroom below 2^31
+  const int64_t lim = ((int64_t)1 << 31) - ((int64_t)1 << 22);
+  return g->groups > 1 && g->groups == g->C && g->K == g->C &&
+         (int64_t)g->N * g->C * g->H * g->W < lim &&
+         (int64_t)g->N * g->C * g->P * g->Q < lim;
 }
 
 bool sa_dwconv_bwd_weight_applies(const ConvGeom *g) {

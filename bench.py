@@ -6,7 +6,7 @@ scaling), SGD(lr 0.1, momentum 0.9, weight_decay 1e-5), float32, graph mode;
 with more than one GPU the optimizer is wrapped in DistOpt (RCCL all-reduce,
 fused buckets, overlapped with backward), one process per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
@@ -26,12 +26,17 @@ BASELINE_IMG_S = {1: 45.0, 2: 88.0, 4: 173.0, 8: 332.0}
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    # 100 timed iterations, as reference examples/cnn/benchmark.py:37
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
     ap.add_argument("--dtype", default="fp32", choices=["fp32", "fp16", "bf16"])
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--no-graph", action="store_true")
+    # DistOpt's fusion threshold.  The reference default is 2097152 elements
+    # (python/singa/opt.py:843); ring all-reduce over point-to-point xGMI
+    # links is latency bound at that size, so the default here is 4x larger.
+    # The value used is reported in the JSON line (config.bucket).
     ap.add_argument("--bucket", type=int, default=8 * 1024 * 1024,
                     help="elements per all-reduce fusion bucket")
     ap.add_argument("--verbosity", type=int, default=0)
@@ -141,6 +146,11 @@ def main():
                 "optimizer": "SGD(lr=0.1, momentum=0.9, weight_decay=1e-5)",
                 "parallelism": "dp%d" % world,
                 "graph": not args.no_graph,
+                "bucket": args.bucket,
+                "bucket_reference_default": 2097152,
+                "hipgraph_segments": dev.hipgraph_segments(),
+                "collectives_in_graph": bool(
+                    sgd.communicator.capturable and not args.no_graph),
             },
         }), flush=True)
         if args.verbosity > 0:

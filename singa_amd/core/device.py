@@ -3,10 +3,11 @@
 A device owns a native graph scheduler (``_rt.Graph``), the streams its ops run
 on and the random-number state.  ``Exec`` either runs an op immediately or, in
 graph mode, records it together with the blocks it reads / writes.  On the GPU
-the recorded graph is replayed through hipGraphs: the replay plan is cut at the
-steps that cannot be captured (collectives, host syncs), every capturable range
-is captured once into a ``torch.cuda.CUDAGraph`` that shares one private memory
-pool with the others, and each later iteration is a handful of graph launches.
+the recorded graph is replayed through hipGraphs: the whole plan -- compute
+kernels and RCCL collectives on their side streams -- is captured once into a
+``torch.cuda.CUDAGraph`` and each later iteration is one graph launch.  Only
+when the collectives are not stream ordered (a host backend) is the plan cut
+at them into several graphs that share one private memory pool.
 
 Behaviour parity: reference include/singa/core/device.h:57-174 (Exec, RunGraph,
 ResetGraph, EnableGraph, Sync, SetRandSeed, SetVerbosity, SetSkipIteration,
@@ -200,6 +201,10 @@ class HipGPU(Device):
         self._eager_done = 0
         self._replay = None
         self._events = {}
+        # set by the communicator: its collectives are stream ordered (RCCL)
+        # and may be captured into the step's hipGraph
+        self.collectives_capturable = False
+        self._stamps = None   # device-side profile of the captured graph
 
     def _new_storage(self, n, tdtype):
         return torch.empty(n, dtype=tdtype, device=self.torch_device)
@@ -218,49 +223,109 @@ class HipGPU(Device):
     def stream_handle(self):
         return torch.cuda.current_stream(self.torch_device).cuda_stream
 
+    def side_streams(self):
+        return (self.stream_pack, self.stream_comm, self.stream_unpack)
+
+    def join_side_streams(self):
+        """Order the current stream after the three communication streams.
+        Inside a hipGraph capture only streams that were forked into the
+        capture are joined (a dependency on uncaptured work is not allowed
+        to enter a capture)."""
+        main = torch.cuda.current_stream(self.torch_device)
+        capturing = torch.cuda.is_current_stream_capturing()
+        for s in self.side_streams():
+            if capturing:
+                with torch.cuda.stream(s):
+                    if not torch.cuda.is_current_stream_capturing():
+                        continue
+            main.wait_stream(s)
+
     # -- graph replay through hipGraphs ---------------------------------------
     def ResetGraph(self):
         super().ResetGraph()
         self._replay = None
         self._eager_done = 0
+        self._stamps = None
+
+    def hipgraph_segments(self):
+        """Number of hipGraph launches one replayed iteration issues (0 while
+        the graph is not captured)."""
+        if self._replay is None:
+            return 0
+        return sum(1 for kind, _ in self._replay.steps if kind == "graph")
 
     def RunGraph(self, serial=False):
         g = self._graph
-        if (not self.use_hipgraph) or self._verbosity > 0:
+        if not self.use_hipgraph:
             return super().RunGraph(serial)
         prev = self._graph_enabled
         self._graph_enabled = False
         try:
             with torch.cuda.device(self.torch_device):
-                if self._replay is not None and self._replay.serial != serial:
+                if self._replay is not None and (
+                        self._replay.serial != serial or
+                        self._replay.verbosity != self._verbosity):
                     self._replay = None
                 if self._replay is None:
                     if self._eager_done < self.warmup_iters:
                         # first iteration runs op by op: lazy handles, lazy
                         # parameter moves and allocator warm-up happen here
                         self._eager_done += 1
-                        if serial:
-                            g.RunInSerial()
-                        else:
-                            g.RunGraph()
+                        g.set_verbosity(0)
+                        try:
+                            if serial:
+                                g.RunInSerial()
+                            else:
+                                g.RunGraph()
+                        finally:
+                            g.set_verbosity(self._verbosity)
                         return
                     self._replay = _HipGraphReplay(self, serial)
+                if self._stamps is not None:
+                    self._stamps.before_replay(g.iteration(),
+                                               self._skip_iteration)
                 self._replay.run()
                 g.FinishIteration()
         finally:
             self._graph_enabled = prev
 
-    # -- profiling with device events -------------------------------------------
+    def PrintTimeProfiling(self):
+        if self._stamps is not None:
+            self._stamps.flush(self._graph)
+        super().PrintTimeProfiling()
+
+    # -- profiling ---------------------------------------------------------------
     def _stream_for(self, name):
-        if name.startswith("Dist_s"):
-            return self.stream_comm
-        if name.startswith("Dist_c1"):
-            return self.stream_pack
-        if name.startswith("Dist_c2"):
-            return self.stream_unpack
-        return torch.cuda.current_stream(self.torch_device)
+        return self._streams_of(name)[0]
+
+    def _streams_of(self, name):
+        """(first, last) stream a node's work runs on, from its name: a
+        ``Dist_<tags>_...`` node names the side streams it crosses (c1 pack,
+        s collective, c2 unpack), everything else runs on the compute stream
+        (the convention of reference src/core/device/cuda_gpu.cc:134-165)."""
+        main = torch.cuda.current_stream(self.torch_device)
+        if not name.startswith("Dist_"):
+            return main, main
+        tags = name[5:].split("_", 1)[0]
+        table = (("c1", self.stream_pack), ("c2", self.stream_unpack),
+                 ("s", self.stream_comm))
+        found = []
+        while tags:
+            for tag, st in table:
+                if tags.startswith(tag):
+                    found.append(st)
+                    tags = tags[len(tag):]
+                    break
+            else:
+                found = []
+                break
+        if not found:
+            return main, main
+        return found[0], found[-1]
 
     def _timed_exec(self, node_id, name):
+        if self._stamps is not None and self.phase == "capture":
+            return self._stamps.around(node_id, name)
         stream = self._stream_for(name)
         ev = self._events.get(node_id)
         if ev is None:
@@ -269,7 +334,7 @@ class HipGPU(Device):
             self._events[node_id] = ev
         ev[0].record(stream)
         self._graph.run_node(node_id)
-        ev[1].record(stream)
+        ev[1].record(self._streams_of(name)[1])
         self._node_clock[node_id] = ev
 
     def _collect(self, node_id):
@@ -279,17 +344,110 @@ class HipGPU(Device):
         return ev[0].elapsed_time(ev[1]) / 1000.0
 
 
+class _GraphStamps(object):
+    """Per-node timing of a captured step.  Timing events cannot be part of a
+    hipGraph, so the capture contains one-thread kernels that read the
+    device's constant-rate clock on the stream the profiled node uses and add
+    the differences up on the device; the host reads the sums when the
+    profile is printed.  Verbosity 1 stamps the forward / backward boundary,
+    2 every node, 3 the communication (``Dist``) nodes; the whole step is
+    always stamped.  What is timed is the production replay itself."""
+
+    def __init__(self, dev, n_nodes, verbosity, names):
+        self.dev = dev
+        self.k = dev.kernels
+        self.verbosity = verbosity
+        self.n = n_nodes
+        td = dev.torch_device
+        self.slots = torch.zeros(n_nodes + 2, dtype=torch.int64, device=td)
+        self.acc = torch.zeros(n_nodes + 1, dtype=torch.float32, device=td)
+        self.gate = torch.zeros(1, dtype=torch.int32, device=td)
+        self.gate_open = False
+        self.sec_per_tick = 1.0 / float(self.k.wall_clock_hz())
+        self.first_node = None
+        self.fwd_closed = False
+        self.names = names
+
+    def _open(self, slot, stream):
+        self.k.stamp_open(self.slots.data_ptr(), slot, stream.cuda_stream)
+
+    def _close(self, slot, node, stream):
+        self.k.stamp_close(self.slots.data_ptr(), slot, self.acc.data_ptr(),
+                           node, self.gate.data_ptr(), self.sec_per_tick,
+                           stream.cuda_stream)
+
+    def begin(self):
+        main = torch.cuda.current_stream(self.dev.torch_device)
+        self._open(self.n, main)             # whole step
+        if self.verbosity == 1:
+            self._open(self.n + 1, main)     # forward part
+
+    def end(self):
+        main = torch.cuda.current_stream(self.dev.torch_device)
+        if self.verbosity == 1 and not self.fwd_closed and \
+                self.first_node is not None:
+            self._close(self.n + 1, self.first_node, main)  # forward only
+            self.fwd_closed = True
+        self._close(self.n, self.n, main)
+
+    def around(self, node_id, name):
+        dev = self.dev
+        g = dev.graph()
+        main = torch.cuda.current_stream(dev.torch_device)
+        if self.first_node is None:
+            self.first_node = node_id
+        if self.verbosity == 1:
+            if not self.fwd_closed and "Backward" in name:
+                self._close(self.n + 1, self.first_node, main)
+                self.fwd_closed = True
+            return g.run_node(node_id)
+        if self.verbosity == 3 and "Dist" not in name:
+            return g.run_node(node_id)
+        first, last = dev._streams_of(name)
+        if first is not main:
+            first.wait_stream(main)          # the node's work starts here
+        self._open(node_id, first)
+        g.run_node(node_id)
+        self._close(node_id, node_id, last)
+
+    def before_replay(self, iteration, skip):
+        if not self.gate_open and iteration >= skip:
+            self.gate.fill_(1)
+            self.gate_open = True
+
+    def flush(self, g):
+        """Move the sums measured so far into the scheduler's per-node
+        times."""
+        torch.cuda.synchronize(self.dev.torch_device)
+        vals = self.acc.cpu().tolist()
+        self.acc.zero_()
+        for i, v in enumerate(vals[:self.n]):
+            if v > 0:
+                g.AddNodeTime(i, v)
+        g.AddTimeElapsed(vals[self.n])
+
+
 class _HipGraphReplay(object):
-    """Captured form of one device graph: alternating hipGraph launches and
-    eagerly executed steps, in plan order."""
+    """Captured form of one device graph.  With stream-ordered collectives
+    (RCCL) the whole plan is ONE hipGraph: the communication nodes fork the
+    side streams from the capturing stream and ``Dist_wait`` joins them back,
+    so the collectives are graph nodes like the kernels around them.  With a
+    host-side collective backend the plan is cut at the communication nodes,
+    which then run eagerly between the captured segments."""
 
     def __init__(self, dev, serial):
         self.serial = serial
         self.dev = dev
+        self.verbosity = dev.verbosity()
         g = dev.graph()
         n = g.Prepare(serial)
         plan = g.plan()
         names = g.node_names()
+        eager_dist = not dev.collectives_capturable
+
+        def is_eager(nm):
+            return eager_dist and nm.startswith(_EAGER_PREFIXES)
+
         self.steps = []  # ("graph", CUDAGraph) | ("eager", node_id)
         ranges = []
         i = 0
@@ -298,25 +456,40 @@ class _HipGraphReplay(object):
             if nm == _SYNC_NAME:
                 i += 1  # host syncs are dropped from the steady state
                 ranges.append(("skip", i - 1, i))
-            elif nm.startswith(_EAGER_PREFIXES):
+            elif is_eager(nm):
                 ranges.append(("eager", i, i + 1))
                 i += 1
             else:
                 j = i
                 while (j < n and names[plan[j]] != _SYNC_NAME and
-                       not names[plan[j]].startswith(_EAGER_PREFIXES)):
+                       not is_eager(names[plan[j]])):
                     j += 1
                 ranges.append(("graph", i, j))
                 i = j
+        # a profile of the captured step needs the step in one piece
+        n_graph = sum(1 for r in ranges if r[0] == "graph")
+        stamps = None
+        if self.verbosity > 0 and n_graph == 1 and \
+                not any(r[0] == "eager" for r in ranges):
+            stamps = _GraphStamps(dev, len(names), self.verbosity, names)
+        dev._stamps = stamps
         pool = torch.cuda.graph_pool_handle()
         cap_stream = torch.cuda.Stream(device=dev.torch_device)
         dev.phase = "capture"
+        g.set_force_profile(stamps is not None)
         try:
             for kind, a, b in ranges:
                 if kind == "graph":
                     cg = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(cg, pool=pool, stream=cap_stream):
+                    with torch.cuda.graph(cg, pool=pool, stream=cap_stream,
+                                          capture_error_mode="thread_local"):
+                        if stamps is not None:
+                            stamps.begin()
                         g.RunRange(a, b)
+                        # every stream forked into the capture ends in it
+                        dev.join_side_streams()
+                        if stamps is not None:
+                            stamps.end()
                     self.steps.append(("graph", cg))
                 elif kind == "eager":
                     # binds its tensors (no execution) while phase == capture
@@ -325,6 +498,7 @@ class _HipGraphReplay(object):
                 else:
                     g.RunRange(a, b)  # only to release the blocks it frees
         finally:
+            g.set_force_profile(False)
             dev.phase = "eager"
 
     def run(self):

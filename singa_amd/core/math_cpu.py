@@ -349,6 +349,32 @@ class CpuMath(object):
         c = vals.numel() if cnt is None else min(int(cnt.item()), vals.numel())
         dense.index_add_(0, idx[:c].long(), -vals[:c])
 
+    def sparse_select(self, x, thr, topk, payload, cap, work):
+        n = x.numel()
+        if topk:
+            k = min(cap, max(1, int(math.ceil(thr * n))))
+            _, idx = torch.topk(x.abs(), k)
+            count = k
+        else:
+            idx = torch.nonzero(x.abs() >= thr).flatten()
+            count = idx.numel()
+            idx = idx[:cap]
+        m = idx.numel()
+        payload[0] = count
+        payload[1:1 + m] = idx.to(torch.int32)
+        payload[1 + cap:1 + cap + m] = x[idx].contiguous().view(torch.int32)
+
+    def sparse_workspace(self):
+        return None
+
+    def sparse_accumulate(self, payloads, nseg, cap, dense, sign=1.0):
+        stride = 1 + 2 * cap
+        for r in range(nseg):
+            p = payloads[r * stride:(r + 1) * stride]
+            c = min(int(p[0]), cap)
+            vals = p[1 + cap:1 + cap + c].contiguous().view(torch.float32)
+            dense.index_add_(0, p[1:1 + c].long(), vals * sign)
+
     # ---- layer norm / gelu ------------------------------------------------------
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, eps):
         xf = x.float()

@@ -11,6 +11,7 @@ the graph's private pool).
 Contract parity: reference src/core/tensor/tensor_math.h:86-485 and
 tensor_math_cuda.h (the CUDA specialisations this backend stands in for).
 """
+import math
 import os
 
 import torch
@@ -703,13 +704,40 @@ class HipMath(object):
 
     def pack(self, plan, views, bucket):
         ptrs, counts, _ = plan
+        assert all(v.dtype == views[0].dtype for v in views), \
+            "a fusion bucket holds tensors of one dtype"
         self.k.pack(_code(views[0]), _code(bucket), ptrs, counts,
                     bucket.data_ptr(), self._s())
 
     def unpack(self, plan, bucket, views, scale):
         ptrs, counts, _ = plan
+        assert all(v.dtype == views[0].dtype for v in views), \
+            "a fusion bucket holds tensors of one dtype"
         self.k.unpack(_code(bucket), _code(views[0]), ptrs, counts,
                       bucket.data_ptr(), float(scale), self._s())
+
+    def sparse_select(self, x, thr, topk, payload, cap, work):
+        """Fill ``payload`` (int32, 1 + 2 * cap words: count, indices, float
+        bits) with the entries of ``x`` that are exchanged: |x| >= thr, or the
+        ceil(thr * n) entries of largest magnitude.  Device only: the count is
+        never read by the host."""
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        assert payload.dtype == torch.int32 and payload.numel() >= 1 + 2 * cap
+        n = x.numel()
+        k = min(cap, max(1, int(math.ceil(thr * n)))) if topk else 0
+        self.k.sparse_select(x.data_ptr(), n, float(thr), 1 if topk else 0, k,
+                             payload.data_ptr(), int(cap), work.data_ptr(),
+                             self._s())
+
+    def sparse_workspace(self):
+        return self._tmp(self.k.topk_abs_workspace(), torch.int32)
+
+    def sparse_accumulate(self, payloads, nseg, cap, dense, sign=1.0):
+        """dense[idx] += sign * value over ``nseg`` payloads laid end to end."""
+        assert dense.dtype == torch.float32 and dense.is_contiguous()
+        self.k.scatter_add_segments(payloads.data_ptr(), int(nseg), int(cap),
+                                    float(sign), dense.data_ptr(),
+                                    dense.numel(), self._s())
 
     def sparsify_threshold(self, x, thr):
         """(values, indices, count) of the entries with |x| >= thr, compacted
@@ -741,11 +769,6 @@ class HipMath(object):
                                   cnt.data_ptr() if cnt is not None else 0,
                                   vals.numel(), dense.data_ptr(), dense.numel(),
                                   self._s())
-
-    def scatter_sub(self, vals, idx, cnt, dense):
-        neg = self._tmp(vals.numel())
-        self.binary_scalar("mul", vals, -1.0, neg)
-        self.scatter_add_sparse(neg, idx, cnt, dense)
 
     # ---- fused optimiser step -------------------------------------------------------------------------------------
     def sgd_update(self, p, g, buf, lr, momentum, dampening, weight_decay,

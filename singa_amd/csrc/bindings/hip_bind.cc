@@ -460,4 +460,31 @@ PYBIND11_MODULE(_hip, m) {
                                 (float *)P(dense), n, S(s)),
           "scatter_add_sparse");
   });
+  m.def("sparse_select", [](uintptr_t x, int64_t n, float thr, int topk,
+                            int64_t k, uintptr_t payload, int64_t cap,
+                            uintptr_t work, uintptr_t s) {
+    check(sa_sparse_select((const float *)CP(x), n, thr, topk, k,
+                           (int *)P(payload), cap, (unsigned *)P(work), S(s)),
+          "sparse_select");
+  });
+  m.def("scatter_add_segments", [](uintptr_t payloads, int nseg, int64_t cap,
+                                   float sign, uintptr_t dense, int64_t n,
+                                   uintptr_t s) {
+    check(sa_scatter_add_segments((const int *)CP(payloads), nseg, cap, sign,
+                                  (float *)P(dense), n, S(s)),
+          "scatter_add_segments");
+  });
+
+  // ---- device-side time stamps ---------------------------------------------------------------------------
+  m.def("stamp_open", [](uintptr_t slots, int i, uintptr_t s) {
+    check(sa_stamp_open((unsigned long long *)P(slots), i, S(s)), "stamp_open");
+  });
+  m.def("stamp_close", [](uintptr_t slots, int open, uintptr_t acc, int node,
+                          uintptr_t gate, float sec_per_tick, uintptr_t s) {
+    check(sa_stamp_close((const unsigned long long *)CP(slots), open,
+                         (float *)P(acc), node, (const int *)CP(gate),
+                         sec_per_tick, S(s)),
+          "stamp_close");
+  });
+  m.def("wall_clock_hz", &sa_wall_clock_hz);
 }

@@ -102,6 +102,9 @@ PYBIND11_MODULE(_rt, m) {
       .def("Prepare", &PyGraph::Prepare)
       .def("RunRange", &PyGraph::RunRange)
       .def("FinishIteration", &PyGraph::FinishIteration)
+      .def("set_force_profile", &PyGraph::set_force_profile)
+      .def("AddNodeTime", &PyGraph::AddNodeTime)
+      .def("AddTimeElapsed", &PyGraph::AddTimeElapsed)
       .def("Debug", &PyGraph::Debug)
       .def("TimeProfiling", &PyGraph::TimeProfiling)
       .def("set_verbosity", &PyGraph::set_verbosity)

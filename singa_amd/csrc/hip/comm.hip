@@ -152,6 +152,32 @@ __global__ void scatter_add_sparse_kernel(const float *__restrict__ vals,
   }
 }
 
+// Sum of `nseg` gathered sparse payloads into a dense vector.  Every payload
+// is `1 + 2 * cap` 32-bit words: the number of selected entries (it may exceed
+// cap when the selection overflowed its capacity; only the first cap were
+// stored), cap indices, cap float values.  One launch covers all segments.
+__global__ void scatter_add_segments_kernel(const int *__restrict__ payloads,
+                                            int nseg, int64_t cap, float sign,
+                                            float *__restrict__ dense,
+                                            int64_t n) {
+  const int64_t stride = 1 + 2 * cap;
+  const int64_t total = (int64_t)nseg * cap;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += step) {
+    const int64_t seg = i / cap, slot = i - seg * cap;
+    const int *p = payloads + seg * stride;
+    int64_t c = p[0];
+    if (c > cap) c = cap;
+    if (slot >= c) continue;
+    const int j = p[1 + slot];
+    const float v = __int_as_float(p[1 + cap + slot]);
+    if (j >= 0 && j < n) atomicAdd(dense + j, sign * v);
+  }
+}
+
+__global__ void set_word_kernel(int *p, int v) { p[0] = v; }
+
 // one launch per kPackMax tensors; offsets are the running sum of the counts
 template <typename TS, typename TD, bool PACK>
 int launch_packing(int nt, void *const *ptrs, const int64_t *counts,
@@ -242,6 +268,33 @@ int sa_topk_abs(const float *x, int64_t n, int64_t k, float *vals, int *idx,
   }
   hipLaunchKernelGGL(topk_select_kernel, grid, block, 0, s, x, n, (unsigned)k,
                      vals, idx, work);
+  return 0;
+}
+
+int sa_sparse_select(const float *x, int64_t n, float thr, int topk, int64_t k,
+                     int *payload, int64_t cap, unsigned *work,
+                     hipStream_t s) {
+  if (cap <= 0 || n <= 0) return -2;
+  int *idx = payload + 1;
+  float *vals = reinterpret_cast<float *>(payload + 1 + cap);
+  if (topk) {
+    if (k > cap) return -2;
+    const int rc = sa_topk_abs(x, n, k, vals, idx, work, s);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, s, payload,
+                       (int)k);
+    return 0;
+  }
+  return sa_sparsify_threshold(x, thr, vals, idx, payload, n, cap, s);
+}
+
+int sa_scatter_add_segments(const int *payloads, int nseg, int64_t cap,
+                            float sign, float *dense, int64_t n,
+                            hipStream_t s) {
+  if (nseg <= 0 || cap <= 0) return 0;
+  hipLaunchKernelGGL(scatter_add_segments_kernel,
+                     dim3(grid_for((int64_t)nseg * cap, 256)), dim3(256), 0, s,
+                     payloads, nseg, cap, sign, dense, n);
   return 0;
 }
 

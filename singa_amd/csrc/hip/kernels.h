@@ -299,3 +299,22 @@ int sa_sparsify_threshold(const float *x, float thr, float *vals, int *idx,
 int sa_scatter_add_sparse(const float *vals, const int *idx, const int *count,
                           int64_t max_count, float *dense, int64_t n,
                           hipStream_t s);
+// Sparse exchange payload: int32 words [count | idx[cap] | float bits[cap]].
+// Selection by threshold (|x| >= thr, count may exceed cap: only cap entries
+// are stored) or the k largest magnitudes (count = k <= cap).
+int sa_sparse_select(const float *x, int64_t n, float thr, int topk, int64_t k,
+                     int *payload, int64_t cap, unsigned *work, hipStream_t s);
+// dense[idx] += sign * value over `nseg` consecutive payloads of capacity cap
+int sa_scatter_add_segments(const int *payloads, int nseg, int64_t cap,
+                            float sign, float *dense, int64_t n, hipStream_t s);
+
+// ---- profile.hip --------------------------------------------------------------
+// Device-side time stamps that can be captured into a hipGraph (timing events
+// cannot): slots[i] = constant-rate wall clock; the closing stamp adds the
+// seconds since slots[open] to acc[node] while gate[0] != 0.
+int sa_stamp_open(unsigned long long *slots, int i, hipStream_t s);
+int sa_stamp_close(const unsigned long long *slots, int open, float *acc,
+                   int node, const int *gate, float sec_per_tick,
+                   hipStream_t s);
+// ticks per second of the clock the stamps read
+double sa_wall_clock_hz();

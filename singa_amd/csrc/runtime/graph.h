@@ -130,6 +130,14 @@ class Graph {
   void RunRange(size_t first, size_t last);
   /// Mark one full iteration as done (advances the profiling counter).
   void FinishIteration() { ++iteration_; }
+  /// While set, every node goes through the timed_exec hook whatever the
+  /// iteration count (a device that captures the plan into a hipGraph puts
+  /// its time stamps into the capture this way).
+  void set_force_profile(bool on) { force_profile_ = on; }
+  /// Times measured by the device itself for replays this graph did not
+  /// execute node by node.
+  void AddNodeTime(int id, float sec) { nodes_.at(id)->elapsed_ += sec; }
+  void AddTimeElapsed(float sec) { time_elapsed_ += sec; }
 
   std::string Debug() const;
   std::string TimeProfiling() const;
@@ -163,7 +171,8 @@ class Graph {
   void AnalyzeEdges();
   void ExecNode(Node *n);
   bool profiling_now() const {
-    return verbosity_ > 0 && iteration_ >= skip_iteration_;
+    return force_profile_ ||
+           (verbosity_ > 0 && iteration_ >= skip_iteration_);
   }
   void RunPlan();
   BlkInfo *NewInfo(Block *blk, BlockType t);
@@ -190,6 +199,7 @@ class Graph {
   int skip_iteration_ = 5;
   int iteration_ = 0;
   float time_elapsed_ = 0.f;
+  bool force_profile_ = false;
 };
 
 }  // namespace singa_amd

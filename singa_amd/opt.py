@@ -547,25 +547,28 @@ class DistOpt(object):
     def _reduce_loop(self, loss, threshold, reduce_one, reduce_fused,
                      pre=None):
         """Shared gradient schedule: big gradients are reduced on their own,
-        small ones are packed until the bucket exceeds ``threshold`` elements."""
+        small ones are packed until the bucket exceeds ``threshold`` elements.
+        A bucket is a flat buffer of one element type, so gradients are
+        bucketed per dtype (16-bit weight gradients and the float32
+        batch-norm gradients of a mixed-precision model fill separate
+        buckets)."""
         plist = []
-        acc = 0
-        glist = []
+        pending = {}          # dtype -> [element count, gradients]
         for p, g in autograd.backward(loss):
             if pre is not None:
                 g = pre(p, g)
             if g.size() > threshold:
                 reduce_one(g.data)
             else:
-                glist.append(g.data)
+                slot = pending.setdefault(g.dtype, [0, []])
+                slot[1].append(g.data)
                 reduce_fused([g.data], send=False)
-                acc += g.size()
-                if acc > threshold:
-                    reduce_fused(glist)
-                    acc = 0
-                    glist = []
+                slot[0] += g.size()
+                if slot[0] > threshold:
+                    reduce_fused(slot[1])
+                    del pending[g.dtype]
             plist.append((p, g))
-        if glist:
+        for _, glist in pending.values():
             reduce_fused(glist)
         self.wait()
         self.update_many(plist)

@@ -14,15 +14,18 @@ over, but the data path is laid out for MI355X:
 * pack, collective and unpack run on three side streams chained by events, so
   a bucket's all-reduce overlaps with the rest of the backward pass on the
   compute stream;
-* sparsified exchange selects, compacts and scatter-adds on the device with a
-  single host read (the largest non-zero count) per exchange;
-* every step is recorded on the device graph as a ``Dist_*`` node.  Under
-  hipGraph replay these nodes run eagerly between the captured segments: while
-  the graph is being captured their bodies only bind their operands.
+* a sparsified exchange is ONE all-gather of fixed-size payloads
+  ``[count | indices | values]`` and ONE scatter-add kernel over all ranks'
+  payloads; the number of selected entries stays on the device, so the host
+  never waits for the GPU;
+* every step is recorded on the device graph as a ``Dist_*`` node.  With RCCL
+  the nodes are captured into the training step's hipGraph together with the
+  compute kernels (side streams forked from and joined back into the capture),
+  so a replayed step issues no Python and no launch per bucket.  With a host
+  backend (gloo rehearsals) they run eagerly between captured segments.
 
 Ring collectives over xGMI are bound by the per-link rate, not by a switch:
-large buckets (tens of MB) amortise the ring's latency better than the
-reference's 8 MB default, which is why ``bench.py`` raises DistOpt's threshold.
+fewer, larger buckets amortise the ring's latency better than many small ones.
 """
 import math
 import os
@@ -62,6 +65,9 @@ _DEBUG = os.environ.get("SINGA_DIST_DEBUG", "0") == "1"
 # bit 1 after the compute stream has been joined with the side streams, bit 2
 # skips the collective itself.  Results must not depend on any of them.
 _STRICT = int(os.environ.get("SINGA_DIST_STRICT", "0"))
+# SINGA_DIST_CAPTURE=0 keeps RCCL collectives out of the hipGraph (they then
+# run eagerly between captured segments, like with a host backend)
+_CAPTURE = os.environ.get("SINGA_DIST_CAPTURE", "1") != "0"
 
 
 def _env_int(names, default):
@@ -121,11 +127,19 @@ class Communicator(object):
         # without a process group a lone rank's all-reduce is the identity
         self._active = dist.is_initialized()
         self._host_backend = self._active and dist.get_backend() != "nccl"
+        # stream-ordered collectives can be part of a captured hipGraph
+        self.capturable = (self._active and not self._host_backend and
+                           _CAPTURE and not _DEBUG and not _STRICT)
+        # fraction of a bucket a threshold-sparsified payload can carry when
+        # the entries held back are kept in an accumulation tensor (entries
+        # beyond the capacity stay in the accumulator and go out later);
+        # without accumulation the capacity is the whole bucket
+        self.spars_cap = float(os.environ.get("SINGA_SPARS_CAP", "1.0"))
         self._dev = None          # device of the last synchronised tensors
         self._blocks = []         # their blocks: what wait() orders against
-        self._buffers = {}        # (slot, dtype) -> flat bucket
+        self._buffers = {}        # (slot, kind, dtype) -> persistent buffer
         self._slot = 0            # bucket index within the iteration
-        self._works = []          # outstanding gloo / RCCL work handles
+        self._warmed = False
 
     # ------------------------------------------------------------------ helpers
     def __del__(self):
@@ -135,8 +149,11 @@ class Communicator(object):
         except Exception:
             pass
 
-    def _bucket(self, dev, slot, n, tdtype):
-        key = (slot, tdtype)
+    def _buffer(self, dev, slot, kind, n, tdtype):
+        """Persistent scratch of this iteration slot: allocated on first use
+        (the eager iteration that precedes graph capture) and reused by every
+        later iteration, so steady-state steps allocate nothing."""
+        key = (slot, kind, tdtype)
         buf = self._buffers.get(key)
         if buf is None or buf.numel() < n or buf.device != dev.torch_device:
             buf = torch.empty(max(int(n), 1), dtype=tdtype,
@@ -151,11 +168,28 @@ class Communicator(object):
 
     def _remember(self, dev, tensors):
         self._dev = dev
+        if dev.lang() != 0:
+            dev.collectives_capturable = self.capturable
         seen = set(id(b) for b in self._blocks)
         for t in tensors:
             if id(t.block()) not in seen:
                 self._blocks.append(t.block())
                 seen.add(id(t.block()))
+
+    def _staged(self, t):
+        """Device tensors with a host backend (gloo; used to rehearse the
+        multi-rank path on machines where RCCL cannot run, e.g. several ranks
+        on one GPU) go through host memory explicitly: the device is drained,
+        the collective runs on a host copy, the result is copied back on the
+        current stream.  (gloo's own device-tensor path waits for the device
+        from its worker thread, which was seen to stall with two ranks on one
+        GPU.)  RCCL collectives are stream ordered and take the tensor as is."""
+        return t.is_cuda and self._host_backend
+
+    @staticmethod
+    def _to_host(t):
+        torch.cuda.synchronize(t.device)
+        return t.cpu()
 
     def _all_reduce(self, flat):
         if not self._active:
@@ -178,40 +212,23 @@ class Communicator(object):
                 self.global_rank, self._seq, flat.numel(), before,
                 float(flat.float().abs().sum())), flush=True)
 
-    def _staged(self, t):
-        """Device tensors with a host backend (gloo; used to rehearse the
-        multi-rank path on machines where RCCL cannot run, e.g. several ranks
-        on one GPU) go through host memory explicitly: the device is drained,
-        the collective runs on a host copy, the result is copied back on the
-        current stream.  (gloo's own device-tensor path waits for the device
-        from its worker thread, which was seen to stall with two ranks on one
-        GPU.)  RCCL collectives are stream ordered and take the tensor as is."""
-        return t.is_cuda and self._host_backend
-
-    @staticmethod
-    def _to_host(t):
-        torch.cuda.synchronize(t.device)
-        return t.cpu()
-
-    def _all_gather(self, out_list, flat):
+    def _all_gather_into(self, out, flat):
+        """out (world_size * n elements) = every rank's ``flat`` (n elements),
+        in rank order: one collective."""
         if not self._active:
-            out_list[0].copy_(flat)
+            out[:flat.numel()].copy_(flat)
         elif self._staged(flat):
             host = self._to_host(flat)
-            outs = [torch.empty_like(host) for _ in out_list]
-            dist.all_gather(outs, host)
-            for o, h in zip(out_list, outs):
-                o.copy_(h)
+            gathered = torch.empty(out.numel(), dtype=host.dtype)
+            dist.all_gather_into_tensor(gathered, host)
+            out.copy_(gathered)
+        elif flat.is_cuda:
+            dist.all_gather_into_tensor(out, flat)
         else:
-            dist.all_gather(out_list, flat)
-
-    @staticmethod
-    def _share(*tensors):
-        """Tell the caching allocator that temporaries made on another side
-        stream are also in use on the current one."""
-        for t in tensors:
-            if t is not None and t.is_cuda:
-                t.record_stream(torch.cuda.current_stream(t.device))
+            # gloo has no flat all-gather on every torch version
+            n = flat.numel()
+            dist.all_gather([out[r * n:(r + 1) * n]
+                             for r in range(self.world_size)], flat)
 
     @staticmethod
     def _streams(dev):
@@ -220,14 +237,19 @@ class Communicator(object):
             return None
         return dev.stream_pack, dev.stream_comm, dev.stream_unpack
 
+    def _skip_body(self, dev):
+        """While the step is captured into hipGraph segments around eagerly
+        executed collectives, a collective's body only binds its operands."""
+        return dev.phase == "capture" and not self.capturable
+
     @staticmethod
     def _operand_views(dev, state, ts):
-        """Flat views of a collective's operands.  A recorded step is replayed
-        as captured hipGraphs around the collectives, which run eagerly: the
-        memory the captured kernels write is the storage the operands had
-        while the graph was being captured, so those views are kept and used
-        at every replay (by then the scheduler has released the blocks, and
-        asking them again would hand out fresh, unrelated storage)."""
+        """Flat views of a collective's operands.  When collectives run
+        eagerly between captured hipGraph segments, the memory the captured
+        kernels write is the storage the operands had while the graph was
+        being captured: those views are kept and used at every replay (by then
+        the scheduler has released the blocks, and asking them again would
+        hand out fresh, unrelated storage)."""
         if dev.phase == "replay" and "views" in state:
             return state["views"]
         views = [x.flat()[:x.Size()] for x in ts]
@@ -238,7 +260,8 @@ class Communicator(object):
     def _run_pipeline(self, dev, stages):
         """Run ``stages`` = [(which_stream, fn), ...] one after another, each
         on its side stream, the first ordered after the compute stream.  The
-        last stream's completion is what ``wait`` joins."""
+        last stream's completion is what ``wait`` joins.  Inside a hipGraph
+        capture the event waits fork the side streams into the capture."""
         st = self._streams(dev)
         if st is None:
             for _, fn in stages:
@@ -258,6 +281,7 @@ class Communicator(object):
             with torch.cuda.stream(s):
                 fn()
             prev = s
+        dev.side_streams_used = True
 
     # ----------------------------------------------------------------- all-reduce
     def synch(self, t):
@@ -271,7 +295,7 @@ class Communicator(object):
 
         def body(x):
             flat = self._operand_views(dev, state, [x])[0]
-            if dev.phase == "capture":
+            if self._skip_body(dev):
                 return
             self._run_pipeline(dev, [("comm", lambda: self._all_reduce(flat))])
 
@@ -296,7 +320,7 @@ class Communicator(object):
         communicator.cc:330-414."""
         tensors = list(tensors)
         assert len(tensors) > 0
-        assert tensors[0].data_type() == dtypes.kFloat32, (
+        assert all(t.data_type() == dtypes.kFloat32 for t in tensors), (
             "This function is only available for input tensor precision 32 "
             "bit, which are converted into 16 bits before transmit")
         self._fused(tensors, send, torch.float16, "fusedSynchHalf")
@@ -307,6 +331,16 @@ class Communicator(object):
         self._remember(dev, tensors)
         if not send or not self._active:
             return
+        # a flat bucket has one element type: tensors of different types
+        # (16-bit weights next to float32 batch-norm parameters) travel in
+        # one bucket per type
+        by_type = {}
+        for t in tensors:
+            by_type.setdefault(t.data_type(), []).append(t)
+        for group in by_type.values():
+            self._fused_one_type(dev, group, wire, tag)
+
+    def _fused_one_type(self, dev, tensors, wire, tag):
         slot = self._next_slot()
         total = sum(t.Size() for t in tensors)
         state = {}
@@ -321,9 +355,9 @@ class Communicator(object):
                 # pack table is built once
                 state["key"] = key
                 state["plan"] = dev.math.pack_plan(views)
-            if dev.phase == "capture":
+            if self._skip_body(dev):
                 return
-            bucket = self._bucket(dev, slot, total, wdt)
+            bucket = self._buffer(dev, slot, "bucket", total, wdt)
             plan = state["plan"]
             self._run_pipeline(dev, [
                 ("pack", lambda: dev.math.pack(plan, views, bucket)),
@@ -355,16 +389,25 @@ class Communicator(object):
             return None, float(args[0]), bool(args[1])
         raise TypeError("expected ([accumulation,] sparsThreshold, topK)")
 
+    def _payload_capacity(self, total, thr, topk, with_acc):
+        if topk:
+            return min(total, max(1, int(math.ceil(thr * total))))
+        if with_acc and self.spars_cap < 1.0:
+            return min(total, max(1, int(math.ceil(self.spars_cap * total))))
+        return total
+
     def _sparse(self, tensors, acc, thr, topk, tag):
         assert len(tensors) > 0
         dev = tensors[0].device()
-        assert tensors[0].data_type() == dtypes.kFloat32, \
+        assert all(t.data_type() == dtypes.kFloat32 for t in tensors), \
             "sparsified exchange supports only fp32"
         self._remember(dev, tensors + ([acc] if acc is not None else []))
         slot = self._next_slot()
         total = sum(t.Size() for t in tensors)
+        cap = self._payload_capacity(total, thr, topk, acc is not None)
+        words = 1 + 2 * cap
         state = {}
-        W = self.world_size
+        W = self.world_size if self._active else 1
 
         def body(*ts):
             if acc is not None:
@@ -378,60 +421,34 @@ class Communicator(object):
             if state.get("key") != key:
                 state["key"] = key
                 state["plan"] = dev.math.pack_plan(views)
-            if dev.phase == "capture":
+            if self._skip_body(dev):
                 return
             m = dev.math
             plan = state["plan"]
-            send = self._bucket(dev, slot, total, torch.float32)
+            send = self._buffer(dev, slot, "dense", total, torch.float32)
+            payload = self._buffer(dev, slot, "payload", words, torch.int32)
+            gathered = self._buffer(dev, slot, "gathered", W * words,
+                                    torch.int32)
+            if "work" not in state:
+                state["work"] = m.sparse_workspace()
             av = bound[-1][:total] if a is not None else None
-            box = {}
 
             def select():
                 m.pack(plan, views, send)
                 if av is not None:
                     m.axpy(1.0, av, send)          # add what was held back
-                if topk:
-                    k = int(math.ceil(thr * total))
-                    vals, idx = m.topk_abs(send, k)
-                    cnt = None
-                else:
-                    vals, idx, cnt = m.sparsify_threshold(send, thr)
+                m.sparse_select(send, thr, topk, payload, cap, state["work"])
                 if av is not None:
                     # residual = everything that is not sent
                     m.copy(send, av)
-                    m.scatter_sub(vals, idx, cnt, av)
-                box["sel"] = (vals, idx, cnt)
+                    m.sparse_accumulate(payload, 1, cap, av, -1.0)
 
             def exchange():
-                vals, idx, cnt = box["sel"]
-                self._share(vals, idx, cnt)
-                if cnt is None:
-                    nmax = vals.numel()
-                    counts = None
-                else:
-                    # ranks select different numbers of entries: agree on the
-                    # largest, the one host read of the exchange
-                    allc = [torch.empty_like(cnt) for _ in range(W)]
-                    self._all_gather(allc, cnt)
-                    counts = torch.cat(allc)
-                    nmax = int(min(int(counts.max().item()), total))
-                    counts = [counts[i:i + 1] for i in range(W)]
-                nmax = max(nmax, 1)
-                gi = [torch.empty(nmax, dtype=torch.int32,
-                                  device=dev.torch_device) for _ in range(W)]
-                gv = [torch.empty(nmax, dtype=torch.float32,
-                                  device=dev.torch_device) for _ in range(W)]
-                self._all_gather(gi, idx[:nmax].contiguous())
-                self._all_gather(gv, vals[:nmax].contiguous())
-                box["gathered"] = (gi, gv, counts, nmax)
+                self._all_gather_into(gathered, payload)
 
             def combine():
-                gi, gv, counts, nmax = box["gathered"]
-                self._share(*(gi + gv + (counts or [])))
                 m.fill(send, 0.0)
-                for r in range(W):
-                    m.scatter_add_sparse(gv[r], gi[r],
-                                         counts[r] if counts else None, send)
+                m.sparse_accumulate(gathered, W, cap, send, 1.0)
                 m.unpack(plan, send, views, 1.0)
 
             self._run_pipeline(dev, [("pack", select), ("comm", exchange),
@@ -452,14 +469,12 @@ class Communicator(object):
         self._slot = 0
 
         def join():
-            if dev.phase == "capture":
+            if self._skip_body(dev):
                 return
             st = self._streams(dev)
             if st is None:
                 return
-            main = torch.cuda.current_stream(dev.torch_device)
-            for s in st:
-                main.wait_stream(s)
+            dev.join_side_streams()
             if _STRICT & 2:
                 torch.cuda.synchronize(dev.torch_device)
 

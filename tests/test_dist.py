@@ -89,6 +89,24 @@ def _collectives(rank, world, holder):
     comm.wait()
     out["topk_acc"] = (tensor.to_numpy(g1), tensor.to_numpy(g2),
                        tensor.to_numpy(acc))
+    # one bucket announced with tensors of two element types (16-bit weight
+    # gradients next to float32 batch-norm gradients)
+    h = tensor.from_numpy((np.arange(5) * (rank + 1)).astype(np.float16))
+    f = tensor.from_numpy(np.full(3, 0.25 * (rank + 1), np.float32))
+    h2 = tensor.from_numpy(np.full(2, rank + 1.0, np.float16))
+    comm.fusedSynch([h.data, f.data, h2.data], True)
+    comm.wait()
+    out["mixed"] = (tensor.to_numpy(h), tensor.to_numpy(f),
+                    tensor.to_numpy(h2))
+    # threshold selection that overflows a capped payload keeps the rest in
+    # the accumulator
+    comm.spars_cap = 0.5
+    g = tensor.from_numpy(base.copy())
+    acc = tensor.from_numpy(np.zeros(6, np.float32))
+    comm.sparsification(g.data, acc.data, 0.05, False)
+    comm.wait()
+    out["thr_capped"] = (tensor.to_numpy(g), tensor.to_numpy(acc))
+    comm.spars_cap = 1.0
     return out
 
 
@@ -117,6 +135,17 @@ def test_collectives_two_ranks():
                                    [0, -6, 0, 9, 0, 3])
         np.testing.assert_allclose(acc, mine * np.array([1, 0, 1, 0, 1, 0]),
                                    rtol=1e-6)
+        h, f, h2 = o["mixed"]
+        assert h.dtype == np.float16 and f.dtype == np.float32
+        np.testing.assert_array_equal(h, np.arange(5) * 3.0)
+        np.testing.assert_array_equal(f, np.full(3, 0.75))
+        np.testing.assert_array_equal(h2, np.full(2, 3.0))
+        # capacity 3 of 6: what was sent plus what stayed behind is the input
+        g, acc = o["thr_capped"]
+        assert np.count_nonzero(acc) == 3
+        np.testing.assert_allclose(
+            res[0]["thr_capped"][1] + res[1]["thr_capped"][1] + g, base * 3,
+            rtol=1e-6)
 
 
 # ------------------------------------------------------------ DistOpt training
@@ -236,6 +265,29 @@ def test_distopt_partial_update_runs_and_syncs():
     res = _spawn(_dist_train, args=("partialUpdate", False, None))
     for k in res[0]:
         assert np.all(np.isfinite(res[0][k]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("option,dtype,verbosity", [
+    ("plain", "fp32", 0), ("plain", "fp16", 0), ("half", "fp32", 0),
+    ("sparseTopK", "fp32", 0), ("sparseThreshold", "fp32", 0),
+    ("plain", "fp32", 3)])
+def test_rccl_collectives_are_captured(option, dtype, verbosity):
+    """Forced single-rank RCCL group: the DistOpt step (pack kernel, RCCL
+    collective on its side stream, unpack kernel, fused update) replays as
+    ONE hipGraph and follows the eager single-process loss trajectory; with
+    a verbosity the communication profile comes from that same replay."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(
+        [sys.executable, "-u",
+         os.path.join(root, "tools", "check_rccl_captured.py"), option, dtype,
+         str(verbosity)],
+        capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "RCCL-CAPTURED-OK" in out.stdout, (
+        out.stdout[-3000:] + out.stderr[-3000:])
+    if verbosity == 3:
+        assert "Dist_" in out.stdout, out.stdout[-3000:]
 
 
 @pytest.mark.gpu

@@ -21,6 +21,8 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 ARCH = "gfx950"
 EXT_SUFFIX = sysconfig.get_config_var("EXT_SUFFIX") or ".so"
+# extra hipcc flags for diagnostic builds, e.g. SA_HIPCC_FLAGS=-DSA_CONV_PROF
+EXTRA_HIPCC = os.environ.get("SA_HIPCC_FLAGS", "").split()
 
 
 def _py_includes():
@@ -95,7 +97,8 @@ def build_hip(force=False, verbose=True):
         if force or _newer(o, [s] + hdrs):
             jobs.append([hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17",
                          "-fPIC", "-ffast-math", "-fno-gpu-rdc",
-                         "-Wno-unused-result", "-c", s, "-o", o])
+                         "-Wno-unused-result"] + EXTRA_HIPCC +
+                        ["-c", s, "-o", o])
     bind = os.path.join(CSRC, "bindings", "hip_bind.cc")
     bo = os.path.join(OBJ, "hip_bind.o")
     objs.append(bo)

@@ -64,6 +64,7 @@ def _is_linear(shp, st):
 
 
 _CONV_AUTOTUNE = os.environ.get("SINGA_CONV_AUTOTUNE", "1") != "0"
+_CONV1X1_GEMM = os.environ.get("SINGA_CONV1X1_GEMM", "1") != "0"
 
 class HipMath(object):
     name = "hip"
@@ -71,6 +72,7 @@ class HipMath(object):
     def __init__(self, dev):
         self.dev = dev
         self.k = dev.kernels
+        self.conv_prof = None
 
     # ---- plumbing -----------------------------------------------------------
     def _s(self):
@@ -450,8 +452,11 @@ class HipMath(object):
     def _geom(self, xshape, wshape, yshape, stride, pad, groups):
         N, C, H, W = xshape
         K, _, R, S = wshape
-        return self.k.ConvGeom(N, C, H, W, K, R, S, yshape[2], yshape[3],
-                               stride[0], stride[1], pad[0], pad[1], groups)
+        g = self.k.ConvGeom(N, C, H, W, K, R, S, yshape[2], yshape[3],
+                            stride[0], stride[1], pad[0], pad[1], groups)
+        if self.conv_prof is not None:   # diagnostic builds: phase counters
+            g.set_prof(self.conv_prof.data_ptr())
+        return g
 
     # Launch-plan autotuning (the role of cuDNN's algorithm search in the
     # reference, convolution.cc:514-640): the first time a (pass, geometry,
@@ -504,9 +509,23 @@ class HipMath(object):
         g.set_scratch(buf.data_ptr(), buf.numel())
         return buf
 
+    @staticmethod
+    def _pointwise16(x, w, stride, pad, groups):
+        """16-bit 1x1 / stride 1 / unpadded convolution: a plain GEMM per
+        image, served by the tiled 16-bit GEMM kernel."""
+        return (_CONV1X1_GEMM and x.dtype in (torch.float16, torch.bfloat16)
+                and w.shape[2] == 1 and w.shape[3] == 1 and groups == 1 and
+                tuple(stride) == (1, 1) and tuple(pad) == (0, 0))
+
     def conv_fwd(self, x, w, b, y, stride, pad, groups):
-        g = self._geom(x.shape, w.shape, y.shape, stride, pad, groups)
         w = self._contig(w)
+        if b is None and self._pointwise16(x, w, stride, pad, groups):
+            N, C, H, W = x.shape
+            if self.k.conv1x1_h16(_code(x), 0, N, C, w.shape[0], H * W,
+                                  x.data_ptr(), w.data_ptr(), 0, y.data_ptr(),
+                                  self._s()):
+                return
+        g = self._geom(x.shape, w.shape, y.shape, stride, pad, groups)
         scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)
             g, y, w.shape[0] // groups, y.shape[0] * y.shape[2] * y.shape[3],
             groups)
@@ -523,8 +542,19 @@ class HipMath(object):
         """dx = backward-data(dy, w) [+ addend]: the sum with a gradient that
         reached the same input along another path happens in the kernel's
         epilogue instead of in a separate pass over dx."""
-        g = self._geom(dx.shape, w.shape, dy.shape, stride, pad, groups)
         w = self._contig(w)
+        if self._pointwise16(dx, w, stride, pad, groups):
+            N, C, H, W = dx.shape
+            ad = None
+            if addend is not None:
+                assert addend.shape == dx.shape and addend.dtype == dx.dtype
+                ad = self._contig(addend)
+            if self.k.conv1x1_h16(_code(dx), 1, N, C, w.shape[0], H * W,
+                                  dy.data_ptr(), w.data_ptr(),
+                                  ad.data_ptr() if ad is not None else 0,
+                                  dx.data_ptr(), self._s()):
+                return
+        g = self._geom(dx.shape, w.shape, dy.shape, stride, pad, groups)
         scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)
             g, dx, dx.shape[1] // groups,
             dx.shape[0] * dx.shape[2] * dx.shape[3], groups)

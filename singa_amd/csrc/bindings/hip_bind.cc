@@ -238,10 +238,23 @@ PYBIND11_MODULE(_hip, m) {
       .def("set_scratch", [](ConvGeom &g, uintptr_t p, int64_t elems) {
         g.scratch = reinterpret_cast<float *>(p);
         g.scratch_elems = elems;
+      })
+      .def("set_prof", [](ConvGeom &g, uintptr_t p) {
+        g.prof = reinterpret_cast<unsigned long long *>(p);
       });
   m.def("conv_fwd", [](int dt, const ConvGeom &g, uintptr_t x, uintptr_t w,
                        uintptr_t bias, uintptr_t y, uintptr_t s) {
     check(sa_conv_fwd(dt, &g, CP(x), CP(w), CP(bias), P(y), S(s)), "conv_fwd");
+  });
+  // returns false when the geometry needs the implicit-GEMM kernel
+  m.def("conv1x1_h16", [](int dt, int mode, int64_t n_img, int64_t C,
+                          int64_t K, int64_t HW, uintptr_t act, uintptr_t w,
+                          uintptr_t addend, uintptr_t out, uintptr_t s) {
+    const int rc = sa_conv1x1_h16(dt, mode, n_img, C, K, HW, CP(act), CP(w),
+                                  CP(addend), P(out), S(s));
+    if (rc == -3) return false;
+    check(rc, "conv1x1_h16");
+    return true;
   });
   m.def("conv_bwd_data", [](int dt, const ConvGeom &g, uintptr_t dy,
                             uintptr_t w, uintptr_t dx, uintptr_t s) {

@@ -189,10 +189,37 @@ __device__ __forceinline__ typename Frag16<T>::V frag16(const float *p, int ld) 
   return __builtin_bit_cast(typename Frag16<T>::V, w);
 }
 
+// Diagnostic build (-DSA_CONV_PROF): wave 0 of every workgroup stamps the
+// shader clock around the phases of its life and adds the sums to the eight
+// 64-bit words of its own record at ConvGeom::prof {prologue, first tile,
+// plan + load issue, MFMA, wait + LDS store, barrier, epilogue, start time}.
+#ifdef SA_CONV_PROF
+__device__ __forceinline__ unsigned long long prof_stamp() {
+  __builtin_amdgcn_sched_barrier(0);
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define PROF_STAMP(v) const unsigned long long v = prof_stamp()
+#define PROF_ADD(acc, a, b) acc += (b) - (a)
+#else
+#define PROF_STAMP(v)
+#define PROF_ADD(acc, a, b)
+#endif
+
 // V1: both operands are plain matrices (1x1 filter, stride 1, no padding,
 // H*W and the channel count multiples of 4): tiles are staged with 4-wide
 // loads and no per-element index arithmetic.
-template <typename T, int MODE, int BM, int BN, int BK, bool V1>
+//
+// V4 (float, forward / backward-data, stride 1, row length a multiple of 4,
+// at most one padding column per side): a thread gathers four adjacent
+// pixels of one filter tap with a single 16-byte load -- in NCHW they are
+// adjacent in memory whatever the tap's horizontal shift, and a 4-byte
+// aligned address is all a dwordx4 buffer load needs.  A group that hangs
+// over the left / right image border is loaded one pixel further in and
+// shifted into place with the overhanging element zeroed.
+template <typename T, int MODE, int BM, int BN, int BK, bool V1, bool V4 = false>
 __global__ void __launch_bounds__(256)
 conv_igemm_kernel(ConvArgs a) {
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -209,6 +236,10 @@ conv_igemm_kernel(ConvArgs a) {
   const ConvGeom &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
+#ifdef SA_CONV_PROF
+  unsigned long long pf_plan = 0, pf_mma = 0, pf_store = 0, pf_bar = 0;
+#endif
+  PROF_STAMP(pf_t0);
 
   // ---- tile assignment -------------------------------------------------------
   // Consecutive workgroup ids are dealt round-robin to the 8 XCDs, each with a
@@ -274,7 +305,7 @@ conv_igemm_kernel(ConvArgs a) {
   // backward-weight: the thread owns B_PER (c, r, s) columns
   int bw_off[B_PER], bw_r[B_PER], bw_s[B_PER];
   if (MODE == CONV_FWD || MODE == CONV_BWD_DATA) {
-    const int j = V1 ? n0 + 4 * (tid % (BN / 4)) : n0 + tid % BN;
+    const int j = (V1 || V4) ? n0 + 4 * (tid % (BN / 4)) : n0 + tid % BN;
     bj_valid = j < Ngemm;
     uint32_t n, pix, y, x;
     if (V1) {
@@ -330,14 +361,14 @@ conv_igemm_kernel(ConvArgs a) {
   // stands for "beyond the reduction range").  The per-element bounds test
   // is then one 64-bit shift whose bit 0 is moved into the sign of the offset.
   uint64_t inv_mask = ~0ull;
-  if (MODE == CONV_FWD && !V1 && a.tap_mask) {
+  if (MODE == CONV_FWD && !V1 && !V4 && a.tap_mask) {
     for (int r = 0; r < g.R; ++r)
       for (int s2 = 0; s2 < g.S; ++s2)
         if ((unsigned)(b_y + r) < (unsigned)g.H &&
             (unsigned)(b_x + s2) < (unsigned)g.W)
           inv_mask &= ~(1ull << (r * g.S + s2));
   }
-  if (MODE == CONV_BWD_DATA && !V1 && a.tap_mask) {
+  if (MODE == CONV_BWD_DATA && !V1 && !V4 && a.tap_mask) {
     for (int r = 0; r < bc.Rc; ++r)
       for (int s2 = 0; s2 < bc.Sc; ++s2)
         if ((unsigned)(b_y - r) < (unsigned)g.P &&
@@ -347,6 +378,7 @@ conv_igemm_kernel(ConvArgs a) {
 
   float ra[A_PER], rb[B_PER];
   int ao[A_PER], bo[B_PER];
+  int bshift[B_PER / 4 > 0 ? B_PER / 4 : 1];  // V4: -1 / 0 / +1 per load
 
   auto store_a_rows_vec = [&](float *as) {
     constexpr int AKV = BK / 4, AROWS = 256 / AKV;
@@ -423,6 +455,52 @@ conv_igemm_kernel(ConvArgs a) {
       for (int i = 0; i < B_PER / 4; ++i) {
         const int kk = k0 + krow + BROWS * i;
         bo[i] = (bj_valid && kk < kend) ? (b_base + kk * a.HW) * SZ : kOob;
+      }
+    } else if (MODE != CONV_BWD_WEIGHT && V4) {
+      constexpr int BV = BN / 4, BROWS = 256 / BV;
+      const int krow = tid / BV;
+      // forward walks the input forwards from (b_y, b_x), backward-data
+      // walks the output gradient backwards
+      const int rows = MODE == CONV_FWD ? g.H : g.P;
+      const int cols = MODE == CONV_FWD ? g.W : g.Q;
+      const int plane = MODE == CONV_FWD ? a.HW : a.PQ;
+      // the A operand of backward-data is gathered as in the scalar path
+      if (MODE == CONV_BWD_DATA) {
+        const int kk = k0 + lane;
+        uint32_t k, rs, rr, ss;
+        bc.div_rcsc.divmod(kk, k, rs);
+        bc.div_sc.divmod(rs, rr, ss);
+        const int t_a = ((grp * a.Kg + (int)k) * a.Cg * a.RS +
+                         (bc.r0 + g.stride_h * (int)rr) * g.S + bc.s0 +
+                         g.stride_w * (int)ss) * SZ;
+        const int m = m0 + tid % BM;
+        const int moff = m * a.RS * SZ;
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+          const int src = ua + (256 / BM) * i;
+          ao[i] = (m < a.M && k0 + src < kend)
+                      ? moff + __builtin_amdgcn_readlane(t_a, src) : kOob;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < B_PER / 4; ++i) {
+        const int kk = k0 + krow + BROWS * i;
+        uint32_t c, rs, r, s;
+        if (MODE == CONV_FWD) {
+          a.div_rs.divmod(kk, c, rs);
+          a.div_s.divmod(rs, r, s);
+        } else {
+          bc.div_rcsc.divmod(kk, c, rs);
+          bc.div_sc.divmod(rs, r, s);
+        }
+        const int dy = MODE == CONV_FWD ? (int)r : -(int)r;
+        const int dx = MODE == CONV_FWD ? (int)s : -(int)s;
+        const int x0 = b_x + dx;
+        const int sh = x0 < 0 ? 1 : (x0 + 3 >= cols ? -1 : 0);
+        const bool ok = kk < kend && (unsigned)(b_y + dy) < (unsigned)rows;
+        bshift[i] = sh;
+        bo[i] = ok ? (b_base + (int)c * plane + dy * cols + dx + sh) * SZ
+                   : kOob;
       }
     } else if (MODE == CONV_FWD) {
       const int kk = k0 + lane;
@@ -519,7 +597,7 @@ conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < A_PER; ++i) ra[i] = BufLd<T>::one(rA, ao[i]);
     }
-    if (MODE != CONV_BWD_WEIGHT && V1) {
+    if (MODE != CONV_BWD_WEIGHT && (V1 || V4)) {
 #pragma unroll
       for (int i = 0; i < B_PER / 4; ++i) BufLd<T>::four(rB, bo[i], &rb[4 * i]);
     } else {
@@ -568,6 +646,23 @@ conv_igemm_kernel(ConvArgs a) {
         *reinterpret_cast<float4 *>(
             &bs[(tid / BV + BROWS * i) * LDB + 4 * (tid % BV)]) =
             make_float4(rb[4 * i], rb[4 * i + 1], rb[4 * i + 2], rb[4 * i + 3]);
+    } else if (V4) {
+      constexpr int BV = BN / 4, BROWS = 256 / BV;
+#pragma unroll
+      for (int i = 0; i < B_PER / 4; ++i) {
+        const float v0 = rb[4 * i], v1 = rb[4 * i + 1], v2 = rb[4 * i + 2],
+                    v3 = rb[4 * i + 3];
+        const int sh = bshift[i];
+        // sh = +1: the group was loaded one pixel to the right of where it
+        // belongs (its first pixel is padding); sh = -1: one to the left
+        const float o0 = sh > 0 ? 0.f : (sh < 0 ? v1 : v0);
+        const float o1 = sh > 0 ? v0 : (sh < 0 ? v2 : v1);
+        const float o2 = sh > 0 ? v1 : (sh < 0 ? v3 : v2);
+        const float o3 = sh > 0 ? v2 : (sh < 0 ? 0.f : v3);
+        *reinterpret_cast<float4 *>(
+            &bs[(tid / BV + BROWS * i) * LDB + 4 * (tid % BV)]) =
+            make_float4(o0, o1, o2, o3);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < B_PER; ++i)
@@ -586,15 +681,19 @@ conv_igemm_kernel(ConvArgs a) {
   // double-buffered LDS: tile t+1 is fetched into registers under the MFMAs
   // of tile t and written to the other buffer, one barrier per tile
   const int nt = (kend - kbeg + BK - 1) / BK;
+  PROF_STAMP(pf_t1);
   if (nt > 0) {
     load_tiles(kbeg);
     store_tiles(0);
   }
   __syncthreads();
+  PROF_STAMP(pf_t2);
   const int lrow = lane & 31, lk = lane >> 5;
   for (int t = 0; t < nt; ++t) {
     const float *as = As[t & 1], *bs = Bs[t & 1];
+    PROF_STAMP(pf_s0);
     if (t + 1 < nt) load_tiles(kbeg + (t + 1) * BK);
+    PROF_STAMP(pf_s1);
     if constexpr (std::is_same<T, float>::value) {
 #pragma unroll
       for (int ks = 0; ks < BK; ks += 2) {
@@ -633,9 +732,17 @@ conv_igemm_kernel(ConvArgs a) {
             acc[i][j] = Frag16<T>::mma(av[i], bv[j], acc[i][j]);
       }
     }
+    PROF_STAMP(pf_s2);
     if (t + 1 < nt) store_tiles((t + 1) & 1);
+    PROF_STAMP(pf_s3);
     __syncthreads();
+    PROF_STAMP(pf_s4);
+    PROF_ADD(pf_plan, pf_s0, pf_s1);
+    PROF_ADD(pf_mma, pf_s1, pf_s2);
+    PROF_ADD(pf_store, pf_s2, pf_s3);
+    PROF_ADD(pf_bar, pf_s3, pf_s4);
   }
+  PROF_STAMP(pf_t3);
 
   // ---- epilogue ---------------------------------------------------------------
   // lane holds GEMM column (lane & 31); register r holds GEMM row
@@ -697,6 +804,25 @@ conv_igemm_kernel(ConvArgs a) {
         }
       }
   }
+#ifdef SA_CONV_PROF
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PROF_STAMP(pf_t4);
+    if (tid == 0 && g.prof) {
+      // one private record per workgroup (slot 0 counts the workgroups)
+      const unsigned long long slot = atomicAdd(g.prof, 1ull);
+      unsigned long long *p = g.prof + 8 + 8 * slot;
+      p[0] = pf_t1 - pf_t0;
+      p[1] = pf_t2 - pf_t1;
+      p[2] = pf_plan;
+      p[3] = pf_mma;
+      p[4] = pf_store;
+      p[5] = pf_bar;
+      p[6] = pf_t4 - pf_t3;
+      p[7] = pf_t0;
+    }
+  }
+#endif
 }
 
 // split partial sums combined in float (+ addend) -> output dtype
@@ -769,6 +895,8 @@ static int env_int(const char *name, int dflt) {
 // forces a tile size.
 static const int kSplitTarget = env_int("SA_CONV_SPLIT_TARGET", 1024);
 static const int kForceTile = env_int("SA_CONV_TILE", 0);
+// SA_CONV_V4=0 keeps the one-pixel-per-load gather for every geometry
+static const int kUseV4 = env_int("SA_CONV_V4", 1);
 
 static inline bool use_big_tile(const ConvArgs &a) {
   const int force = a.g.tile ? a.g.tile : kForceTile;
@@ -797,7 +925,8 @@ static void plan_splits(ConvArgs &a, int64_t tiles, int min_k) {
   a.splits = (a.Kgemm + kps - 1) / kps;
 }
 
-template <typename T, int MODE, int BM, int BN, int BK, bool V1>
+template <typename T, int MODE, int BM, int BN, int BK, bool V1,
+          bool V4 = false>
 void launch_tile(ConvArgs &a, hipStream_t s) {
   a.mt = (a.M + BM - 1) / BM;
   a.nt = (a.Ngemm + BN - 1) / BN;
@@ -808,7 +937,7 @@ void launch_tile(ConvArgs &a, hipStream_t s) {
   else
     grid = dim3((unsigned)(((int64_t)a.mt * a.nt + 7) / 8 * 8), a.splits,
                 a.g.groups * a.ncls);
-  hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, BM, BN, BK, V1>), grid,
+  hipLaunchKernelGGL((conv_igemm_kernel<T, MODE, BM, BN, BK, V1, V4>), grid,
                      dim3(256), 0, s, a);
 }
 
@@ -847,9 +976,22 @@ void launch_conv(ConvArgs &a, int64_t out_elems, bool clear, hipStream_t s,
   if (MODE != CONV_BWD_WEIGHT)
     v1 = a.RS == 1 && g.stride_h == 1 && g.stride_w == 1 && g.pad_h == 0 &&
          g.pad_w == 0 && a.HW % 4 == 0 && a.Cg % 4 == 0 && a.Kg % 4 == 0;
+  bool v4 = false;
+  if constexpr (MODE != CONV_BWD_WEIGHT && std::is_same<T, float>::value) {
+    const int cols = MODE == CONV_FWD ? g.W : g.Q;       // gathered rows
+    const int out_cols = MODE == CONV_FWD ? g.Q : g.W;   // tile rows
+    v4 = !v1 && kUseV4 && g.stride_h == 1 && g.stride_w == 1 &&
+         out_cols % 4 == 0 && cols >= 4 && g.pad_w <= 1 && g.S <= 3 &&
+         g.S - 1 - g.pad_w <= 1 && a.ncls == 1;
+  }
   if (MODE != CONV_BWD_WEIGHT && v1) {
     if (big) launch_tile<T, MODE, 128, 128, 16, true>(a, s);
     else launch_tile<T, MODE, 64, 64, 32, true>(a, s);
+  } else if (v4) {
+    if constexpr (MODE != CONV_BWD_WEIGHT && std::is_same<T, float>::value) {
+      if (big) launch_tile<T, MODE, 128, 128, 16, false, true>(a, s);
+      else launch_tile<T, MODE, 64, 64, 32, false, true>(a, s);
+    }
   } else {
     if (big) launch_tile<T, MODE, 128, 128, 16, false>(a, s);
     else launch_tile<T, MODE, 64, 64, 32, false>(a, s);

@@ -42,6 +42,9 @@ struct GemmArgs {
   // 16-bit tiled kernel only: C is a float buffer receiving the plain
   // product (the partial products of a split reduction)
   int c_float = 0;
+  // 16-bit tiled kernel only: tensor of C's shape and layout added to the
+  // product (a residual gradient that reached the same tensor)
+  const void *addend = nullptr;
 };
 
 // ---------------------------------------------------------------------------
@@ -447,7 +450,10 @@ __device__ __forceinline__ int row_off(int r, int ch) {
 }
 template <int ROWS>
 __device__ __forceinline__ int kmaj_off(int r, int ch) {
-  return r * (ROWS * 2) + ((ch ^ (((r & 3) << 2) | ((r >> 2) & 3))) << 4);
+  // a k-row holds ROWS / 8 chunks: the swizzle stays inside the row
+  constexpr int kMask = ROWS / 8 - 1;
+  return r * (ROWS * 2) +
+         ((ch ^ ((((r & 3) << 2) | ((r >> 2) & 3)) & kMask)) << 4);
 }
 
 // One operand tile: ROWS x 64 elements staged by NT threads; element (i, k)
@@ -635,6 +641,9 @@ gemm_h16_fast_kernel(GemmArgs g, int ntm, int ntn) {
         float v = g.alpha * acc[i][j][r] + bv;
         T *cp = C + row * g.ldc + col;
         if (g.beta != 0.f) v += g.beta * to_f<T>(*cp);
+        if (g.addend)
+          v += to_f<T>(((const T *)g.addend)[(int64_t)blockIdx.z * g.c_bs +
+                                            row * g.ldc + col]);
         if (g.act == 1) v = fmaxf(v, 0.f);
         *cp = from_f<T>(v);
       }
@@ -678,6 +687,15 @@ static void launch_h16_fast(const GemmArgs &g, bool a_kc, bool b_kc,
   if (kGemmTile == 256) big = true;
   if (big) launch_h16_shape<T, 2, 4, 4, 2>(g, a_kc, b_kc, batch, s);
   else launch_h16_shape<T, 2, 2, 2, 2>(g, a_kc, b_kc, batch, s);
+}
+
+// 64-row tiles (1 x 4 waves of 2 x 1 blocks = 64 x 128) for products with at
+// most 64 rows, e.g. 1x1 convolutions with 64 output channels
+template <typename T>
+static void launch_h16_auto(const GemmArgs &g, bool a_kc, bool b_kc,
+                            int64_t batch, hipStream_t s) {
+  if (g.M <= 64) launch_h16_shape<T, 1, 4, 2, 1>(g, a_kc, b_kc, batch, s);
+  else launch_h16_fast<T>(g, a_kc, b_kc, batch, s);
 }
 
 template <int BM, int BN>
@@ -748,12 +766,13 @@ static bool h16_fast_ok(const GemmArgs &g) {
     return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
   };
   const bool a_kc = g.a_cs == 1, b_kc = g.b_rs == 1;
-  const bool a_ok = al16(g.A) && g.a_bs % 8 == 0 &&
-                    (a_kc ? g.a_rs % 8 == 0
-                          : (g.a_rs == 1 && g.a_cs % 8 == 0));
-  const bool b_ok = al16(g.B) && g.b_bs % 8 == 0 &&
-                    (b_kc ? g.b_cs % 8 == 0
-                          : (g.b_cs == 1 && g.b_rs % 8 == 0));
+  // a 16-byte buffer load needs a 4-byte aligned address: two elements
+  const bool a_ok = al16(g.A) && g.a_bs % 2 == 0 &&
+                    (a_kc ? g.a_rs % 2 == 0
+                          : (g.a_rs == 1 && g.a_cs % 2 == 0));
+  const bool b_ok = al16(g.B) && g.b_bs % 2 == 0 &&
+                    (b_kc ? g.b_cs % 2 == 0
+                          : (g.b_cs == 1 && g.b_rs % 2 == 0));
   const int64_t lim = ((int64_t)1 << 30) - 1024;  // elements
   const int64_t a_ext = (g.M - 1) * g.a_rs + (g.K - 1) * g.a_cs;
   const int64_t b_ext = (g.K - 1) * g.b_rs + (g.N - 1) * g.b_cs;
@@ -851,5 +870,48 @@ int sa_gemm_h16_partial(int dtype, int64_t M, int64_t N, int64_t K,
   const bool a_kc = a_cs == 1, b_kc = b_rs == 1;
   if (dtype == kF16) launch_h16_fast<__half>(g, a_kc, b_kc, batch, s);
   else launch_h16_fast<__hip_bfloat16>(g, a_kc, b_kc, batch, s);
+  return 0;
+}
+
+// 16-bit 1x1 convolution with stride 1 and no padding as one GEMM per image,
+// on the tiled 16-bit kernel (16-byte staging, 16-bit LDS images, transposing
+// LDS reads for the pixel-contiguous activations):
+//   mode 0  y[n]  (K x HW) = w (K x C) * x[n] (C x HW)
+//   mode 1  dx[n] (C x HW) = w^T (C x K) * dy[n] (K x HW)  [+ addend[n]]
+// Returns -3 when the geometry does not fit (caller uses the implicit-GEMM
+// convolution kernel).
+int sa_conv1x1_h16(int dtype, int mode, int64_t n_img, int64_t C, int64_t K,
+                   int64_t HW, const void *act, const void *w,
+                   const void *addend, void *out, hipStream_t s) {
+  if (dtype != kF16 && dtype != kBF16) return -1;
+  if (n_img <= 0) return 0;
+  GemmArgs g{};
+  g.alpha = 1.f;
+  g.beta = 0.f;
+  g.bias = nullptr;
+  g.act = 0;
+  g.c_float = 0;
+  g.addend = addend;
+  g.B = act;
+  g.b_cs = 1;
+  g.b_rs = HW;
+  g.C = out;
+  g.ldc = HW;
+  g.N = HW;
+  g.A = w;
+  g.a_bs = 0;
+  if (mode == 0) {
+    g.M = K; g.K = C;
+    g.a_rs = C; g.a_cs = 1;
+    g.b_bs = C * HW; g.c_bs = K * HW;
+  } else {
+    g.M = C; g.K = K;
+    g.a_rs = 1; g.a_cs = C;
+    g.b_bs = K * HW; g.c_bs = C * HW;
+  }
+  if (!h16_fast_ok(g)) return -3;
+  const bool a_kc = g.a_cs == 1;
+  if (dtype == kF16) launch_h16_auto<__half>(g, a_kc, false, n_img, s);
+  else launch_h16_auto<__hip_bfloat16>(g, a_kc, false, n_img, s);
   return 0;
 }

@@ -113,6 +113,13 @@ int sa_gemm_splitk_reduce(int dtype, const float *part, int splits, int64_t M,
                           int64_t ldc, const void *bias, int act,
                           hipStream_t s);
 
+// 16-bit 1x1 / stride 1 / no padding convolution as one tiled GEMM per image:
+// mode 0 forward (act = x, out = y), mode 1 backward-data (act = dy, out = dx,
+// optional addend of dx's shape); -3 = geometry not supported
+int sa_conv1x1_h16(int dtype, int mode, int64_t n_img, int64_t C, int64_t K,
+                   int64_t HW, const void *act, const void *w,
+                   const void *addend, void *out, hipStream_t s);
+
 // device-to-device copy / zero-fill as kernels (4-byte aligned pointers)
 int sa_copy_bytes(void *dst, const void *src, int64_t bytes, hipStream_t s);
 int sa_zero_bytes(void *dst, int64_t bytes, hipStream_t s);
@@ -146,6 +153,8 @@ struct ConvGeom {
   // combined in float there and rounded once into the output)
   float *scratch = nullptr;
   int64_t scratch_elems = 0;
+  // diagnostic builds only: eight 64-bit phase counters (see conv.hip)
+  unsigned long long *prof = nullptr;
 };
 int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                 const void *bias, void *y, hipStream_t s);

@@ -46,18 +46,67 @@ def resnet50_layers():
     return ls
 
 
+USE_GRAPH = True
+
+
 def timeit(fn, iters):
+    """ms per call.  The calls are captured into one hipGraph and replayed,
+    so the host's launch cost (tens of microseconds per call from Python)
+    does not hide kernels shorter than that."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
+    if not USE_GRAPH:
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(iters):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
-        fn()
+    for _ in range(3):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    return e0.elapsed_time(e1) / (3 * iters)
+
+
+PROF_NAMES = ("prologue", "tile0", "plan+issue", "mfma", "wait+store",
+              "barrier", "epilogue")
+
+
+def prof_shares(m, fn):
+    """One call with the diagnostic phase counters on (needs a build with
+    -DSA_CONV_PROF): share of wave 0's cycles per phase, mean cycles per
+    workgroup, and the span between the first workgroup's start and the
+    last one's, in cycles."""
+    m.conv_prof = torch.zeros(8 + 8 * 16384, dtype=torch.int64, device="cuda")
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    n = int(m.conv_prof[0].item())
+    rec = m.conv_prof[8:8 + 8 * n].reshape(n, 8).cpu().double()
+    m.conv_prof = None
+    c = rec[:, :7].sum(0).tolist()
+    tot = float(sum(c)) or 1.0
+    starts = rec[:, 7]
+    return " ".join("%s %.0f%%" % (nm, 100.0 * v / tot)
+                    for nm, v in zip(PROF_NAMES, c)) + \
+        " | cyc/wg %.0f wgs %d start-span %.0f call %.3f ms" % (
+            tot / max(n, 1), n, float(starts.max() - starts.min()),
+            e0.elapsed_time(e1))
+
 
 
 def main():
@@ -67,7 +116,15 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--gemm", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--prof", action="store_true",
+                    help="print phase shares (diagnostic build only)")
+    ap.add_argument("--layers", default="",
+                    help="comma separated layer indices (default: all)")
     args = ap.parse_args()
+    global USE_GRAPH
+    USE_GRAPH = not args.no_graph
+    only = set(int(v) for v in args.layers.split(",")) if args.layers else None
     sdev = sdevice.create_cuda_gpu()
     dev = sdev.torch_device
     dt = getattr(torch, args.dtype)
@@ -79,6 +136,8 @@ def main():
           ("layer C,K,R,s,p,H xcount", "fwd ms", "TF/s", "bwdD ms", "TF/s",
            "bwdW ms", "TF/s"))
     for li, (C, K, R, st, pd, H, cnt) in enumerate(resnet50_layers()):
+        if only is not None and li not in only:
+            continue
         P = (H + 2 * pd - R) // st + 1
         x = torch.randn(N, C, H, H, device=dev, dtype=dt)
         w = torch.randn(K, C, R, R, device=dev, dtype=dt) * 0.05
@@ -111,6 +170,14 @@ def main():
         print("%-34s %10.3f %8.1f | %10.3f %8.1f | %10.3f %8.1f%s" %
               ("%d,%d,%d,%d,%d,%d x%d" % (C, K, R, st, pd, H, cnt), t_f,
                tf(t_f), t_d, tf(t_d), t_w, tf(t_w), err), flush=True)
+        if args.prof:
+            print("   fwd :", prof_shares(m, lambda: m.conv_fwd(
+                x, w, None, y, (st, st), (pd, pd), 1)))
+            if li > 0:
+                print("   bwdD:", prof_shares(m, lambda: m.conv_bwd_data(
+                    dy, w, dx, (st, st), (pd, pd), 1)))
+            print("   bwdW:", prof_shares(m, lambda: m.conv_bwd_weight(
+                dy, x, dw, (st, st), (pd, pd), 1)))
         tot["fwd"] += t_f * cnt
         tot["bwd_data"] += t_d * cnt
         tot["bwd_weight"] += t_w * cnt

@@ -918,6 +918,16 @@ def pow(a, b):
 # comparisons and logic (no gradient)
 # ---------------------------------------------------------------------------
 class _NoGrad(Operator):
+    """Operators without a derivative: their outputs stop the gradient, so
+    chains that only transform data (an attention mask built from the input
+    mask, index arithmetic) are never visited by ``backward``."""
+
+    def _do_forward(self, *xs):
+        ys = super(_NoGrad, self)._do_forward(*xs)
+        self.requires_grad = False
+        for y in ys:
+            y.requires_grad = False
+        return ys
 
     def backward(self, *dys):
         assert False, ('no backward function for %s' %
@@ -1220,6 +1230,50 @@ class Gelu(Operator):
 
 def gelu(x):
     return Gelu()(x)[0]
+
+
+class Attention(Operator):
+    """softmax(scale * q @ kt + mask) @ v with the heads merged:
+
+        q (B, H, Sq, D), kt (B, H, D, Sk), v (B, H, Sk, D), mask broadcastable
+        to (B, H, Sq, Sk)  ->  (B, Sq, H * D)
+
+    One fused kernel per direction: scores and probabilities stay on chip,
+    the transposed views of (B, S, H, D) activations that exporters write in
+    front of the two MatMuls are read in place, and the output already has
+    the layout of the merge-heads Transpose + Reshape that follows them.  The
+    reference runs MatMul, Div, Add, Softmax, MatMul, Transpose, Reshape as
+    separate nodes (examples/onnx/bert/bert-squad.py:102-165)."""
+
+    def __init__(self, scale=1.0):
+        super(Attention, self).__init__()
+        self.scale = float(scale)
+
+    def forward(self, q, kt, v, mask=None):
+        assert q.nDim() == 4 and kt.nDim() == 4 and v.nDim() == 4, \
+            "attention operands are (batch, heads, rows, columns)"
+        out, lse = singa.AttentionForward(q, kt, v, mask, self.scale)
+        B, Sq, H, D = out.shape()
+        if training:
+            self.cache = (q, kt, v, mask, out, lse)
+        return singa.Reshape(out, [B, Sq, H * D])
+
+    def backward(self, dy):
+        q, kt, v, mask, out, lse = self.cache
+        dq, dkt, dv = singa.AttentionBackward(
+            singa.Reshape(dy, list(out.shape())), q, kt, v, mask, out, lse,
+            self.scale)
+        if mask is None:
+            return dq, dkt, dv
+        dmask = None
+        if self.x_needs_grad[3]:       # an additive mask is data, not a weight
+            dmask = _scalar_like(mask, 0.0)
+        return dq, dkt, dv, dmask
+
+
+def attention(q, kt, v, mask=None, scale=1.0):
+    args = [q, kt, v] + ([mask] if mask is not None else [])
+    return Attention(scale)(*args)[0]
 
 
 class BinaryCrossEntropy(Operator):

@@ -375,6 +375,59 @@ class CpuMath(object):
             vals = p[1 + cap:1 + cap + c].contiguous().view(torch.float32)
             dense.index_add_(0, p[1:1 + c].long(), vals * sign)
 
+    def adaptive_update_multi(self, rule, ps, gs, s1, s2, lr, wd, eps, a, b,
+                              step, scale):
+        f = lambda t: float(t.reshape(-1)[0]) if t is not None else 0.0
+        lr, wd, eps, a, b = f(lr), f(wd), f(eps), f(a), f(b)
+        t = f(step) + 1.0
+        for i, (p, g) in enumerate(zip(ps, gs)):
+            pv = p.float()
+            gv = g.float() * scale + wd * pv
+            u = s1[i].float()
+            if rule == 0:
+                u = a * u + (1.0 - a) * gv * gv
+                upd = gv / torch.sqrt(u + eps)
+            elif rule == 1:
+                u = u + gv * gv
+                upd = gv / torch.sqrt(u + eps)
+            else:
+                w = b * s2[i].float() + (1.0 - b) * gv * gv
+                u = a * u + (1.0 - a) * gv
+                s2[i].copy_(w)
+                upd = (u / (1.0 - a ** t)) / (torch.sqrt(w / (1.0 - b ** t)) +
+                                              eps)
+            s1[i].copy_(u)
+            p.copy_(pv - lr * upd)
+
+    # ---- fused attention (same contract as the HIP backend) ------------------------
+    @staticmethod
+    def _attn_probs(q, kt, mask, scale):
+        sc = torch.matmul(q.float(), kt.float()) * scale
+        if mask is not None:
+            sc = sc + mask.float()
+        return sc
+
+    def attention_fwd(self, q, kt, v, mask, scale, out, lse):
+        sc = self._attn_probs(q, kt, mask, scale)
+        lse.copy_(torch.logsumexp(sc, dim=-1))
+        p = torch.softmax(sc, dim=-1)
+        out.copy_(torch.matmul(p, v.float()).permute(0, 2, 1, 3))
+
+    def attention_bwd(self, dout, q, kt, v, mask, scale, out, lse, dq, dk,
+                      dv):
+        sc = self._attn_probs(q, kt, mask, scale)
+        p = torch.exp(sc - lse.unsqueeze(-1))
+        do = dout.float().permute(0, 2, 1, 3)            # (B, H, Sq, D)
+        o = out.float().permute(0, 2, 1, 3)
+        delta = (do * o).sum(-1, keepdim=True)
+        dv.copy_(torch.matmul(p.transpose(-1, -2), do).permute(0, 2, 1, 3))
+        dp = torch.matmul(do, v.float().transpose(-1, -2))
+        ds = p * (dp - delta) * scale
+        dq.copy_(torch.matmul(ds, kt.float().transpose(-1, -2))
+                 .permute(0, 2, 1, 3))
+        dk.copy_(torch.matmul(ds.transpose(-1, -2), q.float())
+                 .permute(0, 2, 1, 3))
+
     # ---- layer norm / gelu ------------------------------------------------------
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, eps):
         xf = x.float()

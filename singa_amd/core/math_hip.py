@@ -840,6 +840,27 @@ class HipMath(object):
             hyper[2].data_ptr(), hyper[3].data_ptr(), 1 if nesterov else 0,
             float(scale), self._s())
 
+    def adaptive_update_multi(self, rule, ps, gs, s1, s2, lr, wd, eps, a, b,
+                              step, scale):
+        """RMSProp (rule 0) / AdaGrad (1) / Adam (2) on a list of parameters
+        of one dtype in one launch per 48 tensors; states have the
+        parameters' dtype, hyper-parameters are one-element tensors."""
+        gg = []
+        for p, g in zip(ps, gs):
+            g = self._contig(g)
+            if g.dtype != p.dtype:
+                g = self._cast(g, p.dtype)
+            gg.append(g)
+        hyper = [self._f32(t) if t is not None else None
+                 for t in (lr, wd, eps, a, b, step)]
+        ptr = [t.data_ptr() if t is not None else 0 for t in hyper]
+        self.k.adaptive_update_multi(
+            _code(ps[0]), int(rule), [p.data_ptr() for p in ps],
+            [g.data_ptr() for g in gg], [t.data_ptr() for t in s1],
+            [t.data_ptr() for t in s2] if s2 else [],
+            [p.numel() for p in ps], ptr[0], ptr[1], ptr[2], ptr[3], ptr[4],
+            ptr[5], float(scale), self._s())
+
     # ---- layer norm / gelu ------------------------------------------------------
     def layernorm_fwd(self, x, gamma, beta, y, mean, rstd, eps):
         """Rows = all leading dimensions, normalised over the last one."""
@@ -883,6 +904,55 @@ class HipMath(object):
         dy, x = self._contig(dy), self._contig(x)
         self.k.gelu_bwd(_code(x), dy.data_ptr(), x.data_ptr(), dx.data_ptr(),
                         x.numel(), self._s())
+
+    # ---- fused attention ----------------------------------------------------------------
+    def _attn_desc(self, q, kt, v, mask, scale):
+        """q (B, H, Sq, D), kt (B, H, D, Sk), v (B, H, Sk, D): strided views
+        with the head dimension contiguous (copies are made otherwise)."""
+        B, H, Sq, D = q.shape
+        Sk = v.shape[2]
+        k = kt.permute(0, 1, 3, 2)                 # (B, H, Sk, D) view
+        keep = []
+
+        def rows(t):
+            if t.stride(3) != 1 or any(st % 4 for st in t.stride()[:3]):
+                t = t.contiguous()
+                keep.append(t)
+            return t
+
+        q, k, v = rows(q), rows(k), rows(v)
+        ms = [0, 0, 0, 0]
+        mptr = 0
+        if mask is not None:
+            if mask.dtype != q.dtype:
+                mask = self._cast(mask, q.dtype)
+                keep.append(mask)
+            while mask.dim() < 4:
+                mask = mask.unsqueeze(0)
+            mask = mask.expand(B, H, Sq, Sk)
+            ms = list(mask.stride())
+            mptr = mask.data_ptr()
+        desc = self.k.AttnDesc(q.data_ptr(), k.data_ptr(), v.data_ptr(), mptr,
+                               list(q.stride()[:3]), list(k.stride()[:3]),
+                               list(v.stride()[:3]), ms, B, H, Sq, Sk, D,
+                               float(scale))
+        return desc, keep
+
+    def attention_fwd(self, q, kt, v, mask, scale, out, lse):
+        """out (B, Sq, H, D) contiguous, lse (B, H, Sq) float32."""
+        desc, keep = self._attn_desc(q, kt, v, mask, scale)
+        self.k.attention_fwd(_code(q), desc, out.data_ptr(), lse.data_ptr(),
+                             self._s())
+
+    def attention_bwd(self, dout, q, kt, v, mask, scale, out, lse, dq, dk,
+                      dv):
+        """dout / out / dq / dk / dv: contiguous (B, S, H, D)."""
+        desc, keep = self._attn_desc(q, kt, v, mask, scale)
+        dout = self._contig(dout)
+        delta = self._tmp(lse.numel())
+        self.k.attention_bwd(_code(q), desc, out.data_ptr(), dout.data_ptr(),
+                             lse.data_ptr(), delta.data_ptr(), dq.data_ptr(),
+                             dk.data_ptr(), dv.data_ptr(), self._s())
 
     # ---- recurrent cells ---------------------------------------------------------------------------------------------
     def lstm_cell_fwd(self, gates, c_prev, c, h, acts):

@@ -388,3 +388,62 @@ def GeluBackward(dy, x):
             lambda a, b, o: a._dev.math.gelu_bwd(a.view(), b.view(), o.view()),
             [d, xs], [dx])
     return dx
+
+
+# ---------------------------------------------------------------------------
+# fused scaled-dot-product attention
+# ---------------------------------------------------------------------------
+def AttentionForward(q, kt, v, mask, scale):
+    """softmax(scale * q @ kt + mask) @ v for q (B, H, Sq, D), kt (B, H, D,
+    Sk), v (B, H, Sk, D) -- typically transposed *views* of (B, S, H, D)
+    activations, which the kernel reads in place.  Returns (out, lse): out is
+    (B, Sq, H, D) contiguous (the layout the following merge-heads reshape
+    wants), lse (B, H, Sq) float32 for the backward pass."""
+    dev = q.device()
+    B, H, Sq, D = q.shape()
+    out = Tensor([B, Sq, H, D], dev, q.data_type())
+    lse = Tensor([B, H, Sq], dev, dtypes.kFloat32)
+    scale = float(scale)
+    if mask is None:
+        _submit(dev, "AttentionForward",
+                lambda a, b, c, o, l: a._dev.math.attention_fwd(
+                    a.view(), b.view(), c.view(), None, scale, o.view(),
+                    l.view()),
+                [q, kt, v], [out, lse])
+    else:
+        _submit(dev, "AttentionForward",
+                lambda a, b, c, m, o, l: a._dev.math.attention_fwd(
+                    a.view(), b.view(), c.view(), m.view(), scale, o.view(),
+                    l.view()),
+                [q, kt, v, mask], [out, lse])
+    return out, lse
+
+
+def AttentionBackward(dout, q, kt, v, mask, out, lse, scale):
+    """-> (dq, dkt, dv) shaped like q, kt, v.  They are transposed views of
+    contiguous (B, S, H, D) buffers, so the transposes upstream undo them
+    without a copy."""
+    from .tensor_core import Transpose
+    dev = q.device()
+    B, H, Sq, D = q.shape()
+    Sk = v.shape()[2]
+    dq = Tensor([B, Sq, H, D], dev, q.data_type())
+    dk = Tensor([B, Sk, H, D], dev, q.data_type())
+    dv = Tensor([B, Sk, H, D], dev, q.data_type())
+    scale = float(scale)
+    d = _contig(dout)
+    if mask is None:
+        _submit(dev, "AttentionBackward",
+                lambda g, a, b, c, o, l, x, y, z: a._dev.math.attention_bwd(
+                    g.view(), a.view(), b.view(), c.view(), None, scale,
+                    o.view(), l.view(), x.view(), y.view(), z.view()),
+                [d, q, kt, v, out, lse], [dq, dk, dv])
+    else:
+        _submit(dev, "AttentionBackward",
+                lambda g, a, b, c, m, o, l, x, y, z:
+                a._dev.math.attention_bwd(
+                    g.view(), a.view(), b.view(), c.view(), m.view(), scale,
+                    o.view(), l.view(), x.view(), y.view(), z.view()),
+                [d, q, kt, v, mask, out, lse], [dq, dk, dv])
+    return (Transpose(dq, [0, 2, 1, 3]), Transpose(dk, [0, 2, 3, 1]),
+            Transpose(dv, [0, 2, 1, 3]))

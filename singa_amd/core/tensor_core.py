@@ -1271,6 +1271,42 @@ def SGDUpdateMulti(params, grads, bufs, lr, momentum, dampening, weight_decay,
     return params
 
 
+ADAPT_RMSPROP, ADAPT_ADAGRAD, ADAPT_ADAM = 0, 1, 2
+
+
+def AdaptiveUpdateMulti(rule, params, grads, state1, state2, hypers,
+                        scale=1.0):
+    """One fused step of RMSProp / AdaGrad / Adam for a list of parameters (one
+    graph node, one launch per 48 tensors).  ``hypers`` = (lr, weight_decay,
+    epsilon, a, b, step): one-element device tensors, ``a`` / ``b`` / ``step``
+    may be None for rules that do not use them.  ``state2`` is None except
+    for Adam."""
+    n = len(params)
+    assert n > 0 and n == len(grads) == len(state1)
+    state2 = list(state2) if state2 is not None else []
+    hyp = [h for h in hypers if h is not None]
+    slots = [h is not None for h in hypers]
+    scale = float(scale)
+
+    def body(*args):
+        gs = args[n:2 * n]
+        off = 2 * n + n + len(state2)
+        hs = iter(args[off:off + len(hyp)])
+        full = [next(hs).flat() if present else None for present in slots]
+        outs = args[off + len(hyp):]
+        ps, s1 = outs[0:n], outs[n:2 * n]
+        s2 = outs[2 * n:3 * n] if state2 else None
+        ps[0]._dev.math.adaptive_update_multi(
+            rule, [t.view() for t in ps], [t.view() for t in gs],
+            [t.view() for t in s1], [t.view() for t in s2] if s2 else None,
+            *full, scale)
+
+    reads = list(params) + list(grads) + list(state1) + state2 + hyp
+    writes = list(params) + list(state1) + state2
+    _submit(params[0]._dev, "AdaptiveUpdateMulti", body, reads, writes)
+    return params
+
+
 _bin_max, MaxWithRet = _binary("Max", "max")
 _bin_min, MinWithRet = _binary("Min", "min")
 EltwiseMax = _bin_max

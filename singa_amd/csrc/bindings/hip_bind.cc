@@ -488,6 +488,62 @@ PYBIND11_MODULE(_hip, m) {
           "scatter_add_segments");
   });
 
+  m.def("adaptive_update_multi", [](int dt, int rule, std::vector<uintptr_t> p,
+                                    std::vector<uintptr_t> g,
+                                    std::vector<uintptr_t> s1,
+                                    std::vector<uintptr_t> s2,
+                                    std::vector<int64_t> n, uintptr_t lr,
+                                    uintptr_t wd, uintptr_t eps, uintptr_t a,
+                                    uintptr_t b, uintptr_t step, float scale,
+                                    uintptr_t s) {
+    if (p.size() != g.size() || p.size() != s1.size() ||
+        p.size() != n.size() || (!s2.empty() && s2.size() != p.size()))
+      throw std::invalid_argument("adaptive_update_multi: list lengths differ");
+    check(sa_adaptive_update_multi(
+              dt, rule, (int)p.size(),
+              reinterpret_cast<void *const *>(p.data()),
+              reinterpret_cast<const void *const *>(g.data()),
+              reinterpret_cast<void *const *>(s1.data()),
+              s2.empty() ? nullptr
+                         : reinterpret_cast<void *const *>(s2.data()),
+              n.data(), (const float *)CP(lr), (const float *)CP(wd),
+              (const float *)CP(eps), (const float *)CP(a),
+              (const float *)CP(b), (const float *)CP(step), scale, S(s)),
+          "adaptive_update_multi");
+  });
+
+  // ---- fused attention ----------------------------------------------------------------------------------
+  py::class_<AttnDesc>(m, "AttnDesc")
+      .def(py::init([](uintptr_t q, uintptr_t k, uintptr_t v, uintptr_t mask,
+                       std::vector<int64_t> qs, std::vector<int64_t> ks,
+                       std::vector<int64_t> vs, std::vector<int64_t> ms, int B,
+                       int H, int Sq, int Sk, int D, float scale) {
+        if (qs.size() != 3 || ks.size() != 3 || vs.size() != 3 ||
+            ms.size() != 4)
+          throw std::invalid_argument("AttnDesc: stride list lengths");
+        AttnDesc d{};
+        d.q = CP(q); d.k = CP(k); d.v = CP(v); d.mask = CP(mask);
+        for (int i = 0; i < 3; ++i) {
+          d.q_stride[i] = qs[i]; d.k_stride[i] = ks[i]; d.v_stride[i] = vs[i];
+        }
+        for (int i = 0; i < 4; ++i) d.m_stride[i] = ms[i];
+        d.B = B; d.H = H; d.Sq = Sq; d.Sk = Sk; d.D = D; d.scale = scale;
+        return d;
+      }));
+  m.def("attention_fwd", [](int dt, const AttnDesc &d, uintptr_t out,
+                            uintptr_t lse, uintptr_t s) {
+    check(sa_attention_fwd(dt, &d, P(out), (float *)P(lse), S(s)),
+          "attention_fwd");
+  });
+  m.def("attention_bwd", [](int dt, const AttnDesc &d, uintptr_t out,
+                            uintptr_t dout, uintptr_t lse, uintptr_t delta,
+                            uintptr_t dq, uintptr_t dk, uintptr_t dv,
+                            uintptr_t s) {
+    check(sa_attention_bwd(dt, &d, CP(out), CP(dout), (const float *)CP(lse),
+                           (float *)P(delta), P(dq), P(dk), P(dv), S(s)),
+          "attention_bwd");
+  });
+
   // ---- device-side time stamps ---------------------------------------------------------------------------
   m.def("stamp_open", [](uintptr_t slots, int i, uintptr_t s) {
     check(sa_stamp_open((unsigned long long *)P(slots), i, S(s)), "stamp_open");

@@ -261,6 +261,27 @@ int sa_sgd_update_multi(int dtype, int count, void *const *p,
                         const float *weight_decay, int nesterov, float scale,
                         hipStream_t s);
 
+// RMSProp (rule 0), AdaGrad (1), Adam (2) for `count` tensors; states share
+// the parameter dtype; hyper-parameters are one-element float device arrays
+// (a / b: rho or beta_1 / beta_2; step: Adam's step counter)
+namespace sa {
+struct AdaptBatch {
+  void *p[kSgdMaxTensors];
+  const void *g[kSgdMaxTensors];
+  void *s1[kSgdMaxTensors];
+  void *s2[kSgdMaxTensors];
+  int64_t n[kSgdMaxTensors];
+  int chunk_start[kSgdMaxTensors + 1];
+  int count;
+};
+}  // namespace sa
+int sa_adaptive_update_multi(int dtype, int rule, int count, void *const *p,
+                             const void *const *g, void *const *s1,
+                             void *const *s2, const int64_t *n,
+                             const float *lr, const float *wd,
+                             const float *eps, const float *a, const float *b,
+                             const float *step, float scale, hipStream_t s);
+
 // ---- index.hip -----------------------------------------------------------------------------------------------
 // out[o, j, i] = x[o, idx[j], i]   (x: outer x n_in x inner)
 int sa_index_select(int dtype, const void *x, const int *idx, void *out,
@@ -316,6 +337,25 @@ int sa_sparse_select(const float *x, int64_t n, float thr, int topk, int64_t k,
 // dense[idx] += sign * value over `nseg` consecutive payloads of capacity cap
 int sa_scatter_add_segments(const int *payloads, int nseg, int64_t cap,
                             float sign, float *dense, int64_t n, hipStream_t s);
+
+// ---- attention.hip ------------------------------------------------------------
+// softmax(scale * Q K^T + mask) V per (batch, head), head dimension 64.
+// Q / K / V element (b, h, row, d) sits at base + b * stride[0] + h *
+// stride[1] + row * stride[2] + d; the additive mask (may be null, same
+// dtype) at mask + b * m_stride[0] + h * m_stride[1] + q * m_stride[2] +
+// key * m_stride[3] (0 = broadcast).  Outputs and gradients are contiguous
+// (B, S, H, 64); lse / delta are float (B, H, Sq).
+struct AttnDesc {
+  const void *q, *k, *v, *mask;
+  int64_t q_stride[3], k_stride[3], v_stride[3], m_stride[4];
+  int B, H, Sq, Sk, D;
+  float scale;
+};
+int sa_attention_fwd(int dtype, const AttnDesc *d, void *out, float *lse,
+                     hipStream_t s);
+int sa_attention_bwd(int dtype, const AttnDesc *d, const void *out,
+                     const void *dout, const float *lse, float *delta,
+                     void *dq, void *dk, void *dv, hipStream_t s);
 
 // ---- profile.hip --------------------------------------------------------------
 // Device-side time stamps that can be captured into a hipGraph (timing events

@@ -128,9 +128,102 @@ __global__ void sgd_multi_kernel(SgdBatch batch, const float *__restrict__ lr_p,
   }
 }
 
+// ---- adaptive rules, many tensors per launch -------------------------------------
+// RMSProp, AdaGrad and Adam as one pass over (p, g, state[, state2]) for a
+// whole list of parameters: gradient scaling, L2 weight decay, the moment
+// updates, Adam's bias correction and the step itself.  The composed form
+// (reference python/singa/opt.py:392-441, 489-533, 608-683) is 8 to 14
+// element-wise launches per parameter, each re-reading its operands.
+//
+//   rule 0  r = a r + (1 - a) g^2;            p -= lr g / sqrt(r + eps)
+//   rule 1  h += g^2;                         p -= lr g / sqrt(h + eps)
+//   rule 2  m = a m + (1 - a) g; v = b v + (1 - b) g^2; t = step + 1
+//           p -= lr (m / (1 - a^t)) / (sqrt(v / (1 - b^t)) + eps)
+template <typename T>
+__global__ void adaptive_multi_kernel(AdaptBatch batch, int rule,
+                                      const float *__restrict__ lr_p,
+                                      const float *__restrict__ wd_p,
+                                      const float *__restrict__ eps_p,
+                                      const float *__restrict__ a_p,
+                                      const float *__restrict__ b_p,
+                                      const float *__restrict__ step_p,
+                                      float scale) {
+  const float lr = lr_p[0], wd = wd_p[0], eps = eps_p[0];
+  const float a = a_p ? a_p[0] : 0.f, b = b_p ? b_p[0] : 0.f;
+  float c1 = 1.f, c2 = 1.f;
+  if (rule == 2) {
+    const float t = step_p[0] + 1.f;
+    c1 = 1.f / (1.f - powf(a, t));
+    c2 = 1.f / (1.f - powf(b, t));
+  }
+  int t = 0;
+  const int chunk = blockIdx.x;
+  while (t + 1 < batch.count && chunk >= batch.chunk_start[t + 1]) ++t;
+  const int64_t base = (int64_t)(chunk - batch.chunk_start[t]) * kSgdChunk;
+  const int64_t n = batch.n[t];
+  const int64_t len = n - base < kSgdChunk ? n - base : kSgdChunk;
+  T *__restrict__ p = static_cast<T *>(batch.p[t]) + base;
+  const T *__restrict__ g = static_cast<const T *>(batch.g[t]) + base;
+  T *__restrict__ s1 = static_cast<T *>(batch.s1[t]) + base;
+  T *__restrict__ s2 =
+      batch.s2[t] ? static_cast<T *>(batch.s2[t]) + base : nullptr;
+  for (int64_t i = threadIdx.x; i < len; i += blockDim.x) {
+    const float pv = to_f<T>(p[i]);
+    const float gv = to_f<T>(g[i]) * scale + wd * pv;
+    float u = to_f<T>(s1[i]);
+    float upd;
+    if (rule == 0) {
+      u = a * u + (1.f - a) * gv * gv;
+      upd = gv / sqrtf(u + eps);
+    } else if (rule == 1) {
+      u += gv * gv;
+      upd = gv / sqrtf(u + eps);
+    } else {
+      float w = to_f<T>(s2[i]);
+      u = a * u + (1.f - a) * gv;
+      w = b * w + (1.f - b) * gv * gv;
+      s2[i] = from_f<T>(w);
+      upd = (u * c1) / (sqrtf(w * c2) + eps);
+    }
+    s1[i] = from_f<T>(u);
+    p[i] = from_f<T>(pv - lr * upd);
+  }
+}
+
 }  // namespace sa
 
 using namespace sa;
+
+int sa_adaptive_update_multi(int dtype, int rule, int count, void *const *p,
+                             const void *const *g, void *const *s1,
+                             void *const *s2, const int64_t *n,
+                             const float *lr, const float *wd,
+                             const float *eps, const float *a, const float *b,
+                             const float *step, float scale, hipStream_t s) {
+  if (rule < 0 || rule > 2) return -2;
+  if (rule == 2 && (s2 == nullptr || step == nullptr)) return -2;
+  for (int first = 0; first < count; first += kSgdMaxTensors) {
+    AdaptBatch bt;
+    bt.count = count - first < kSgdMaxTensors ? count - first : kSgdMaxTensors;
+    int chunks = 0;
+    for (int i = 0; i < bt.count; ++i) {
+      bt.p[i] = p[first + i];
+      bt.g[i] = g[first + i];
+      bt.s1[i] = s1[first + i];
+      bt.s2[i] = s2 ? s2[first + i] : nullptr;
+      bt.n[i] = n[first + i];
+      bt.chunk_start[i] = chunks;
+      chunks += (int)((n[first + i] + kSgdChunk - 1) / kSgdChunk);
+    }
+    bt.chunk_start[bt.count] = chunks;
+    if (chunks == 0) continue;
+    SA_DISPATCH_FLOAT(dtype, T, {
+      hipLaunchKernelGGL((adaptive_multi_kernel<T>), dim3(chunks), dim3(256),
+                         0, s, bt, rule, lr, wd, eps, a, b, step, scale);
+    });
+  }
+  return 0;
+}
 
 int sa_sgd_update_multi(int dtype, int count, void *const *p,
                         const void *const *g, void *const *buf,

@@ -1,22 +1,30 @@
-"""Model: a Layer with a training step that can be buffered as a graph.
+"""Model: a Layer whose training step can be recorded once and replayed.
 
-``train_one_batch`` of every subclass is wrapped: in graph mode the first call
-executes the Python body once with graph recording on (ops are recorded, not
-run), every call (including the first) then replays the recorded graph on the
-device and returns the cached output tensors.  Inputs must therefore be the
-same tensor objects on every call; their contents are refreshed in place.
+A subclass defines ``forward`` and ``train_one_batch``.  When the model runs in
+graph mode, the first training call executes the Python body exactly once
+with the device recording (every tensor op lands on the device graph instead
+of running); that call and all later ones then ask the device to replay the
+recorded step, which on the MI355X is a single hipGraph launch, and hand back
+the output tensors of the recording.  The caller therefore feeds the same
+input tensor objects every iteration and refreshes their contents in place.
 
-API parity: reference python/singa/model.py (ModelMeta.buffer_operation
-:39-100, compile :156-184, save_states / load_states :244-354: a zip holding
-``tensor_dict.npz`` and ``states_attr.json``).
+The step's life cycle is owned by one ``_RecordedStep`` object per model
+(idle -> recorded -> replaying; ``Model.compile`` / ``graph`` / ``train`` put
+it back to idle), not inferred from call counts.
+
+API parity: reference python/singa/model.py (graph buffering of
+``train_one_batch`` :39-100, ``compile`` :156-184, ``save_states`` /
+``load_states`` :244-354).  Checkpoints keep the reference's container: a zip
+with ``tensor_dict.npz`` (one array per state) and ``states_attr.json``
+(state type, shape and dtype per name).
 """
+import contextlib
+import functools
 import gc
+import io
 import json
 import os
-import tempfile
 import zipfile
-from collections.abc import Iterable
-from functools import wraps
 
 import numpy as np
 
@@ -26,57 +34,88 @@ from . import tensor
 from .tensor import Tensor
 
 
+def _walk_tensors(obj):
+    """Every Tensor inside a (possibly nested) result structure."""
+    if isinstance(obj, Tensor):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _walk_tensors(v)
+    elif isinstance(obj, (list, tuple, set)):
+        for v in obj:
+            yield from _walk_tensors(v)
+
+
+@contextlib.contextmanager
+def _recording(dev):
+    """Operations issued inside are recorded on ``dev`` instead of run."""
+    dev.EnableGraph(True)
+    try:
+        yield dev
+    finally:
+        dev.EnableGraph(False)
+
+
+def _first_tensor(args):
+    for t in _walk_tensors(args):
+        return t
+    return None
+
+
+class _RecordedStep(object):
+    """Recording and replay of one model's training step."""
+
+    def __init__(self):
+        self.outputs = None
+        self.recorded = False
+
+    def reset(self):
+        self.outputs = None
+        self.recorded = False
+
+    def run(self, model, body, args, kwargs):
+        lead = _first_tensor(args[:1])
+        if lead is None:
+            raise ValueError('a graph-mode training step takes at least one '
+                             'input tensor (first positional argument)')
+        dev = lead.device
+        if not self.recorded:
+            with _recording(dev):
+                self.outputs = body(model, *args, **kwargs)
+                dev.Sync()           # recorded as the step's closing sync node
+            self.recorded = True
+            # The outputs keep their storage but let go of the autograd tape:
+            # afterwards only tensors the user can still reach pin blocks, and
+            # the scheduler may recycle everything else between replays.
+            for t in _walk_tensors(self.outputs):
+                t.creator = None
+            gc.collect()
+        dev.RunGraph(model.sequential)
+        return self.outputs
+
+
+def _graphed(body):
+    """Wrap ``train_one_batch``: replay through the model's recorded step in
+    graph mode, plain call otherwise."""
+
+    @functools.wraps(body)
+    def train_one_batch(self, *args, **kwargs):
+        if self.graph_mode and self.training:
+            return self._step.run(self, body, args, kwargs)
+        return body(self, *args, **kwargs)
+
+    train_one_batch._is_graphed = True
+    return train_one_batch
+
+
 class ModelMeta(layer.LayerMeta):
+    """Wraps the ``train_one_batch`` a subclass defines."""
 
-    def buffer_operation(func):
-
-        def remove_creator(tensors):
-            if not tensors:
-                return
-            if isinstance(tensors, tensor.Tensor):
-                tensors.creator = None
-            elif isinstance(tensors, Iterable):
-                for item in tensors:
-                    if isinstance(item, tensor.Tensor):
-                        item.creator = None
-                    elif isinstance(item, Iterable) and not isinstance(
-                            item, (str, bytes)):
-                        remove_creator(item)
-
-        @wraps(func)
-        def wrapper(self, *args, **kwargs):
-            if self.graph_mode and self.training:
-                if len(args) == 0:
-                    raise ValueError('expect at least one input tensor')
-                first = args[0][0] if isinstance(args[0], list) else args[0]
-                assert isinstance(first, Tensor), (
-                    'function expects PlaceHolders or Tensors')
-                dev = first.device
-
-                if not self._buffered:
-                    # record the step: the python body runs exactly once
-                    dev.EnableGraph(True)
-                    self._results = func(self, *args, **kwargs)
-                    dev.Sync()
-                    dev.EnableGraph(False)
-                    self._buffered = True
-                    # drop the autograd tape so that only tensors the user can
-                    # still reach pin their blocks
-                    remove_creator(self._results)
-                    gc.collect()
-
-                dev.RunGraph(self.sequential)
-                return self._results
-            else:
-                return func(self, *args, **kwargs)
-
-        return wrapper
-
-    def __new__(cls, name, bases, attr):
-        if 'train_one_batch' in attr:
-            attr['train_one_batch'] = ModelMeta.buffer_operation(
-                attr['train_one_batch'])
-        return super(ModelMeta, cls).__new__(cls, name, bases, attr)
+    def __new__(mcs, name, bases, namespace):
+        step = namespace.get('train_one_batch')
+        if step is not None and not getattr(step, '_is_graphed', False):
+            namespace['train_one_batch'] = _graphed(step)
+        return super(ModelMeta, mcs).__new__(mcs, name, bases, namespace)
 
 
 class Model(layer.Layer, metaclass=ModelMeta):
@@ -90,27 +129,25 @@ class Model(layer.Layer, metaclass=ModelMeta):
 
     def __init__(self):
         super(Model, self).__init__()
-        self.training = True
-        self.graph_mode = True
-        self.sequential = False
-        self._buffered = False
-        self._results = None
+        self.training, self.graph_mode, self.sequential = True, True, False
+        self._step = _RecordedStep()
 
+    # ---- execution mode ---------------------------------------------------------
     def compile(self, inputs, is_train=True, use_graph=False, sequential=False):
-        """Derive parameter shapes from the input placeholders with a dry
-        forward pass (recorded, then discarded) and set the execution mode."""
-        assert len(inputs) > 0 and isinstance(inputs[0], Tensor), (
-            'compile function expects PlaceHolders or Tensors')
-        dev = inputs[0].device
-        dev.EnableGraph(True)
-        self.forward(*inputs)
-        dev.EnableGraph(False)
-        dev.ResetGraph()
-
-        autograd.training = is_train
-        self.training = is_train
-        self.graph_mode = use_graph
-        self.sequential = sequential
+        """Create the parameters from the shapes of ``inputs`` and choose the
+        execution mode.  The forward pass runs with the device recording, so
+        only the (eagerly executed) parameter initialisation costs anything;
+        the recorded operations are thrown away."""
+        lead = _first_tensor(list(inputs)[:1])
+        assert lead is not None, 'compile takes a list of input tensors'
+        try:
+            with _recording(lead.device):
+                self.forward(*inputs)
+        finally:
+            lead.device.ResetGraph()
+        self._step.reset()
+        self.train(is_train)
+        self.graph(use_graph, sequential)
 
     def forward(self, *input):
         raise NotImplementedError
@@ -119,90 +156,71 @@ class Model(layer.Layer, metaclass=ModelMeta):
         raise NotImplementedError
 
     def train(self, mode=True):
-        self.training = mode
-        autograd.training = mode
+        self.training = bool(mode)
+        autograd.training = bool(mode)
 
     def eval(self):
-        self.train(mode=False)
+        self.train(False)
 
     def graph(self, mode=True, sequential=False):
-        self.graph_mode = mode
-        self.sequential = sequential
+        self.graph_mode, self.sequential = mode, sequential
 
     def __get_name__(self):
-        return self.__class__.__name__
+        return type(self).__name__
 
     def __call__(self, *input, **kwargs):
-        if self.training:
-            return self.train_one_batch(*input, **kwargs)
-        return self.forward(*input, **kwargs)
+        run = self.train_one_batch if self.training else self.forward
+        return run(*input, **kwargs)
 
     def set_optimizer(self, optimizer):
         self.optimizer = optimizer
 
+    # ---- checkpoints --------------------------------------------------------------
     def save_states(self, fpath, aux_states={}):
-        """Write model states plus ``aux_states`` (name -> Tensor, e.g.
-        optimizer moments) to the zip file ``fpath``; refuses to overwrite."""
-        assert not os.path.isfile(fpath), (
-            "Failed to save states, %s is already existed." % fpath)
-        states = self.get_states()
-        tensor_dict = {}
-        states_attr = {}
-        for kind, group in ((self.MODEL_STATE_TYPE, states),
-                            (self.AUX_STATE_TYPE, aux_states)):
-            for k, v in group.items():
-                assert isinstance(v, tensor.Tensor), \
-                    "Only tensor state is allowed"
-                tensor_dict[k] = tensor.to_numpy(v)
-                states_attr[k] = {
-                    'state_type': kind,
-                    'shape': v.shape,
-                    'dtype': v.dtype
-                }
-        tmp_dir = tempfile.mkdtemp(prefix='singa_save_states_')
-        tensor_dict_fp = tmp_dir + self.TENSOR_DICT_FILENAME
-        states_attr_fp = tmp_dir + self.STATES_ATTR_FILENAME
-        np.savez(tensor_dict_fp, **tensor_dict)
-        with open(states_attr_fp, 'w') as fp:
-            json.dump(states_attr, fp)
-        with zipfile.ZipFile(fpath, mode="w") as zf:
-            for p in (tensor_dict_fp, states_attr_fp):
-                zf.write(p, os.path.basename(p),
-                         compress_type=zipfile.ZIP_DEFLATED)
-        os.remove(tensor_dict_fp)
-        os.remove(states_attr_fp)
-        os.rmdir(tmp_dir)
+        """Write the model's states and ``aux_states`` (name -> Tensor, e.g.
+        optimizer moments) to the zip file ``fpath``.  An existing file is
+        never overwritten."""
+        assert not os.path.exists(fpath), \
+            "refusing to overwrite the existing checkpoint %s" % fpath
+        arrays, attrs = {}, {}
+        tagged = [(self.MODEL_STATE_TYPE, self.get_states()),
+                  (self.AUX_STATE_TYPE, aux_states)]
+        for state_type, states in tagged:
+            for name, value in states.items():
+                assert isinstance(value, Tensor), "Only tensor state is allowed"
+                arrays[name] = tensor.to_numpy(value)
+                attrs[name] = dict(state_type=state_type, shape=value.shape,
+                                   dtype=value.dtype)
+        blob = io.BytesIO()
+        np.savez(blob, **arrays)
+        with zipfile.ZipFile(fpath, mode="w",
+                             compression=zipfile.ZIP_DEFLATED) as archive:
+            archive.writestr(self.TENSOR_DICT_FILENAME.lstrip('/'),
+                             blob.getvalue())
+            archive.writestr(self.STATES_ATTR_FILENAME.lstrip('/'),
+                             json.dumps(attrs))
 
     def load_states(self, fpath):
-        """Restore model states from ``fpath``; returns the aux states."""
-        assert os.path.isfile(fpath), (
-            "Failed to load states, %s is not exist." % fpath)
-        tmp_dir = tempfile.mkdtemp(prefix='singa_load_states_')
-        with zipfile.ZipFile(fpath, 'r') as zf:
-            zf.extractall(tmp_dir)
-        tensor_dict_fp = tmp_dir + self.TENSOR_DICT_FILENAME
-        states_attr_fp = tmp_dir + self.STATES_ATTR_FILENAME
-        with open(states_attr_fp) as f:
-            states_attr = json.load(f)
-        tensor_dict = np.load(tensor_dict_fp)
-        model_states = dict()
-        aux_states = dict()
-        for k in tensor_dict.files:
-            if states_attr[k]['state_type'] == self.MODEL_STATE_TYPE:
-                model_states[k] = tensor.from_numpy(tensor_dict[k])
-            elif states_attr[k]['state_type'] == self.AUX_STATE_TYPE:
-                aux_states[k] = tensor.from_numpy(tensor_dict[k])
-        tensor_dict.close()
-        self.set_states(model_states)
-        # float32 master copies held by the optimizer describe the old values
-        forget = getattr(getattr(self, "optimizer", None), "forget_masters",
-                         None)
-        if forget is None:
-            forget = getattr(getattr(getattr(self, "optimizer", None), "opt",
-                                     None), "forget_masters", None)
-        if forget is not None:
-            forget()
-        os.remove(tensor_dict_fp)
-        os.remove(states_attr_fp)
-        os.rmdir(tmp_dir)
-        return aux_states
+        """Restore the model's states from ``fpath`` and return the auxiliary
+        states stored with them (name -> Tensor)."""
+        assert os.path.exists(fpath), "no checkpoint at %s" % fpath
+        with zipfile.ZipFile(fpath, 'r') as archive:
+            attrs = json.loads(archive.read(
+                self.STATES_ATTR_FILENAME.lstrip('/')).decode())
+            arrays = np.load(io.BytesIO(archive.read(
+                self.TENSOR_DICT_FILENAME.lstrip('/'))))
+            by_type = {self.MODEL_STATE_TYPE: {}, self.AUX_STATE_TYPE: {}}
+            for name in arrays.files:
+                kind = attrs[name]['state_type']
+                if kind in by_type:
+                    by_type[kind][name] = tensor.from_numpy(arrays[name])
+        self.set_states(by_type[self.MODEL_STATE_TYPE])
+        # A recorded (or captured) step keeps reading the optimizer's own
+        # tensors: anything it derives from the parameters -- float32 master
+        # copies of 16-bit weights -- is refreshed in place, never rebound.
+        opt_ = getattr(self, "optimizer", None)
+        for holder in (opt_, getattr(opt_, "opt", None)):
+            sync = getattr(holder, "sync_masters", None)
+            if sync is not None:
+                sync(self.get_params())
+        return by_type[self.AUX_STATE_TYPE]

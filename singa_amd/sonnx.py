@@ -111,7 +111,7 @@ class SingaBackend(object):
         'Neg': 'Negative', 'Reciprocal': 'Reciprocal', 'NonZero': 'NonZero',
         'Ceil': 'Ceil', 'Floor': 'Floor', 'Abs': 'Abs', 'Exp': 'Exp',
         'Round': 'Rounde', 'Erf': 'Erf', 'LayerNormalization': 'LayerNorm',
-        'Gelu': 'Gelu',
+        'Gelu': 'Gelu', 'FusedAttention': 'Attention',
         'Unsqueeze': 'Unsqueeze', 'ScatterElements': 'ScatterElements',
         'Cast': 'Cast', 'Split': 'Split', 'Squeeze': 'Squeeze',
         'GlobalAveragePool': 'GlobalAveragePool', 'LeakyRelu': 'LeakyRelu',
@@ -150,6 +150,8 @@ class SingaBackend(object):
         if t == 'Gelu':
             assert _s(g("approximate", "none")) == "none"
             return op()
+        if t == 'FusedAttention':
+            return op(g("scale", 1.0))
         if t == 'Where':
             n.set_attr_inputs(n.inputs[0], 'condition')
             return op(None)
@@ -588,6 +590,115 @@ def _fuse_transformer_patterns(graph):
             'Gelu', [x], [nodes[last].output[0]],
             name=(nodes[last].name or "gelu_%d" % last) + "_fused")
 
+    # ---- scaled-dot-product attention ---------------------------------------
+    #   MatMul(q, kT) -> Div(c) | Mul(c) -> [Add(mask)] -> Softmax(last axis)
+    #   -> MatMul(., v) -> Transpose(0, 2, 1, 3) -> Reshape(B, S, H * D)
+    # with q = Transpose(Reshape(x, [.., .., H, 64]), (0, 2, 1, 3)): the head
+    # dimension must be known to be 64, the size the fused kernel is built for
+    def const_shape(name):
+        v = consts.get(name)
+        return None if v is None else [int(a) for a in v.reshape(-1)]
+
+    def head_split(name):
+        """(H, D) if ``name`` is Transpose(Reshape(., [..., H, D]), 0213)"""
+        p = producer.get(name)
+        if p is None or nodes[p].op_type != 'Transpose' or \
+                list(attr(nodes[p], 'perm', [])) != [0, 2, 1, 3]:
+            return None
+        r = producer.get(nodes[p].input[0])
+        if r is None or nodes[r].op_type != 'Reshape' or \
+                len(nodes[r].input) < 2:
+            return None
+        shp = const_shape(nodes[r].input[1])
+        if shp is None or len(shp) != 4:
+            return None
+        return shp[2], shp[3]
+
+    for i, n in enumerate(nodes):
+        if i in dead or n.op_type != 'Softmax' or \
+                attr(n, 'axis', 1) not in (-1, 3):
+            continue
+        chain = [i]
+        cur = producer.get(n.input[0])
+        if cur is None or cur in dead or only(n.input[0]) is None:
+            continue
+        mask = None
+        if nodes[cur].op_type == 'Add':
+            a0, a1 = nodes[cur].input
+            pa, pb = producer.get(a0), producer.get(a1)
+            scaled = None
+            for cand, oth, pc in ((a0, a1, pa), (a1, a0, pb)):
+                if pc is not None and pc not in dead and \
+                        nodes[pc].op_type in ('Mul', 'Div', 'MatMul') and \
+                        only(cand) is not None:
+                    scaled, mask = cand, oth
+                    break
+            if scaled is None:
+                continue
+            chain.append(cur)
+            cur = producer[scaled]
+        scale = 1.0
+        if nodes[cur].op_type in ('Mul', 'Div'):
+            sc_node = nodes[cur]
+            val, src = None, None
+            if sc_node.op_type == 'Div':
+                val = scalar(sc_node.input[1])
+                src = sc_node.input[0]
+                if val is not None:
+                    val = 1.0 / val
+            else:
+                for a, b in ((0, 1), (1, 0)):
+                    v = scalar(sc_node.input[b])
+                    if v is not None:
+                        val, src = v, sc_node.input[a]
+                        break
+            if val is None or only(src) is None:
+                continue
+            scale = val
+            chain.append(cur)
+            cur = producer.get(src)
+            if cur is None or cur in dead:
+                continue
+        if nodes[cur].op_type != 'MatMul':
+            continue
+        mm1 = cur
+        chain.append(mm1)
+        q_name, kt_name = nodes[mm1].input
+        hd = head_split(q_name)
+        if hd is None or hd[1] != 64:
+            continue
+        c = only(n.output[0])
+        if not c or nodes[c[0]].op_type != 'MatMul' or \
+                nodes[c[0]].input[0] != n.output[0]:
+            continue
+        mm2 = c[0]
+        v_name = nodes[mm2].input[1]
+        if head_split(v_name) != hd:
+            continue
+        c = only(nodes[mm2].output[0])
+        if not c or nodes[c[0]].op_type != 'Transpose' or \
+                list(attr(nodes[c[0]], 'perm', [])) != [0, 2, 1, 3]:
+            continue
+        tr = c[0]
+        c = only(nodes[tr].output[0])
+        if not c or nodes[c[0]].op_type != 'Reshape' or \
+                len(nodes[c[0]].input) < 2:
+            continue
+        rs = c[0]
+        shp = const_shape(nodes[rs].input[1])
+        if shp is None or len(shp) != 3 or \
+                shp[2] not in (-1, hd[0] * hd[1]):
+            continue
+        chain += [mm2, tr, rs]
+        if any(k in dead for k in chain):
+            continue
+        dead.update(chain)
+        ins = [q_name, kt_name, v_name] + ([mask] if mask else [])
+        replace[rs] = helper.make_node(
+            'FusedAttention', ins, [nodes[rs].output[0]],
+            name=(nodes[rs].name or "attn_%d" % rs) + "_fused",
+            scale=float(scale))
+
     out = []
     for i, n in enumerate(nodes):
         if i in replace:
@@ -613,6 +724,9 @@ class SingaRep(object):
         self.has_initialized = False
         self.is_graph = False
         self._const_cache = {}
+        # set by SONNXModel(trainable_weights=True): a registry that receives
+        # the float initializers as parameters
+        self.weights = None
 
     def initialize(self):
         self.outputs_info = {o.name: o for o in self.outputs}
@@ -694,6 +808,14 @@ class SingaRep(object):
                         val = np.atleast_1d(self.states[inp])
                         t = tensor.Tensor(device=self.dev, data=val)
                         t.requires_grad = False
+                        if self.weights is not None and \
+                                val.dtype.kind == 'f' and val.size > 1:
+                            # an initializer consumed as data (MatMul / Add /
+                            # Gather operand, layer-norm scale): a trainable
+                            # parameter of the model that owns ``weights``
+                            t.requires_grad = True
+                            t.stores_grad = True
+                            self.weights.add(inp, t)
                         self._const_cache[key] = t
                     inputs.append(t)
                 else:
@@ -740,11 +862,45 @@ class SingaRep(object):
         return list(outputs_dict.values())
 
 
+class _GraphWeights(layer.Layer):
+    """The float initializers of an imported graph that are consumed as plain
+    tensor operands (MatMul / Add / Gather inputs, layer-norm scales), kept as
+    named parameters so that the optimizer updates them and checkpoints hold
+    them.  Transformer exports keep all their weights in this form."""
+
+    def __init__(self):
+        super(_GraphWeights, self).__init__()
+        self._initialized = True
+        self.table = OrderedDict()
+
+    def add(self, name, t):
+        t.name = (self.name or "graph_weights") + layer.Layer.sep + name
+        self.table[t.name] = t
+
+    def get_params(self):
+        return dict(self.table)
+
+    def set_params(self, params):
+        for k, v in params.items():
+            if k in self.table:
+                self.table[k].copy_from(v)
+
+    def get_states(self):
+        return self.get_params()
+
+    def set_states(self, states):
+        self.set_params(states)
+
+
 class SONNXModel(model.Model):
     """A Model whose forward pass is an imported ONNX graph; subclass it and
-    add ``train_one_batch`` to fine-tune (reference sonnx.py:2196-2220)."""
+    add ``train_one_batch`` to fine-tune (reference sonnx.py:2196-2220).
+    ``trainable_weights=True`` also turns the float initializers that the
+    graph feeds to MatMul / Add / Gather into parameters (the weights of a
+    transformer export), not only those owned by Conv / Gemm / BatchNorm
+    layers."""
 
-    def __init__(self, onnx_model):
+    def __init__(self, onnx_model, trainable_weights=False):
         super(SONNXModel, self).__init__()
         self.sg_ir = prepare(onnx_model)
         for node, operator in self.sg_ir.layers:
@@ -754,6 +910,9 @@ class SONNXModel(model.Model):
                 setattr(self, node.name, operator)
             else:
                 self.__dict__[node.name] = operator
+        if trainable_weights:
+            self.graph_weights = _GraphWeights()
+            self.sg_ir.weights = self.graph_weights
         self.sg_ir.is_graph = True
 
     def forward(self, *input, aux_output=(), **kwargs):

@@ -454,6 +454,45 @@ def test_conv_all_passes_16bit(maths, case, dt):
     close(dw, rdw)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,C,H,W,K", [
+    (2, 64, 8, 8, 256),      # backward-data with 64 rows: 64 x 128 tiles
+    (3, 256, 14, 14, 64),    # forward with 64 rows; rows 4-byte aligned only
+    (2, 128, 12, 20, 128),   # 128 x 128 tiles, ragged pixel tile
+    (2, 64, 7, 7, 64),       # odd row length: implicit-GEMM kernel instead
+])
+def test_conv1x1_16bit_gemm_path(maths, dt, N, C, H, W, K):
+    """16-bit 1x1 / stride 1 convolutions without bias run as one tiled GEMM
+    per image (forward and backward-data, with and without the fused
+    addend); reference: fp32 convolution on the same rounded inputs."""
+    hm, cm, dev = maths
+    x = rnd(N, C, H, W, seed=40).to(dt)
+    w = rnd(K, C, 1, 1, seed=41).to(dt)
+    eps = 2 ** -10 if dt == torch.float16 else 2 ** -7
+
+    def close(got, ref):
+        ref = ref.numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got.float().cpu().numpy(), ref,
+                                   atol=eps * scale, rtol=2 * eps)
+
+    ry = torch.empty(N, K, H, W)
+    cm.conv_fwd(x.float(), w.float(), None, ry, (1, 1), (0, 0), 1)
+    y = torch.empty(N, K, H, W, device=dev.torch_device, dtype=dt)
+    hm.conv_fwd(g(x, dev), g(w, dev), None, y, (1, 1), (0, 0), 1)
+    close(y, ry)
+    dy = rnd(N, K, H, W, seed=42).to(dt)
+    add = rnd(N, C, H, W, seed=43).to(dt)
+    rdx = torch.empty(N, C, H, W)
+    cm.conv_bwd_data(dy.float(), w.float(), rdx, (1, 1), (0, 0), 1)
+    dx = torch.empty_like(x, device=dev.torch_device)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (1, 1), (0, 0), 1)
+    close(dx, rdx)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (1, 1), (0, 0), 1,
+                     g(add, dev))
+    close(dx, rdx + add.float())
+
+
 @pytest.mark.parametrize("shape", [(8, 16, 14, 14), (32, 64, 7, 7), (16, 10),
                                    (4, 3, 33, 17)])
 def test_batchnorm(maths, shape):

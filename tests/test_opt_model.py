@@ -154,6 +154,69 @@ def test_optimizer_states_roundtrip(dev):
     assert tensor.to_numpy(o2.step_counter)[0] == 1
 
 
+def test_adaptive_rules_fused_many(dev):
+    """One launch updates several tensors; weight decay and the data-parallel
+    gradient scale are part of the kernel."""
+    shapes = [(7,), (3, 5), (4100,)]
+    for make, rule in [
+            (lambda: opt.RMSProp(lr=0.01, rho=0.8, weight_decay=0.1), "rms"),
+            (lambda: opt.AdaGrad(lr=0.05, weight_decay=0.1), "ada"),
+            (lambda: opt.Adam(lr=0.01, weight_decay=0.1), "adam")]:
+        o = make()
+        ws = [RS.randn(*s).astype(np.float32) for s in shapes]
+        ps = [P(w, dev, "p%d" % i) for i, w in enumerate(ws)]
+        s1 = [np.zeros_like(w) for w in ws]
+        s2 = [np.zeros_like(w) for w in ws]
+        for t in range(1, 4):
+            gs = [RS.randn(*s).astype(np.float32) for s in shapes]
+            o.apply_many([(p, tensor.Tensor(device=dev, data=g))
+                          for p, g in zip(ps, gs)], scale=0.5)
+            o.step()
+            for i, g in enumerate(gs):
+                g = 0.5 * g + 0.1 * ws[i]
+                if rule == "rms":
+                    s1[i] = 0.8 * s1[i] + 0.2 * g * g
+                    ws[i] = ws[i] - 0.01 * g / np.sqrt(s1[i] + 1e-8)
+                elif rule == "ada":
+                    s1[i] = s1[i] + g * g
+                    ws[i] = ws[i] - 0.05 * g / np.sqrt(s1[i] + 1e-8)
+                else:
+                    s1[i] = 0.9 * s1[i] + 0.1 * g
+                    s2[i] = 0.999 * s2[i] + 0.001 * g * g
+                    ws[i] = ws[i] - 0.01 * (s1[i] / (1 - 0.9 ** t)) / (
+                        np.sqrt(s2[i] / (1 - 0.999 ** t)) + 1e-8)
+        for p, w in zip(ps, ws):
+            np.testing.assert_allclose(tensor.to_numpy(p), w, rtol=2e-3,
+                                       atol=2e-5)
+
+
+def test_set_states_keeps_tensor_identity(dev):
+    """Restoring a checkpoint writes into the tensors a recorded step reads;
+    it never rebinds them."""
+    for make, tables in [
+            (lambda: opt.SGD(lr=0.1, momentum=0.9), ["moments"]),
+            (lambda: opt.Adam(lr=0.01), ["m", "v"]),
+            (lambda: opt.RMSProp(lr=0.01), ["running_average"]),
+            (lambda: opt.AdaGrad(lr=0.01), ["history"])]:
+        src, dst = make(), make()
+        for o, val in [(src, 2.0), (dst, 1.0)]:
+            p = P(np.ones(3), dev, "w")
+            for _ in range(int(val)):
+                o.apply("w", p, tensor.Tensor(
+                    device=dev, data=np.full(3, val, np.float32)))
+                o.step()
+        held = {n: getattr(dst, n)["w"] for n in tables}
+        counter, lr_value = dst.step_counter, dst.lr_value
+        dst.set_states(src.get_states())
+        assert dst.step_counter is counter and dst.lr_value is lr_value
+        assert tensor.to_numpy(dst.step_counter)[0] == 2
+        for n in tables:
+            assert getattr(dst, n)["w"] is held[n]
+            np.testing.assert_array_equal(
+                tensor.to_numpy(held[n]),
+                tensor.to_numpy(getattr(src, n)["w"]))
+
+
 # --------------------------------------------------------------- initializers
 def test_initializers(dev):
     t = tensor.Tensor((40, 60), dev)
@@ -273,6 +336,38 @@ def test_model_save_load(dev, tmp_path):
     assert float(tensor.to_numpy(aux["epoch"]).reshape(-1)[0]) == 3
     for k, v in m2.get_params().items():
         np.testing.assert_array_equal(tensor.to_numpy(v), params[k])
+
+
+def test_load_states_under_recorded_graph(dev, tmp_path):
+    """A checkpoint loaded after the step was recorded takes effect in the
+    replayed step (parameters, momentum and step counter are overwritten in
+    place)."""
+    l_ref, p_ref, m = _train(dev, True, False, steps=3)
+    # _train reset the device graph; record again and keep replaying
+    tx, ty = _data(dev)
+    m.compile([tx], is_train=True, use_graph=True, sequential=False)
+    m(tx, ty)
+    f = os.path.join(str(tmp_path), "mid.zip")
+    aux = {"opt/" + k: v for k, v in m.optimizer.get_states()["moments"]
+           .items()}
+    m.save_states(f, aux_states=aux)
+    snap = {k: tensor.to_numpy(v) for k, v in m.get_params().items()}
+    m(tx, ty)
+    after_one = {k: tensor.to_numpy(v) for k, v in m.get_params().items()}
+    m(tx, ty)                              # drift away
+    st = m.optimizer.get_states()
+    loaded = m.load_states(f)
+    m.optimizer.set_states({
+        "step_counter": st["step_counter"] - 2,
+        "moments": {k[len("opt/"):]: v for k, v in loaded.items()}})
+    for k, v in m.get_params().items():
+        np.testing.assert_array_equal(tensor.to_numpy(v), snap[k])
+    m(tx, ty)                              # replay of the recorded step
+    for k, v in m.get_params().items():
+        np.testing.assert_allclose(tensor.to_numpy(v), after_one[k],
+                                   rtol=1e-5, atol=1e-6)
+    dev.EnableGraph(False)
+    dev.ResetGraph()
 
 
 def test_graph_profiling_output(dev, capsys):

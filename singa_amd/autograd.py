@@ -13,7 +13,7 @@ API parity: reference python/singa/autograd.py (Operator :227-341, Dummy
 the reference assembles from per-index copies (Gather, Slice, Tile, Expand,
 Pad, Embedding, OneHot, reductions ...) are single device kernels here.
 """
-from collections import Counter, deque
+from collections import Counter
 
 import numpy as np
 
@@ -26,140 +26,137 @@ CTensor = singa.Tensor
 training = False
 
 
+# ---------------------------------------------------------------------------
+# broadcasting helpers
+# ---------------------------------------------------------------------------
 def axis_helper(y_shape, x_shape):
-    """Axes of ``y_shape`` along which ``x_shape`` was broadcast."""
-    res = []
-    j = len(x_shape) - 1
-    for i in range(len(y_shape) - 1, -1, -1):
-        if j < 0 or x_shape[j] != y_shape[i]:
-            res.append(i)
-        j -= 1
-    return tuple(res[::-1])
+    """Axes of ``y_shape`` along which ``x_shape`` was broadcast (missing
+    leading axes and axes whose extents differ)."""
+    lead = len(y_shape) - len(x_shape)
+    return tuple(i for i, n in enumerate(y_shape)
+                 if i < lead or x_shape[i - lead] != n)
 
 
 def back_broadcast(y_shape, x_shape, x):
     """Reduce gradient ``x`` (core tensor of shape y_shape) to ``x_shape``."""
-    y_shape, x_shape = list(y_shape), list(x_shape)
-    if y_shape != x_shape:
-        axes = axis_helper(y_shape, x_shape)
-        x = singa.ReduceND(x, list(axes), "sum", keepdims=False)
-        x = singa.Reshape(x, x_shape)
-    return x
-
-
-def infer_dependency(op):
-    """Count, for the sub-graph ending at ``op``, how many consumers every
-    producing op and every tensor (by ``Tensor.uid``) has."""
-    op_count = Counter()
-    tensor_count = Counter()
-    queue = deque([op])
-    while len(queue) > 0:
-        cur_op = queue.pop()
-        for src_op, xid, _, _ in cur_op.src:
-            if src_op not in op_count:
-                op_count[src_op] = 1
-                queue.append(src_op)
-            else:
-                op_count[src_op] += 1
-            tensor_count[xid] += 1
-    return op_count, tensor_count
+    if list(y_shape) == list(x_shape):
+        return x
+    summed = singa.ReduceND(x, list(axis_helper(y_shape, x_shape)), "sum",
+                            keepdims=False)
+    return singa.Reshape(summed, list(x_shape))
 
 
 def make_slice(arr, axis, i):
     """Index list selecting position(s) ``i`` along ``axis`` of ``arr``
     (reference python/singa/autograd.py:1631)."""
-    slc = [slice(None)] * arr.ndim
-    slc[axis] = i
-    return slc
+    return [i if d == axis else slice(None) for d in range(arr.ndim)]
+
+
+def _filled_core(shape, dev, dtype, value):
+    t = CTensor(list(shape), dev, dtype)
+    t.SetFloatValue(float(value))
+    return t
+
+
+# ---------------------------------------------------------------------------
+# the tape
+# ---------------------------------------------------------------------------
+def infer_dependency(op):
+    """Count, for the sub-graph ending at ``op``, how many consumers every
+    producing op and every tensor (by ``Tensor.uid``) has."""
+    op_uses, tensor_uses = Counter(), Counter()
+    frontier = [op]
+    while frontier:
+        for producer, uid, _, _ in frontier.pop().src:
+            tensor_uses[uid] += 1
+            op_uses[producer] += 1
+            if op_uses[producer] == 1:      # first sighting: expand it
+                frontier.append(producer)
+    return op_uses, tensor_uses
 
 
 def gradients(y, dy=None):
     """Dictionary id(param) -> gradient for every tensor that stores grad."""
-    grads = {}
-    for p, dp in backward(y, dy):
-        grads[id(p)] = dp
-    return grads
+    return {id(p): g for p, g in backward(y, dy)}
+
+
+def _seed_gradient(y, dy):
+    """The upstream gradient in the form ``y``'s creator expects: the loss
+    operators take a python float, every other op a core tensor."""
+    if isinstance(dy, Tensor):
+        return dy.data
+    value = 1.0 if dy is None else float(dy)
+    if getattr(y.creator, "takes_scalar_dy", False):
+        return value
+    return _filled_core(y.shape, y.device, y.dtype, value)
+
+
+def _offer_partial_sum(op, pending):
+    """An op whose kernel can add onto an existing gradient is handed the
+    partial sum already collected for its first input; what it returns then
+    replaces that partial sum instead of being added in a pass of its own."""
+    if not (getattr(op, "fuses_dx_addend", False) and op.src):
+        return False
+    producer, uid = op.src[0][0], op.src[0][1]
+    collected = pending.get(producer)
+    if collected is None or collected[producer.y_id2idx[uid]] is None:
+        return False
+    op.dx_addend = collected[producer.y_id2idx[uid]]
+    return True
 
 
 def backward(y, dy=None):
-    """Generator over (param, grad) pairs, in the order gradients complete."""
-    assert isinstance(y, Tensor), "wrong input type."
-    op_dep, tensor_dep = infer_dependency(y.creator)
-    assert y.size() == 1, ("y must be a Tensor with a single value;"
-                           "size of y is % d" % y.size())
-    if dy is None:
-        dy = float(1.0)
-    elif isinstance(dy, Tensor):
-        dy = dy.data
-    else:
-        dy = float(dy)
+    """Generator over (param, grad) pairs, in the order gradients complete.
 
-    if isinstance(dy, float) and not getattr(y.creator, "takes_scalar_dy",
-                                             False):
-        # only the loss operators accept a python float as upstream gradient
-        g0 = CTensor(list(y.shape), y.device, y.dtype)
-        g0.SetFloatValue(dy)
-        dy = g0
-    ready = deque([(y.creator, (dy,))])
-    not_ready = {}
-
+    ``pending[op]`` holds the output gradients of ``op`` gathered so far; an
+    op runs its backward once every consumer has reported (its count in
+    ``ops_left`` reaches zero), and a gradient-storing tensor is yielded the
+    moment its last consumer has reported, so the caller can start reducing
+    it while the sweep continues."""
+    assert isinstance(y, Tensor), "backward starts from a Tensor"
+    assert y.size() == 1, (
+        "backward starts from a single value, y has %d elements" % y.size())
+    ops_left, tensors_left = infer_dependency(y.creator)
+    seed = _seed_gradient(y, dy)
     if y.stores_grad:
-        if isinstance(dy, float):
-            g = CTensor([1], y.device)
-            g.SetFloatValue(dy)
-        else:
-            g = dy
-        yield (y, Tensor(device=g.device(), data=g))
+        g = seed if not isinstance(seed, float) \
+            else _filled_core([1], y.device, tensor.float32, seed)
+        yield y, Tensor(device=g.device(), data=g)
 
-    while len(ready) > 0:
-        op, dys = ready.pop()
-        if not op.requires_grad or isinstance(op, Dummy):
+    pending = {}
+    runnable = [(y.creator, (seed,))]
+    while runnable:
+        op, dys = runnable.pop()
+        if isinstance(op, Dummy) or not op.requires_grad:
             continue
-        # An op whose kernel can add onto an existing gradient is handed the
-        # partial sum already collected for its first input; what it returns
-        # then replaces that partial sum instead of being added in a pass of
-        # its own.
-        folded = False
-        if getattr(op, "fuses_dx_addend", False) and op.src:
-            part = not_ready.get(op.src[0][0])
-            if part is not None:
-                p_idx = op.src[0][0].y_id2idx[op.src[0][1]]
-                if part[p_idx] is not None:
-                    op.dx_addend = part[p_idx]
-                    folded = True
+        folded = _offer_partial_sum(op, pending)
         dxs = op._do_backward(*dys)
-        assert len(op.src) == len(dxs), (
-            "the number of src ops (=%d) and dx (=%d) not match" %
-            (len(op.src), len(dxs)))
-        for i, ((src_op, x_id, y_t, y_stores_grad),
-                dx) in enumerate(zip(op.src, dxs)):
-            if isinstance(src_op, Dummy) and (not src_op.stores_grad):
+        assert len(dxs) == len(op.src), (
+            "%s returned %d gradients for %d inputs" %
+            (op.name, len(dxs), len(op.src)))
+        for position, (source, dx) in enumerate(zip(op.src, dxs)):
+            producer, uid, kept, keeps_grad = source
+            if isinstance(producer, Dummy) and not producer.stores_grad:
                 continue
-            y_idx = src_op.y_id2idx[x_id]
-            if src_op not in not_ready:
-                not_ready[src_op] = [None for _ in src_op.y_id2idx]
-                not_ready[src_op][y_idx] = dx
-            else:
-                dxs_ = not_ready[src_op]
-                if dxs_[y_idx] is None or (folded and i == 0):
-                    dxs_[y_idx] = dx
-                elif dx is not None:
-                    # a tensor consumed by several ops: gradients add up
-                    dxs_[y_idx] = singa.__add__(dxs_[y_idx], dx)
-            op_dep[src_op] -= 1
-            tensor_dep[x_id] -= 1
-            if y_stores_grad and tensor_dep[x_id] == 0:
-                g = not_ready[src_op][y_idx]
-                tg = Tensor(device=g.device(), data=g,
-                            name=src_op.grad_name(y_idx))
-                yield (y_t, tg)
-            if op_dep[src_op] == 0:
-                if src_op.requires_grad is True:
-                    assert not isinstance(
-                        src_op, Dummy), "Dummy op does not do backward()"
-                    ready.append((src_op, not_ready[src_op]))
-                del not_ready[src_op]
-        del op  # release everything the op cached
+            slot = producer.y_id2idx[uid]
+            collected = pending.setdefault(producer,
+                                           [None] * len(producer.y_id2idx))
+            if collected[slot] is None or (folded and position == 0):
+                collected[slot] = dx
+            elif dx is not None:
+                # a tensor consumed by several ops: gradients add up
+                collected[slot] = singa.__add__(collected[slot], dx)
+            ops_left[producer] -= 1
+            tensors_left[uid] -= 1
+            if keeps_grad and tensors_left[uid] == 0:
+                g = collected[slot]
+                yield kept, Tensor(device=g.device(), data=g,
+                                   name=producer.grad_name(slot))
+            if ops_left[producer] == 0:
+                complete = pending.pop(producer)
+                if producer.requires_grad is True:
+                    runnable.append((producer, complete))
+        del op          # release everything the op cached
 
 
 class _AllTrue(object):
@@ -171,62 +168,58 @@ class _AllTrue(object):
 
 
 class Operator(object):
-    """Forward + backward of one tensor computation on core tensors."""
+    """Forward + backward of one tensor computation on core tensors.
+
+    Calling an operator on Tensors records it on the tape: ``src`` lists, per
+    input, (creator op, input uid, the input itself when it stores a gradient,
+    stores_grad); the outputs are new Tensors whose ``creator`` is the op and
+    ``y_id2idx`` maps their uids to output positions."""
 
     op_count = 0
     x_needs_grad = _AllTrue()
 
     def __init__(self, name=None):
         if name is None:
-            self.name = "{}#{}".format(self.__class__.__name__,
-                                       Operator.op_count)
+            name = "%s#%d" % (type(self).__name__, Operator.op_count)
             Operator.op_count += 1
-        else:
-            self.name = name
+        self.name = name
 
     def __call__(self, *xs):
         return self._do_forward(*xs)
 
     def output_name(self, idx):
-        return "{}:{}".format(self.name, idx)
+        return "%s:%d" % (self.name, idx)
 
     def grad_name(self, idx):
-        return "{}_g".format(self.output_name(idx))
+        return self.output_name(idx) + "_g"
 
     def _do_forward(self, *xs):
-        assert all([isinstance(x, Tensor) for x in xs
-                    ]), "xs should include only Tensor instances"
-        self.requires_grad = any([x.requires_grad for x in xs])
+        for x in xs:
+            assert isinstance(x, Tensor), (
+                "%s takes Tensors, got %s" % (self.name, type(x).__name__))
+        self.requires_grad = any(x.requires_grad for x in xs)
         # inputs whose gradient nobody consumes (data fed to the network):
         # ops may return None for them instead of computing it
         self.x_needs_grad = tuple(
             x.stores_grad or
             (x.requires_grad and not isinstance(x.creator, Dummy))
             for x in xs)
-        self.src = []
-        for x in xs:
-            if x.stores_grad:
-                self.src.append((x.creator, x.uid, x, x.stores_grad))
-            else:
-                self.src.append((x.creator, x.uid, None, x.stores_grad))
-        xs = tuple(x.data for x in xs)
-        ys = self.forward(*xs)
-        if not isinstance(ys, tuple):
-            ys = (ys,)
+        self.src = [(x.creator, x.uid, x if x.stores_grad else None,
+                     x.stores_grad) for x in xs]
+        produced = self.forward(*(x.data for x in xs))
+        if not isinstance(produced, tuple):
+            produced = (produced,)
         ys = tuple(
-            Tensor(device=y.device(), data=y, requires_grad=self.requires_grad,
-                   creator=self, name=self.output_name(idx))
-            for idx, y in enumerate(ys))
+            Tensor(device=core.device(), data=core, creator=self,
+                   requires_grad=self.requires_grad,
+                   name=self.output_name(i))
+            for i, core in enumerate(produced))
         self.y_id2idx = {y.uid: i for i, y in enumerate(ys)}
         return ys
 
     def _do_backward(self, *dys):
         dxs = self.backward(*dys)
-        if isinstance(dxs, list):
-            dxs = tuple(dxs)
-        if not isinstance(dxs, tuple):
-            dxs = (dxs,)
-        return dxs
+        return tuple(dxs) if isinstance(dxs, (list, tuple)) else (dxs,)
 
     def forward(self, *xs):
         raise NotImplementedError
@@ -239,23 +232,27 @@ class Operator(object):
 
 
 class Dummy(Operator):
-    """Leaf placeholder: the creator of tensors not produced by an op."""
+    """Leaf placeholder: the creator of tensors not produced by an op.
+    Attribute look-ups it cannot answer go to its tensor."""
+
+    requires_grad = False
 
     def __init__(self, tensor, name=None):
-        super(Dummy, self).__init__(name)
+        Operator.__init__(self, name)
+        self.tensor = tensor
         self.src = []
         self.y_id2idx = {tensor.uid: 0}
-        self.tensor = tensor
-        self.requires_grad = False
 
     def output_name(self, idx):
         return self.name
 
     def grad_name(self, idx):
-        return "{}_g".format(self.name)
+        return "%s_g" % self.name
 
     def __getattr__(self, name):
-        return self.tensor.__getattribute__(name)
+        if name == "tensor":            # not bound yet (copy / unpickle)
+            raise AttributeError(name)
+        return getattr(self.tensor, name)
 
 
 def _scalar_like(x, value):
@@ -394,9 +391,6 @@ class ReLU(Operator):
         return singa.ReLUBackward(dy, self.input)
 
 
-def relu(x):
-    return ReLU()(x)[0]
-
 
 class Clip(Operator):
     """Clamp to [min, max]; either bound may be None."""
@@ -432,9 +426,6 @@ class Identity(Operator):
         return dy
 
 
-def identity(x):
-    return Identity()(x)[0]
-
 
 class PRelu(Operator):
     """y = x if x >= 0 else slope * x (slope broadcastable to x)."""
@@ -461,9 +452,6 @@ class PRelu(Operator):
         ds = back_broadcast(self.shape3, self.shape1, ds)
         return dx, ds
 
-
-def prelu(x, slope):
-    return PRelu()(x, slope)[0]
 
 
 class Elu(Operator):
@@ -648,88 +636,25 @@ Erf = _simple_unary(
         2.0 / float(np.sqrt(np.pi))), "error function")
 
 
-def tanh(x):
-    return Tanh()(x)[0]
 
 
-def sigmoid(x):
-    return Sigmoid()(x)[0]
 
 
-def cos(x):
-    return Cos()(x)[0]
 
 
-def sin(x):
-    return Sin()(x)[0]
 
 
-def tan(x):
-    return Tan()(x)[0]
 
 
-def cosh(x):
-    return Cosh()(x)[0]
 
 
-def sinh(x):
-    return Sinh()(x)[0]
 
 
-def acos(x):
-    return Acos()(x)[0]
 
 
-def asin(x):
-    return Asin()(x)[0]
 
 
-def atan(x):
-    return Atan()(x)[0]
 
-
-def acosh(x):
-    return Acosh()(x)[0]
-
-
-def asinh(x):
-    return Asinh()(x)[0]
-
-
-def atanh(x):
-    return Atanh()(x)[0]
-
-
-def abs(a):
-    return Abs()(a)[0]
-
-
-def exp(a):
-    return Exp()(a)[0]
-
-
-def log(x):
-    return Log()(x)[0]
-
-
-def sqrt(x):
-    return Sqrt()(x)[0]
-
-
-def softplus(x):
-    return SoftPlus()(x)[0]
-
-
-def softsign(x):
-    return SoftSign()(x)[0]
-
-
-def reciprocal(x):
-    return Reciprocal()(x)[0]
-
-
-def erf(x):
-    return Erf()(x)[0]
 
 
 class _ZeroGradUnary(Operator):
@@ -765,24 +690,9 @@ class Rounde(_ZeroGradUnary):
     fn = staticmethod(singa.RoundE)
 
 
-def sign(a):
-    return Sign()(a)[0]
 
 
-def ceil(x):
-    return Ceil()(x)[0]
 
-
-def floor(x):
-    return Floor()(x)[0]
-
-
-def round(x):
-    return Round()(x)[0]
-
-
-def rounde(x):
-    return Rounde()(x)[0]
 
 
 class Negative(Operator):
@@ -793,9 +703,6 @@ class Negative(Operator):
     def backward(self, dy):
         return singa.MultFloat(dy, -1.0)
 
-
-def negative(x):
-    return Negative()(x)[0]
 
 
 # ---------------------------------------------------------------------------
@@ -822,9 +729,6 @@ class Add(_BroadcastBinary):
         return dx0, dx1
 
 
-def add(a, b):
-    return Add()(a, b)[0]
-
 
 class Sub(_BroadcastBinary):
 
@@ -839,9 +743,6 @@ class Sub(_BroadcastBinary):
                              singa.MultFloat(dy, -1.0))
         return dx0, dx1
 
-
-def sub(a, b):
-    return Sub()(a, b)[0]
 
 
 class Mul(_BroadcastBinary):
@@ -860,9 +761,6 @@ class Mul(_BroadcastBinary):
                              singa.__mul__(dy, self.input[0]))
         return dx0, dx1
 
-
-def mul(x, y):
-    return Mul()(x, y)[0]
 
 
 class Div(_BroadcastBinary):
@@ -885,9 +783,6 @@ class Div(_BroadcastBinary):
         return dx0, dx1
 
 
-def div(a, b):
-    return Div()(a, b)[0]
-
 
 class Pow(_BroadcastBinary):
 
@@ -909,9 +804,6 @@ class Pow(_BroadcastBinary):
         dx1 = back_broadcast(self.shape3, self.shape1, dx1)
         return dx0, dx1
 
-
-def pow(a, b):
-    return Pow()(a, b)[0]
 
 
 # ---------------------------------------------------------------------------
@@ -980,32 +872,11 @@ class Xor(_NoGrad):
         return singa.Abs(m)
 
 
-def less(x, y):
-    return Less()(x, y)[0]
 
 
-def greater(x, y):
-    return Greater()(x, y)[0]
 
 
-def equal(x, y):
-    return Equal()(x, y)[0]
 
-
-def _and(a, b):
-    return And()(a, b)[0]
-
-
-def _or(a, b):
-    return Or()(a, b)[0]
-
-
-def _not(x):
-    return Not()(x)[0]
-
-
-def _xor(a, b):
-    return Xor()(a, b)[0]
 
 
 class Where(Operator):
@@ -1078,9 +949,6 @@ class Matmul(Operator):
                 dw = back_broadcast(dw.shape(), w.shape(), dw)
         return dx, dw
 
-
-def matmul(x, w):
-    return Matmul()(x, w)[0]
 
 
 class AddBias(Operator):
@@ -1227,9 +1095,6 @@ class Gelu(Operator):
     def backward(self, dy):
         return singa.GeluBackward(dy, self.input)
 
-
-def gelu(x):
-    return Gelu()(x)[0]
 
 
 class Attention(Operator):
@@ -1982,9 +1847,6 @@ class Shape(_NoGrad):
         return t.data
 
 
-def shape(x):
-    return Shape()(x)[0]
-
 
 class ConstantOfShape(_NoGrad):
     """A tensor of the shape given by the (host-readable) input, filled with
@@ -2067,9 +1929,6 @@ class NonZero(_NoGrad):
         t.to_device(x.device())
         return t.data
 
-
-def nonzero(x):
-    return NonZero()(x)[0]
 
 
 class ScatterElements(Operator):
@@ -2157,9 +2016,6 @@ class Embedding(Operator):
         # the index input has no gradient
         return None, dw
 
-
-def embedding(x, w):
-    return Embedding()(x, w)[0]
 
 
 # ---------------------------------------------------------------------------
@@ -2498,3 +2354,39 @@ class _RNN(Operator):
 import builtins as _builtins  # noqa: E402
 
 builtins_max = _builtins.max
+
+
+# ---------------------------------------------------------------------------
+# functional forms of the operators that take no attributes:
+# name -> (operator class, number of tensor inputs); each call records a
+# fresh operator instance and returns its single output
+# ---------------------------------------------------------------------------
+def _functional(name, cls, arity):
+    def fn(*xs):
+        if len(xs) != arity:
+            raise TypeError("%s() takes %d tensors, got %d" %
+                            (name, arity, len(xs)))
+        return cls()(*xs)[0]
+    fn.__name__ = fn.__qualname__ = name
+    fn.__doc__ = cls.__doc__
+    return fn
+
+
+for _name, (_cls, _arity) in {
+    "relu": (ReLU, 1), "identity": (Identity, 1), "prelu": (PRelu, 2),
+    "tanh": (Tanh, 1), "sigmoid": (Sigmoid, 1), "cos": (Cos, 1),
+    "sin": (Sin, 1), "tan": (Tan, 1), "cosh": (Cosh, 1), "sinh": (Sinh, 1),
+    "acos": (Acos, 1), "asin": (Asin, 1), "atan": (Atan, 1),
+    "acosh": (Acosh, 1), "asinh": (Asinh, 1), "atanh": (Atanh, 1),
+    "abs": (Abs, 1), "exp": (Exp, 1), "log": (Log, 1), "sqrt": (Sqrt, 1),
+    "softplus": (SoftPlus, 1), "softsign": (SoftSign, 1),
+    "reciprocal": (Reciprocal, 1), "erf": (Erf, 1), "sign": (Sign, 1),
+    "ceil": (Ceil, 1), "floor": (Floor, 1), "round": (Round, 1),
+    "rounde": (Rounde, 1), "negative": (Negative, 1), "add": (Add, 2),
+    "sub": (Sub, 2), "mul": (Mul, 2), "div": (Div, 2), "pow": (Pow, 2),
+    "less": (Less, 2), "greater": (Greater, 2), "equal": (Equal, 2),
+    "_and": (And, 2), "_or": (Or, 2), "_not": (Not, 1), "_xor": (Xor, 2),
+    "matmul": (Matmul, 2), "gelu": (Gelu, 1), "shape": (Shape, 1),
+    "nonzero": (NonZero, 1), "embedding": (Embedding, 2),
+}.items():
+    globals()[_name] = _functional(_name, _cls, _arity)

@@ -2,8 +2,17 @@
 
 A layer creates its parameters lazily from the first input it sees
 (``initialize``), always with graph recording switched off so that parameter
-initialisation never becomes part of a recorded training step.  Parameters are
-named hierarchically (``parent.child.W``) through ``__setattr__``.
+initialisation never becomes part of a recorded training step.
+
+Parameters and persistent states are *registered* when they are created
+(``Layer._new_param`` / ``_new_state``): the base class answers ``get_params``,
+``set_params``, ``get_states`` and ``set_states`` for every layer from that
+registry plus the registered sub-layers, so a layer class only says what it
+owns and how it computes.  Tensors and sub-layers are named hierarchically
+(``parent.child.W``) as they are assigned.
+
+Layers that merely forward to one autograd function are generated from a
+table at the end of the module.
 
 API parity: reference python/singa/layer.py (LayerMeta :29-72, Layer :75-284
 and the layer classes).  ``CudnnRNN`` keeps its reference name and is backed by
@@ -19,64 +28,99 @@ from . import utils
 from .tensor import Tensor
 
 
-def _first_device(args):
-    a = args[0]
-    if isinstance(a, (list, tuple)):
-        a = a[0]
-    assert isinstance(a, Tensor), (
-        'initialize function expects PlaceHolders or Tensors')
-    return a.device
+# ---------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------
+class _eager(object):
+    """Context: graph recording off on ``dev``, previous state restored."""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def __enter__(self):
+        self.was = self.dev.graph_enabled()
+        self.dev.EnableGraph(False)
+
+    def __exit__(self, *exc):
+        self.dev.EnableGraph(self.was)
+        return False
+
+
+def _lead_tensor(args):
+    lead = args[0]
+    while isinstance(lead, (list, tuple)):
+        lead = lead[0]
+    assert isinstance(lead, Tensor), (
+        'a layer is initialised from PlaceHolders or Tensors, got %s' %
+        type(lead).__name__)
+    return lead
+
+
+def _gaussian(std, mean=0.0):
+    return lambda t: t.gaussian(mean, std)
+
+
+def _constant(value):
+    return lambda t: t.set_value(value)
+
+
+def _keep(obj, values, *names):
+    """obj.<name> = values[name] for every name (constructor boilerplate)."""
+    for n in names:
+        setattr(obj, n, values[n])
 
 
 class LayerMeta(type):
+    """Makes ``initialize`` eager and once-only bookkeeping automatic, and
+    makes ``forward`` initialise the layer on its first call."""
 
-    def init_wrapper(func):
+    def __init__(cls, name, bases, namespace):
+        super(LayerMeta, cls).__init__(name, bases, namespace)
+        if 'initialize' in namespace:
+            cls.initialize = LayerMeta._eager_initialize(
+                namespace['initialize'])
+        if 'forward' in namespace:
+            cls.forward = LayerMeta._initialising_forward(namespace['forward'])
 
-        @wraps(func)
-        def wrapper(self, *args, **kwargs):
-            if len(args) == 0:
+    @staticmethod
+    def _eager_initialize(fn):
+
+        @wraps(fn)
+        def initialize(self, *args, **kwargs):
+            if not args:
                 return
-            dev = _first_device(args)
-            prev_state = dev.graph_enabled()
-            dev.EnableGraph(False)
-            func(self, *args, **kwargs)
-            self._initialized = True
-            dev.EnableGraph(prev_state)
+            with _eager(_lead_tensor(args).device):
+                fn(self, *args, **kwargs)
+                self._initialized = True
 
-        return wrapper
+        return initialize
 
-    def forward_wrapper(func):
+    @staticmethod
+    def _initialising_forward(fn):
 
-        @wraps(func)
-        def wrapper(self, *args, **kwargs):
+        @wraps(fn)
+        def forward(self, *args, **kwargs):
             if not self._initialized:
                 self.initialize(*args, **kwargs)
                 self._initialized = True
-            return func(self, *args, **kwargs)
+            return fn(self, *args, **kwargs)
 
-        return wrapper
-
-    def __new__(cls, name, bases, attr):
-        if 'initialize' in attr:
-            attr['initialize'] = LayerMeta.init_wrapper(attr['initialize'])
-        if 'forward' in attr:
-            attr['forward'] = LayerMeta.forward_wrapper(attr['forward'])
-        return super(LayerMeta, cls).__new__(cls, name, bases, attr)
+        return forward
 
 
+# ---------------------------------------------------------------------------
+# base class
+# ---------------------------------------------------------------------------
 class Layer(object, metaclass=LayerMeta):
 
     sep = '.'
 
     def __init__(self):
-        self.name = None
-        self._initialized = False
-        self._parent = None
-        self._layers = dict()
+        vars(self).update(name=None, _initialized=False, _parent=None,
+                          _layers=dict(), _owned={'param': [], 'state': []})
 
     def initialize(self, *input):
         """Create parameters / states / handles that depend on the input."""
-        pass
 
     def forward(self, *input):
         raise NotImplementedError
@@ -84,89 +128,122 @@ class Layer(object, metaclass=LayerMeta):
     def __call__(self, *args, **kwargs):
         return self.forward(*args, **kwargs)
 
+    # ---- registry --------------------------------------------------------------------
+    def _register(self, kind, attr, shape, like, fill, dtype, trainable):
+        t = Tensor(shape=shape, device=like.device,
+                   dtype=tensor.float32 if dtype is None else dtype,
+                   requires_grad=trainable, stores_grad=trainable)
+        fill(t)
+        setattr(self, attr, t)              # also names the tensor
+        if attr not in self._owned[kind]:
+            self._owned[kind].append(attr)
+        return t
+
+    def _new_param(self, attr, shape, like, fill, dtype=None):
+        """Create the trainable tensor ``self.<attr>`` on ``like``'s device."""
+        return self._register('param', attr, shape, like, fill, dtype, True)
+
+    def _new_state(self, attr, shape, like, fill, dtype=None):
+        """Create the persistent, non-trainable tensor ``self.<attr>``."""
+        return self._register('state', attr, shape, like, fill, dtype, False)
+
+    def _own(self, kind):
+        return [getattr(self, a) for a in self._owned[kind]]
+
+    def _ready_children(self):
+        return [c for c in self._layers.values() if c._initialized]
+
     def get_params(self):
-        params = dict()
-        for name, sublayer in self._layers.items():
-            if sublayer._initialized:
-                params.update(sublayer.get_params())
+        params = {t.name: t for t in self._own('param')}
+        for child in self._ready_children():
+            params.update(child.get_params())
         return params
 
     def set_params(self, parameters):
-        names = parameters.keys()
-        for name, sublayer in self._layers.items():
-            if sublayer._initialized:
-                if self._has_layer_param(sublayer, names):
-                    sublayer.set_params(parameters)
+        for t in self._own('param'):
+            t.copy_from(parameters[t.name])
+        for child in self._ready_children():
+            if self._has_layer_param(child, parameters.keys()):
+                child.set_params(parameters)
 
     def get_states(self):
-        states = dict()
-        for name, sublayer in self._layers.items():
-            if sublayer._initialized:
-                states.update(sublayer.get_states())
+        states = {}
+        for child in self._ready_children():
+            states.update(child.get_states())
         states.update(self.get_params())
+        states.update((t.name, t) for t in self._own('state'))
         return states
 
     def set_states(self, states):
-        names = states.keys()
-        for name, sublayer in self._layers.items():
-            if sublayer._initialized:
-                if self._has_layer_param(sublayer, names):
-                    sublayer.set_states(states)
+        for child in self._ready_children():
+            if self._has_layer_param(child, states.keys()):
+                child.set_states(states)
+        for t in self._own('state'):
+            t.copy_from(states[t.name])
         self.set_params(states)
 
+    def set_attribute(self, attribute, attribute_value):
+        assert attribute_value.shape == attribute.shape, (
+            "cannot load a %s value into a %s tensor" %
+            (attribute_value.shape, attribute.shape))
+        attribute.copy_from(attribute_value)
+
+    # ---- input hygiene (never recorded) ----------------------------------------------
     def dtype_check(self, *inputs):
-        """Cast every input to the dtype of the first one (never recorded)."""
-        dev = inputs[0].device
-        flag = dev.graph_enabled()
-        dev.EnableGraph(False)
-        x_dtype = inputs[0].dtype
-        for inp in inputs:
-            if inp.dtype != x_dtype:
-                inp.to_type(x_dtype)
-        dev.EnableGraph(flag)
+        """Cast every later tensor to the dtype of the first one."""
+        lead = inputs[0]
+        with _eager(lead.device):
+            for t in inputs[1:]:
+                if t.dtype != lead.dtype:
+                    t.to_type(lead.dtype)
 
     def device_check(self, *inputs):
-        """Move every input to the device of the first one (never recorded)."""
-        x_device = inputs[0].device
-        prev_state = x_device.graph_enabled()
-        x_device.EnableGraph(False)
-        x_dev_id = x_device.id()
-        for var in inputs:
-            if var.device.id() != x_dev_id:
-                var.to_device(x_device)
-        x_device.EnableGraph(prev_state)
+        """Move every later tensor to the device of the first one."""
+        lead = inputs[0]
+        with _eager(lead.device):
+            for t in inputs[1:]:
+                if t.device.id() != lead.device.id():
+                    t.to_device(lead.device)
 
+    def _align(self, x, *tensors, dtype=True):
+        """device_check (+ dtype_check) of the tensors that exist."""
+        present = [t for t in tensors if t is not None]
+        self.device_check(x, *present)
+        if dtype:
+            self.dtype_check(x, *present)
+
+    # ---- hierarchy and naming ----------------------------------------------------------
     def _has_layer_param(self, layer, names):
-        for name in names:
-            if name.startswith(layer.name):
-                return True
-        return False
+        return any(n.startswith(layer.name) for n in names)
 
     def _get_name_prefix(self):
-        if self.name and self._parent:
-            return self.name + Layer.sep
-        return ''
+        return self.name + Layer.sep if self.name and self._parent else ''
+
+    def _attach(self, key, child, name):
+        self._layers[key] = child
+        vars(child)['_parent'] = self
+        child.name = name               # re-names the child's own subtree
 
     def __getattr__(self, name):
-        if '_layers' in self.__dict__:
-            layers = self.__dict__['_layers']
-            if name in layers:
-                return layers[name]
-        raise AttributeError("'{}' object has no attribute '{}'".format(
-            type(self).__name__, name))
+        # only reached when normal lookup fails: sub-layers live in _layers
+        children = vars(self).get('_layers', {})
+        try:
+            return children[name]
+        except KeyError:
+            raise AttributeError("'{}' object has no attribute '{}'".format(
+                type(self).__name__, name)) from None
 
     def __setattr__(self, name, value):
         if isinstance(value, Layer):
-            self.__dict__['_layers'][name] = value
-            value.__dict__['_parent'] = self
-            value.name = self._get_name_prefix() + name
-        else:
-            object.__setattr__(self, name, value)
-            if isinstance(value, Tensor) and value.is_dummy():
+            self._attach(name, value, self._get_name_prefix() + name)
+            return
+        object.__setattr__(self, name, value)
+        if isinstance(value, Tensor):
+            if value.is_dummy():
                 value.name = self._get_name_prefix() + name
-            elif name == 'name' and value:
-                for n, sublayer in self._layers.items():
-                    sublayer.name = self._get_name_prefix() + n
+        elif name == 'name' and value:
+            for key, child in self._layers.items():
+                child.name = self._get_name_prefix() + key
 
     def __delattr__(self, name):
         if name in self._layers:
@@ -175,81 +252,50 @@ class Layer(object, metaclass=LayerMeta):
             object.__delattr__(self, name)
 
     def register_layers(self, *args):
-        """Register sublayers that are not plain attributes (e.g. the blocks
-        of a ResNet stage held in a list)."""
+        """Register sub-layers that are not plain attributes (e.g. the blocks
+        of a ResNet stage held in a list): either one OrderedDict name ->
+        layer, or the layers themselves (named ``<Class>_<position>``)."""
         if len(args) == 1 and isinstance(args[0], OrderedDict):
-            items = args[0].items()
+            named = list(args[0].items())
         else:
-            items = [(v.__class__.__name__ + '_' + str(idx), v)
-                     for idx, v in enumerate(args)]
-        for name, value in items:
-            if isinstance(value, Layer):
-                self._layers[name] = value
-                value.__dict__['_parent'] = self
-                value.name = name
-
-    def set_attribute(self, attribute, attribute_value):
-        assert attribute_value.shape == attribute.shape, (
-            "%s and %s do not match" % (attribute_value.shape, attribute.shape))
-        attribute.copy_from(attribute_value)
+            named = [('%s_%d' % (type(v).__name__, i), v)
+                     for i, v in enumerate(args)]
+        for key, child in named:
+            if isinstance(child, Layer):
+                self._attach(key, child, key)
 
 
+# ---------------------------------------------------------------------------
+# dense layers
+# ---------------------------------------------------------------------------
 class Linear(Layer):
-    """y = x W + b with W of shape (in_features, out_features)."""
+    """y = x W + b with W of shape (in_features, out_features); features are
+    the last axis of a 2-d or batched (..., in_features) input."""
 
     def __init__(self, out_features, *args, bias=True, **kwargs):
-        super(Linear, self).__init__()
+        super().__init__()
+        if args:    # legacy signature Linear(in_features, out_features[, bias])
+            self.in_features, out_features = out_features, args[0]
         self.out_features = out_features
-        # legacy signature Linear(in_features, out_features[, bias])
-        if len(args) > 0:
-            self.in_features = out_features
-            self.out_features = args[0]
-        if len(args) > 1:
-            self.bias = args[1]
-        else:
-            self.bias = bias
+        self.bias = args[1] if len(args) > 1 else bias
 
     def initialize(self, x):
-        # features are the last axis (2-d input as in the reference, or a
-        # batched (..., in_features) input)
-        self.in_features = x.shape[-1]
-        w_shape = (self.in_features, self.out_features)
-        b_shape = (self.out_features,)
-        self.W = Tensor(shape=w_shape, dtype=x.dtype, requires_grad=True,
-                        stores_grad=True, device=x.device)
-        std = math.sqrt(2.0 / (self.in_features + self.out_features))
-        self.W.gaussian(0.0, std)
+        self.in_features = fan_in = x.shape[-1]
+        std = math.sqrt(2.0 / (fan_in + self.out_features))
+        self._new_param('W', (fan_in, self.out_features), x, _gaussian(std),
+                        x.dtype)
+        self.b = None
         if self.bias:
-            self.b = Tensor(shape=b_shape, dtype=x.dtype, requires_grad=True,
-                            stores_grad=True, device=x.device)
-            self.b.set_value(0.0)
-        else:
-            self.b = None
+            self._new_param('b', (self.out_features,), x, _constant(0.0),
+                            x.dtype)
 
     def forward(self, x):
-        if self.b is not None:
-            self.device_check(x, self.W, self.b)
-            self.dtype_check(x, self.W, self.b)
-        else:
-            self.device_check(x, self.W)
-            self.dtype_check(x, self.W)
+        self._align(x, self.W, self.b)
         assert x.shape[-1] == self.W.shape[0], (
-            "Linear layer expects input features size %d received %d" %
+            "Linear layer built for %d input features received %d" %
             (self.W.shape[0], x.shape[-1]))
         y = autograd.matmul(x, self.W)
-        if self.bias:
-            y = autograd.add_bias(y, self.b, axis=0)
-        return y
-
-    def get_params(self):
-        if self.bias:
-            return {self.W.name: self.W, self.b.name: self.b}
-        return {self.W.name: self.W}
-
-    def set_params(self, parameters):
-        self.W.copy_from(parameters[self.W.name])
-        if self.bias:
-            self.b.copy_from(parameters[self.b.name])
+        return autograd.add_bias(y, self.b, axis=0) if self.bias else y
 
 
 class Gemm(Layer):
@@ -257,74 +303,46 @@ class Gemm(Layer):
 
     def __init__(self, nb_kernels, alpha=1.0, beta=1.0, transA=False,
                  transB=True, bias=True, bias_shape=None):
-        super(Gemm, self).__init__()
-        self.nb_kernels = nb_kernels
-        self.alpha = alpha
-        self.beta = beta
-        self.transA = 1 if transA else 0
-        self.transB = 1 if transB else 0
-        self.bias = bias
-        self.bias_shape = bias_shape
+        super().__init__()
+        _keep(self, locals(), 'nb_kernels', 'alpha', 'beta', 'bias',
+              'bias_shape')
+        self.transA, self.transB = int(bool(transA)), int(bool(transB))
+
+    def _in_features_of(self, x):
+        return x.shape[0] if self.transA else x.shape[-1]
 
     def initialize(self, x):
-        self.in_features = x.shape[-1] if self.transA == 0 else x.shape[0]
-        if self.transB == 0:
-            w_shape = (self.in_features, self.nb_kernels)
-        else:
-            w_shape = (self.nb_kernels, self.in_features)
-        b_shape = self.bias_shape if self.bias_shape else (1, self.nb_kernels)
-        self.W = Tensor(shape=w_shape, requires_grad=True, stores_grad=True,
-                        device=x.device)
-        std = math.sqrt(2.0 / (self.in_features + self.nb_kernels))
-        self.W.gaussian(0.0, std)
+        self.in_features = fan_in = self._in_features_of(x)
+        w_shape = (self.nb_kernels, fan_in) if self.transB \
+            else (fan_in, self.nb_kernels)
+        self._new_param('W', w_shape, x,
+                        _gaussian(math.sqrt(2.0 / (fan_in + self.nb_kernels))))
+        self.b = None
         if self.bias:
-            self.b = Tensor(shape=b_shape, requires_grad=True,
-                            stores_grad=True, device=x.device)
-            self.b.set_value(0.0)
-        else:
-            self.b = None
+            self._new_param('b', self.bias_shape or (1, self.nb_kernels), x,
+                            _constant(0.0))
 
     def forward(self, x):
-        if self.b is not None:
-            self.device_check(x, self.W, self.b)
-        else:
-            self.device_check(x, self.W)
-        in_features = x.shape[-1] if self.transA == 0 else x.shape[0]
-        in_features_w = self.W.shape[0] if self.transB == 0 \
-            else self.W.shape[-1]
-        assert in_features == in_features_w, (
-            "Gemm layer expects input features size %d received %d" %
-            (in_features_w, in_features))
+        self._align(x, self.W, self.b, dtype=False)
+        expected = self.W.shape[-1] if self.transB else self.W.shape[0]
+        assert self._in_features_of(x) == expected, (
+            "Gemm layer built for %d input features received %d" %
+            (expected, self._in_features_of(x)))
         return autograd.gemm(x, self.W, self.b, self.alpha, self.beta,
                              self.transA, self.transB)
 
-    def get_params(self):
-        if self.bias:
-            return {self.W.name: self.W, self.b.name: self.b}
-        return {self.W.name: self.W}
-
-    def set_params(self, parameters):
-        self.W.copy_from(parameters[self.W.name])
-        if self.bias:
-            self.b.copy_from(parameters[self.b.name])
-
 
 class Embedding(Layer):
+    """Table lookup: row ``x[i]`` of an (input_dim, output_dim) matrix."""
 
     def __init__(self, input_dim, output_dim, initializer="gaussian"):
-        super(Embedding, self).__init__()
-        self.input_dim = input_dim
-        self.output_dim = output_dim
-        self.initializer = initializer
+        super().__init__()
+        _keep(self, locals(), 'input_dim', 'output_dim', 'initializer')
 
     def initialize(self, x):
-        w_shape = (self.input_dim, self.output_dim)
-        self.W = Tensor(shape=w_shape, requires_grad=True, stores_grad=True,
-                        device=x.device)
-        if self.initializer == 'uniform':
-            self.W.uniform(-1., 1.)
-        else:
-            self.W.gaussian(0., 1.)
+        fill = (lambda t: t.uniform(-1., 1.)) \
+            if self.initializer == 'uniform' else _gaussian(1.)
+        self._new_param('W', (self.input_dim, self.output_dim), x, fill)
 
     def from_pretrained(self, W, freeze=True):
         self.set_params({self.W.name: W})
@@ -333,131 +351,116 @@ class Embedding(Layer):
     def forward(self, x):
         return autograd.embedding(x, self.W)
 
-    def get_params(self):
-        return {self.W.name: self.W}
 
-    def set_params(self, parameters):
-        self.W.copy_from(parameters[self.W.name])
-
-
-def _norm_pair(v, what):
+# ---------------------------------------------------------------------------
+# sliding-window layers
+# ---------------------------------------------------------------------------
+def _pair(v, what):
     if isinstance(v, int):
         return (v, v)
     if isinstance(v, (tuple, list)):
         return tuple(v)
-    raise TypeError("Wrong %s type." % what)
+    raise TypeError("%s is an int or a pair, got %r" % (what, v))
 
 
 def _split_padding(padding):
-    """(symmetric (h, w) padding, odd remainder (top, bottom, left, right))."""
-    odd = (0, 0, 0, 0)
-    if isinstance(padding, int):
-        return (padding, padding), odd
-    if isinstance(padding, (tuple, list)):
-        if len(padding) == 2:
-            return tuple(padding), odd
-        if len(padding) == 4:
-            hm = padding[0] - padding[1]
-            wm = padding[2] - padding[3]
-            odd = (max(hm, 0), max(-hm, 0), max(wm, 0), max(-wm, 0))
-            return (padding[0] - odd[0], padding[2] - odd[2]), odd
+    """(symmetric (h, w) padding, odd remainder (top, bottom, left, right)).
+    Accepts None, an int, (h, w) or (top, bottom, left, right)."""
+    none = (0, 0, 0, 0)
     if padding is None:
-        return (0, 0), odd
-    raise TypeError("Wrong padding value.")
+        return (0, 0), none
+    if isinstance(padding, int):
+        return (padding, padding), none
+    if isinstance(padding, (tuple, list)) and len(padding) == 2:
+        return tuple(padding), none
+    if isinstance(padding, (tuple, list)) and len(padding) == 4:
+        top, bottom, left, right = padding
+        odd = (max(top - bottom, 0), max(bottom - top, 0),
+               max(left - right, 0), max(right - left, 0))
+        return (top - odd[0], left - odd[2]), odd
+    raise TypeError("padding is None, an int, a pair or a 4-tuple, got %r" %
+                    (padding,))
 
 
-class Conv2d(Layer):
+class _Windowed(Layer):
+    """Shared geometry of convolution and pooling: ``kernel_size``, ``stride``,
+    symmetric ``padding`` plus ``odd_padding``, and ``pad_mode``."""
+
+    def _set_window(self, kernel_size, stride, padding, pad_mode):
+        self.kernel_size = _pair(kernel_size, "kernel_size")
+        self.stride = self.kernel_size if stride is None \
+            else _pair(stride, "stride")
+        self.padding, self.odd_padding = _split_padding(padding)
+        self.pad_mode = pad_mode
+
+    def _padded_probe(self, x):
+        """Resolve SAME_* padding against ``x`` and return a core tensor with
+        the shape the kernels will see (odd padding applied)."""
+        if self.pad_mode in ("SAME_UPPER", "SAME_LOWER"):
+            pad, self.odd_padding = utils.get_padding_shape(
+                self.pad_mode, x.shape[2:], self.kernel_size, self.stride)
+            self.padding = [pad[0], pad[2]]
+        top, bottom, left, right = self.odd_padding
+        n, c, h, w = x.shape
+        return singa.Tensor([n, c, h + top + bottom, w + left + right],
+                            x.device, x.dtype)
+
+
+class Conv2d(_Windowed):
     """2-d convolution (NCHW).  ``pad_mode`` SAME_UPPER / SAME_LOWER derives
     the padding from the input; ``activation="RELU"`` appends a ReLU."""
 
     def __init__(self, nb_kernels, kernel_size, *args, stride=1, padding=0,
                  dilation=1, group=1, bias=True, pad_mode="NOTSET",
                  activation="NOTSET", **kwargs):
-        super(Conv2d, self).__init__()
-        # legacy signature Conv2d(in_channels, out_channels, kernel[, stride
-        # [, padding]])
-        if len(args) > 0:
-            nb_kernels = kernel_size
-            kernel_size = args[0]
-        if len(args) > 1:
-            stride = args[1]
-        if len(args) > 2:
-            padding = args[2]
-
-        self.nb_kernels = nb_kernels
-        self.kernel_size = _norm_pair(kernel_size, "kernel_size")
-        self.stride = _norm_pair(stride, "stride")
-        self.padding, self.odd_padding = _split_padding(padding)
-        self.dilation = dilation
-        self.group = group
-        self.bias = bias
-        self.pad_mode = pad_mode
-        self.activation = activation
+        super().__init__()
+        if args:
+            # legacy Conv2d(in_channels, out_channels, kernel[, stride[, pad]])
+            nb_kernels, kernel_size = kernel_size, args[0]
+            stride = args[1] if len(args) > 1 else stride
+            padding = args[2] if len(args) > 2 else padding
         if dilation != 1 and list(dilation) != [1, 1]:
-            raise ValueError("Not implemented yet")
-        self.inner_params = {
-            "cudnn_prefer": "fastest",
-            "workspace_MB_limit": 1024,
-        }
-        for kwarg in kwargs:
-            if kwarg not in self.inner_params:
-                raise TypeError("Keyword argument not understood:", kwarg)
-            self.inner_params[kwarg] = kwargs[kwarg]
+            raise ValueError("dilated convolution is not implemented")
+        self._set_window(kernel_size, stride, padding, pad_mode)
+        _keep(self, locals(), 'nb_kernels', 'dilation', 'group', 'bias',
+              'activation')
+        # accepted for source compatibility; the HIP kernels pick their own
+        # algorithm and workspace
+        self.inner_params = {"cudnn_prefer": "fastest",
+                             "workspace_MB_limit": 1024}
+        unknown = set(kwargs) - set(self.inner_params)
+        if unknown:
+            raise TypeError("Keyword argument not understood:",
+                            sorted(unknown)[0])
+        self.inner_params.update(kwargs)
 
     def initialize(self, x):
         self.in_channels = x.shape[1]
-        w_shape = (self.nb_kernels, int(self.in_channels / self.group),
-                   self.kernel_size[0], self.kernel_size[1])
-        self.W = Tensor(shape=w_shape, requires_grad=True, stores_grad=True,
-                        device=x.device)
-        std = math.sqrt(
-            2.0 / (w_shape[1] * self.kernel_size[0] * self.kernel_size[1] +
-                   self.nb_kernels))
-        self.W.gaussian(0.0, std)
+        kh, kw = self.kernel_size
+        per_group = self.in_channels // self.group
+        std = math.sqrt(2.0 / (per_group * kh * kw + self.nb_kernels))
+        self._new_param('W', (self.nb_kernels, per_group, kh, kw), x,
+                        _gaussian(std))
+        self.b = None
         if self.bias:
-            self.b = Tensor(shape=(self.nb_kernels,), requires_grad=True,
-                            stores_grad=True, device=x.device)
-            self.b.set_value(0.0)
-        else:
-            self.b = None
-
-        if self.pad_mode in ("SAME_UPPER", "SAME_LOWER"):
-            pad, self.odd_padding = utils.get_padding_shape(
-                self.pad_mode, x.shape[2:], self.kernel_size, self.stride)
-            self.padding = [pad[0], pad[2]]
-
-        x_shape = list(x.shape)
-        if tuple(self.odd_padding) != (0, 0, 0, 0):
-            x_shape[2] += (self.odd_padding[0] + self.odd_padding[1])
-            x_shape[3] += (self.odd_padding[2] + self.odd_padding[3])
-        probe = singa.Tensor(x_shape, x.device, x.dtype)
+            self._new_param('b', (self.nb_kernels,), x, _constant(0.0))
+        probe = self._padded_probe(x)
         if not hasattr(self, "handle"):
-            self.handle = singa.ConvHandle(probe, self.kernel_size,
-                                           self.stride, self.padding,
-                                           self.in_channels, self.nb_kernels,
-                                           self.bias, self.group)
+            self.handle = singa.ConvHandle(
+                probe, self.kernel_size, self.stride, self.padding,
+                self.in_channels, self.nb_kernels, self.bias, self.group)
 
     def forward(self, x):
-        self.device_check(x, *[s for k, s in self.get_states().items()])
-        self.dtype_check(x, *[s for k, s in self.get_states().items()])
-        assert (self.group >= 1 and self.in_channels % self.group
-                == 0), "please set reasonable group."
-        assert (self.nb_kernels >= self.group and self.nb_kernels % self.group
-                == 0), "nb_kernels and group dismatched."
+        self._align(x, self.W, self.b)
+        assert self.group >= 1 and self.in_channels % self.group == 0, (
+            "%d input channels cannot be split into %d groups" %
+            (self.in_channels, self.group))
+        assert self.nb_kernels >= self.group and \
+            self.nb_kernels % self.group == 0, (
+                "%d kernels cannot be split into %d groups" %
+                (self.nb_kernels, self.group))
         y = autograd.conv2d(self.handle, x, self.W, self.b, self.odd_padding)
-        if self.activation == "RELU":
-            y = autograd.relu(y)
-        return y
-
-    def get_params(self):
-        if self.bias:
-            return {self.W.name: self.W, self.b.name: self.b}
-        return {self.W.name: self.W}
-
-    def set_params(self, parameters):
-        self.W.copy_from(parameters[self.W.name])
-        if self.bias:
-            self.b.copy_from(parameters[self.b.name])
+        return autograd.relu(y) if self.activation == "RELU" else y
 
 
 class SeparableConv2d(Layer):
@@ -465,19 +468,13 @@ class SeparableConv2d(Layer):
 
     def __init__(self, nb_kernels, kernel_size, *args, stride=1, padding=0,
                  bias=False):
-        super(SeparableConv2d, self).__init__()
-        if len(args) > 0:
-            nb_kernels = kernel_size
-            kernel_size = args[0]
-        if len(args) > 1:
-            stride = args[1]
-        if len(args) > 2:
-            padding = args[2]
-        self.nb_kernels = nb_kernels
-        self.kernel_size = kernel_size
-        self.stride = stride
-        self.padding = padding
-        self.bias = bias
+        super().__init__()
+        if args:    # legacy (in_channels, out_channels, kernel[, stride[, pad]])
+            nb_kernels, kernel_size = kernel_size, args[0]
+            stride = args[1] if len(args) > 1 else stride
+            padding = args[2] if len(args) > 2 else padding
+        _keep(self, locals(), 'nb_kernels', 'kernel_size', 'stride', 'padding',
+              'bias')
 
     def initialize(self, x):
         self.in_channels = x.shape[1]
@@ -487,167 +484,113 @@ class SeparableConv2d(Layer):
         self.point_conv = Conv2d(self.nb_kernels, 1, bias=self.bias)
 
     def forward(self, x):
-        y = self.depthwise_conv(x)
-        y = self.point_conv(y)
-        return y
+        return self.point_conv(self.depthwise_conv(x))
 
 
 class BatchNorm2d(Layer):
     """Batch normalisation over (N, H, W) per channel.  ``momentum`` is the
     weight of the batch statistics in the running average (see
-    ``singa_wrap.BatchNormHandle``)."""
+    ``singa_wrap.BatchNormHandle``).  Statistics and affine parameters stay
+    in float32 for 16-bit inputs.
+
+    ``activation="RELU"`` computes relu(bn(x)) -- and, when the layer is
+    called with a second tensor, relu(bn(x) + residual) -- inside the
+    normalisation kernel instead of as separate graph nodes."""
 
     def __init__(self, *args, momentum=0.9, activation=None):
-        """``activation="RELU"`` computes relu(bn(x)) -- and, when the layer
-        is called with a second tensor, relu(bn(x) + residual) -- inside the
-        normalisation kernel instead of as separate graph nodes."""
-        super(BatchNorm2d, self).__init__()
-        if len(args) > 0:
+        super().__init__()
+        if args:                         # legacy (channels[, momentum])
             self.channels = args[0]
-        if len(args) > 1:
-            momentum = args[1]
-        self.momentum = momentum
-        assert 0 <= momentum <= 1.0, ("Illegal momentum")
+            momentum = args[1] if len(args) > 1 else momentum
+        assert 0 <= momentum <= 1.0, "momentum %r outside [0, 1]" % momentum
         assert activation in (None, "RELU"), "only RELU can be fused"
-        self.activation = activation
+        _keep(self, locals(), 'momentum', 'activation')
 
     def initialize(self, x, residual=None):
-        self.channels = x.shape[1]
-        param_shape = (self.channels,)
-        self.scale = Tensor(shape=param_shape, requires_grad=True,
-                            stores_grad=True, device=x.device)
-        self.scale.set_value(1.0)
-        self.bias = Tensor(shape=param_shape, requires_grad=True,
-                           stores_grad=True, device=x.device)
-        self.bias.set_value(0.0)
-        self.running_mean = Tensor(shape=param_shape, requires_grad=False,
-                                   stores_grad=False, device=x.device)
-        self.running_mean.set_value(0.0)
-        self.running_var = Tensor(shape=param_shape, requires_grad=False,
-                                  stores_grad=False, device=x.device)
-        self.running_var.set_value(1.0)
+        self.channels = c = x.shape[1]
+        self._new_param('scale', (c,), x, _constant(1.0))
+        self._new_param('bias', (c,), x, _constant(0.0))
+        self._new_state('running_mean', (c,), x, _constant(0.0))
+        self._new_state('running_var', (c,), x, _constant(1.0))
         if not hasattr(self, "handle"):
             self.handle = singa.BatchNormHandle(self.momentum, x.data)
 
     def forward(self, x, residual=None):
         assert x.shape[1] == self.channels, (
-            "number of channels dismatched. %d vs %d" %
-            (x.shape[1], self.channels))
-        self.device_check(x, self.scale, self.bias, self.running_mean,
-                          self.running_var)
-        # statistics and affine parameters stay in float32 for half inputs
+            "built for %d channels, input has %d" % (self.channels,
+                                                     x.shape[1]))
+        own = (self.scale, self.bias, self.running_mean, self.running_var)
+        self.device_check(x, *own)
         if residual is not None:
             assert self.activation == "RELU", \
                 "a residual input needs activation='RELU'"
-            return autograd.batchnorm_add_relu_2d(
-                self.handle, x, self.scale, self.bias, self.running_mean,
-                self.running_var, residual)
-        if self.activation == "RELU":
-            return autograd.batchnorm_relu_2d(
-                self.handle, x, self.scale, self.bias, self.running_mean,
-                self.running_var)
-        return autograd.batchnorm_2d(self.handle, x, self.scale, self.bias,
-                                     self.running_mean, self.running_var)
-
-    def get_params(self):
-        return {self.scale.name: self.scale, self.bias.name: self.bias}
-
-    def set_params(self, parameters):
-        self.scale.copy_from(parameters[self.scale.name])
-        self.bias.copy_from(parameters[self.bias.name])
-
-    def get_states(self):
-        ret = self.get_params()
-        ret[self.running_mean.name] = self.running_mean
-        ret[self.running_var.name] = self.running_var
-        return ret
-
-    def set_states(self, states):
-        self.set_params(states)
-        self.running_mean.copy_from(states[self.running_mean.name])
-        self.running_var.copy_from(states[self.running_var.name])
+            return autograd.batchnorm_add_relu_2d(self.handle, x, *own,
+                                                  residual)
+        op = autograd.batchnorm_relu_2d if self.activation == "RELU" \
+            else autograd.batchnorm_2d
+        return op(self.handle, x, *own)
 
 
-class Pooling2d(Layer):
+class Pooling2d(_Windowed):
+    """Max / average pooling over (N, C, H, W); (N, C, L) inputs of the 1-d
+    variants are pooled as (N, C, 1, L)."""
 
     def __init__(self, kernel_size, stride=None, padding=0, is_max=True,
                  pad_mode="NOTSET"):
-        super(Pooling2d, self).__init__()
-        self.kernel_size = _norm_pair(kernel_size, "kernel_size")
-        if stride is None:
-            self.stride = self.kernel_size
-        else:
-            self.stride = _norm_pair(stride, "stride")
-        self.padding, self.odd_padding = _split_padding(padding)
+        super().__init__()
+        self._set_window(kernel_size, stride, padding, pad_mode)
         self.is_max = is_max
-        self.pad_mode = pad_mode
 
     @staticmethod
     def _as_4d(x):
-        """(N, C, L) inputs of the 1-d poolings are pooled as (N, C, 1, L)."""
-        if len(x.shape) == 3:
-            return autograd.reshape(x, (x.shape[0], x.shape[1], 1, x.shape[2]))
-        return x
+        if len(x.shape) != 3:
+            return x
+        n, c, length = x.shape
+        return autograd.reshape(x, (n, c, 1, length))
 
     def initialize(self, x):
-        x = self._as_4d(x)
-        if self.pad_mode in ("SAME_UPPER", "SAME_LOWER"):
-            pad, self.odd_padding = utils.get_padding_shape(
-                self.pad_mode, x.shape[2:], self.kernel_size, self.stride)
-            self.padding = [pad[0], pad[2]]
-        x_shape = list(x.shape)
-        if tuple(self.odd_padding) != (0, 0, 0, 0):
-            x_shape[2] += (self.odd_padding[0] + self.odd_padding[1])
-            x_shape[3] += (self.odd_padding[2] + self.odd_padding[3])
-        probe = singa.Tensor(x_shape, x.device, x.dtype)
+        probe = self._padded_probe(self._as_4d(x))
         self.handle = singa.PoolingHandle(probe, self.kernel_size, self.stride,
                                           self.padding, self.is_max)
 
     def forward(self, x):
+        y = autograd.pooling_2d(self.handle, self._as_4d(x), self.odd_padding)
         if len(x.shape) == 3:
-            y = autograd.pooling_2d(self.handle, self._as_4d(x),
-                                    self.odd_padding)
-            return autograd.reshape(y, (y.shape[0], y.shape[1], y.shape[3]))
-        return autograd.pooling_2d(self.handle, x, self.odd_padding)
+            y = autograd.reshape(y, (y.shape[0], y.shape[1], y.shape[3]))
+        return y
 
 
-class MaxPool2d(Pooling2d):
-
+def _pooling_variant(name, is_max, one_d):
     def __init__(self, kernel_size, stride=None, padding=0, pad_mode="NOTSET"):
-        super(MaxPool2d, self).__init__(kernel_size, stride, padding, True,
-                                        pad_mode)
+        if one_d:
+            stride = kernel_size if stride is None else stride
+            kernel_size, stride, padding = (1, kernel_size), (1, stride), \
+                (0, padding)
+        Pooling2d.__init__(self, kernel_size, stride, padding, is_max,
+                           pad_mode)
+    return LayerMeta(name, (Pooling2d,),
+                     {'__init__': __init__, '__module__': __name__})
 
 
-class AvgPool2d(Pooling2d):
-
-    def __init__(self, kernel_size, stride=None, padding=0, pad_mode="NOTSET"):
-        super(AvgPool2d, self).__init__(kernel_size, stride, padding, False,
-                                        pad_mode)
-
-
-class MaxPool1d(Pooling2d):
-
-    def __init__(self, kernel_size, stride=None, padding=0, pad_mode="NOTSET"):
-        if stride is None:
-            stride = kernel_size
-        super(MaxPool1d, self).__init__((1, kernel_size), (1, stride),
-                                        (0, padding), True, pad_mode)
+MaxPool2d = _pooling_variant('MaxPool2d', True, False)
+AvgPool2d = _pooling_variant('AvgPool2d', False, False)
+MaxPool1d = _pooling_variant('MaxPool1d', True, True)
+AvgPool1d = _pooling_variant('AvgPool1d', False, True)
 
 
-class AvgPool1d(Pooling2d):
-
-    def __init__(self, kernel_size, stride=None, padding=0, pad_mode="NOTSET"):
-        if stride is None:
-            stride = kernel_size
-        super(AvgPool1d, self).__init__((1, kernel_size), (1, stride),
-                                        (0, padding), False, pad_mode)
-
-
+# ---------------------------------------------------------------------------
+# recurrent layers
+# ---------------------------------------------------------------------------
 class RNN_Base(Layer):
 
     def step_forward(self, x=None, h=None, c=None, Wx=None, Wh=None, Bx=None,
                      Bh=None, b=None):
         raise NotImplementedError
+
+    def _remember(self, values):
+        _keep(self, values, 'input_size', 'hidden_size', 'num_layers',
+              'nonlinearity', 'bias', 'batch_first', 'dropout',
+              'bidirectional')
 
 
 class RNN(RNN_Base):
@@ -656,64 +599,35 @@ class RNN(RNN_Base):
     def __init__(self, input_size, hidden_size, num_layers=1,
                  nonlinearity="tanh", bias=True, batch_first=False, dropout=0,
                  bidirectional=False):
-        super(RNN, self).__init__()
-        self.input_size = input_size
-        self.hidden_size = hidden_size
-        self.num_layers = num_layers
-        self.nonlinearity = nonlinearity
-        self.bias = bias
-        self.batch_first = batch_first
-        self.dropout = dropout
-        self.bidirectional = bidirectional
+        super().__init__()
+        self._remember(locals())
 
     def initialize(self, xs, h0):
-        self.Wx = Tensor(shape=(self.input_size, self.hidden_size),
-                         requires_grad=True, stores_grad=True, device=xs[0].device)
-        self.Wx.gaussian(0.0, 1.0)
-        self.Wh = Tensor(shape=(self.hidden_size, self.hidden_size),
-                         requires_grad=True, stores_grad=True, device=xs[0].device)
-        self.Wh.gaussian(0.0, 1.0)
-        self.b = Tensor(shape=(self.hidden_size,), requires_grad=True,
-                        stores_grad=True, device=xs[0].device)
-        self.b.set_value(0.0)
+        x, n, d = xs[0], self.hidden_size, self.input_size
+        self._new_param('Wx', (d, n), x, _gaussian(1.0))
+        self._new_param('Wh', (n, n), x, _gaussian(1.0))
+        self._new_param('b', (n,), x, _constant(0.0))
 
     def forward(self, xs, h0):
-        if not isinstance(xs, tuple):
-            xs = tuple(xs)
-        inputs = xs + (h0,)
-        self.device_check(*inputs)
-        self.device_check(inputs[0], self.Wx, self.Wh, self.b)
-        batchsize = xs[0].shape[0]
-        out = []
-        h = self.step_forward(xs[0], h0, self.Wx, self.Wh, self.b)
-        out.append(h)
-        for x in xs[1:]:
-            assert x.shape[0] == batchsize
+        xs = tuple(xs)
+        self.device_check(*xs, h0)
+        self.device_check(xs[0], self.Wx, self.Wh, self.b)
+        h, out = h0, []
+        for x in xs:
+            assert x.shape[0] == xs[0].shape[0], "batch size changed mid-sequence"
             h = self.step_forward(x, h, self.Wx, self.Wh, self.b)
             out.append(h)
         return out, h
 
     def step_forward(self, x, h, Wx, Wh, b):
-        y2 = autograd.matmul(h, Wh)
-        y1 = autograd.matmul(x, Wx)
-        y = autograd.add(y2, y1)
-        y = autograd.add_bias(y, b, axis=0)
-        if self.nonlinearity == "tanh":
-            y = autograd.tanh(y)
-        elif self.nonlinearity == "relu":
-            y = autograd.relu(y)
-        else:
-            raise ValueError
-        return y
-
-    def get_params(self):
-        return {self.Wx.name: self.Wx, self.Wh.name: self.Wh,
-                self.b.name: self.b}
-
-    def set_params(self, parameters):
-        self.Wx.copy_from(parameters[self.Wx.name])
-        self.Wh.copy_from(parameters[self.Wh.name])
-        self.b.copy_from(parameters[self.b.name])
+        try:
+            act = {"tanh": autograd.tanh, "relu": autograd.relu}[
+                self.nonlinearity]
+        except KeyError:
+            raise ValueError("nonlinearity is 'tanh' or 'relu', got %r" %
+                             (self.nonlinearity,)) from None
+        pre = autograd.add(autograd.matmul(h, Wh), autograd.matmul(x, Wx))
+        return act(autograd.add_bias(pre, b, axis=0))
 
 
 class LSTM(RNN_Base):
@@ -727,224 +641,56 @@ class LSTM(RNN_Base):
     def __init__(self, input_size, hidden_size, nonlinearity="tanh",
                  num_layers=1, bias=True, batch_first=False, dropout=0,
                  bidirectional=False):
-        super(LSTM, self).__init__()
-        self.input_size = input_size
-        self.hidden_size = hidden_size
-        self.num_layers = num_layers
-        self.nonlinearity = nonlinearity
-        self.bias = bias
-        self.batch_first = batch_first
-        self.dropout = dropout
-        self.bidirectional = bidirectional
+        super().__init__()
+        self._remember(locals())
 
-    def _all(self):
-        ws = [getattr(self, "Wx_" + g) for g in self._gates] + \
-             [getattr(self, "Wh_" + g) for g in self._gates]
-        bs = [getattr(self, "Bx_" + g) for g in self._gates] + \
-             [getattr(self, "Bh_" + g) for g in self._gates]
-        return ws, bs
+    def _family(self, prefix):
+        return [getattr(self, prefix + g) for g in self._gates]
 
     def initialize(self, xs, h0_c0):
-        for g in self._gates:
-            setattr(self, "Wx_" + g,
-                    Tensor(shape=(self.input_size, self.hidden_size),
-                           requires_grad=True, stores_grad=True, device=xs[0].device))
-        for g in self._gates:
-            setattr(self, "Wh_" + g,
-                    Tensor(shape=(self.hidden_size, self.hidden_size),
-                           requires_grad=True, stores_grad=True, device=xs[0].device))
-        for g in self._gates:
-            setattr(self, "Bx_" + g, Tensor(shape=(self.hidden_size,),
-                                            requires_grad=True,
-                                            stores_grad=True, device=xs[0].device))
-        for g in self._gates:
-            setattr(self, "Bh_" + g, Tensor(shape=(self.hidden_size,),
-                                            requires_grad=True,
-                                            stores_grad=True, device=xs[0].device))
-        ws, bs = self._all()
-        for w in ws:
-            w.gaussian(0.0, 0.01)
-        for b in bs:
-            b.set_value(0.0)
+        x, n, d = xs[0], self.hidden_size, self.input_size
+        for prefix, shape, fill in (("Wx_", (d, n), _gaussian(0.01)),
+                                    ("Wh_", (n, n), _gaussian(0.01)),
+                                    ("Bx_", (n,), _constant(0.0)),
+                                    ("Bh_", (n,), _constant(0.0))):
+            for g in self._gates:
+                self._new_param(prefix + g, shape, x, fill)
 
     def forward(self, xs, h0_c0):
-        h0, c0 = h0_c0
-        if not isinstance(xs, list):
-            xs = list(xs)
-        inputs = xs + [h0, c0]
-        self.device_check(*inputs)
-        self.device_check(inputs[0], *[s for k, s in self.get_states().items()])
-        batchsize = xs[0].shape[0]
+        h, c = h0_c0
+        xs = list(xs)
+        self.device_check(*xs, h, c)
+        self.device_check(xs[0], *self._own('param'))
         # gate-concatenated views of the parameters, built once per call
-        Wx = autograd.cat([getattr(self, "Wx_" + g) for g in self._gates], 1)
-        Wh = autograd.cat([getattr(self, "Wh_" + g) for g in self._gates], 1)
-        Bx = autograd.cat([getattr(self, "Bx_" + g) for g in self._gates], 0)
-        Bh = autograd.cat([getattr(self, "Bh_" + g) for g in self._gates], 0)
-        B = autograd.add(Bx, Bh)
+        Wx = autograd.cat(self._family("Wx_"), 1)
+        Wh = autograd.cat(self._family("Wh_"), 1)
+        B = autograd.add(autograd.cat(self._family("Bx_"), 0),
+                         autograd.cat(self._family("Bh_"), 0))
         out = []
-        h, c = h0, c0
         for x in xs:
-            assert x.shape[0] == batchsize
+            assert x.shape[0] == xs[0].shape[0], "batch size changed mid-sequence"
             h, c = self._fused_step(x, h, c, Wx, Wh, B)
             out.append(h)
         return out, h, c
 
     def _fused_step(self, x, h, c, Wx, Wh, B):
         gates = autograd.add(autograd.matmul(x, Wx), autograd.matmul(h, Wh))
-        gates = autograd.add_bias(gates, B, axis=0)
-        return rnn_cells.lstm_cell(gates, c)
+        return rnn_cells.lstm_cell(autograd.add_bias(gates, B, axis=0), c)
 
     def step_forward(self, x, h, c):
         """One LSTM step from the un-concatenated parameters."""
-        def gate(g):
-            y1 = autograd.add_bias(
+        def pre(g):
+            from_x = autograd.add_bias(
                 autograd.matmul(x, getattr(self, "Wx_" + g)),
                 getattr(self, "Bx_" + g), axis=0)
-            y2 = autograd.add_bias(
+            from_h = autograd.add_bias(
                 autograd.matmul(h, getattr(self, "Wh_" + g)),
                 getattr(self, "Bh_" + g), axis=0)
-            return autograd.add(y1, y2)
-        i = autograd.sigmoid(gate("i"))
-        f = autograd.sigmoid(gate("f"))
-        o = autograd.sigmoid(gate("o"))
-        g = autograd.tanh(gate("g"))
-        cout = autograd.add(autograd.mul(f, c), autograd.mul(i, g))
-        hout = autograd.mul(o, autograd.tanh(cout))
-        return hout, cout
-
-    def get_params(self):
-        ws, bs = self._all()
-        return {t.name: t for t in ws + bs}
-
-    def set_params(self, parameters):
-        ws, bs = self._all()
-        for t in ws + bs:
-            t.copy_from(parameters[t.name])
-
-
-# ---- layers without parameters --------------------------------------------
-class LayerNorm(Layer):
-    """Normalisation over the last dimension with a learned scale and bias
-    (an addition over the reference's layer set; one fused kernel per
-    direction)."""
-
-    def __init__(self, eps=1e-5):
-        super(LayerNorm, self).__init__()
-        self.eps = eps
-
-    def initialize(self, x):
-        d = x.shape[-1]
-        self.scale = Tensor(shape=(d,), requires_grad=True, stores_grad=True,
-                            device=x.device, dtype=x.dtype)
-        self.scale.set_value(1.0)
-        self.bias = Tensor(shape=(d,), requires_grad=True, stores_grad=True,
-                           device=x.device, dtype=x.dtype)
-        self.bias.set_value(0.0)
-
-    def forward(self, x):
-        self.device_check(x, self.scale, self.bias)
-        return autograd.layer_norm(x, self.scale, self.bias, self.eps)
-
-    def get_params(self):
-        return {self.scale.name: self.scale, self.bias.name: self.bias}
-
-    def set_params(self, parameters):
-        self.scale.copy_from(parameters[self.scale.name])
-        self.bias.copy_from(parameters[self.bias.name])
-
-
-class Gelu(Layer):
-
-    def forward(self, x):
-        return autograd.gelu(x)
-
-
-class ReLU(Layer):
-
-    def forward(self, x):
-        return autograd.relu(x)
-
-
-class Sigmoid(Layer):
-
-    def forward(self, x):
-        return autograd.sigmoid(x)
-
-
-class Add(Layer):
-
-    def forward(self, a, b):
-        return autograd.add(a, b)
-
-
-class Flatten(Layer):
-
-    def __init__(self, axis=1):
-        super(Flatten, self).__init__()
-        self.axis = axis
-
-    def forward(self, x):
-        return autograd.flatten(x, self.axis)
-
-
-class SoftMaxCrossEntropy(Layer):
-
-    def forward(self, x, t):
-        return autograd.softmax_cross_entropy(x, t)
-
-
-class SoftMax(Layer):
-
-    def forward(self, x):
-        return autograd.softmax(x)
-
-
-class MeanSquareError(Layer):
-
-    def forward(self, x, t):
-        return autograd.mse_loss(x, t)
-
-
-class CrossEntropy(Layer):
-
-    def forward(self, x, t):
-        return autograd.cross_entropy(x, t)
-
-
-class BinaryCrossEntropy(Layer):
-
-    def forward(self, x, t):
-        return autograd.binary_cross_entropy(x, t)
-
-
-class Dropout(Layer):
-    """Like the reference, ``ratio`` is passed positionally into
-    ``autograd.dropout(x, seed, ratio)`` and therefore lands in ``seed``; the
-    effective drop ratio is the operator's default 0.5 (reference
-    python/singa/layer.py:1522)."""
-
-    def __init__(self, ratio=0.5):
-        super(Dropout, self).__init__()
-        self.ratio = ratio
-
-    def forward(self, x):
-        return autograd.dropout(x, self.ratio)
-
-
-class Cat(Layer):
-
-    def __init__(self, axis=0):
-        super(Cat, self).__init__()
-        self.axis = axis
-
-    def forward(self, xs):
-        return autograd.cat(xs, self.axis)
-
-
-class Reshape(Layer):
-
-    def forward(self, x, shape):
-        return autograd.reshape(x, shape)
+            return autograd.add(from_x, from_h)
+        i, f, o = (autograd.sigmoid(pre(g)) for g in "ifo")
+        cand = autograd.tanh(pre("g"))
+        c_next = autograd.add(autograd.mul(f, c), autograd.mul(i, cand))
+        return autograd.mul(o, autograd.tanh(c_next)), c_next
 
 
 class CudnnRNN(Layer):
@@ -952,71 +698,126 @@ class CudnnRNN(Layer):
     flat weight tensor, run by fused recurrent HIP kernels on the GPU and by
     the same algorithm on the host."""
 
+    # mode codes of the recurrent kernels
+    _modes = {"relu": 0, "vanilla": 1, "tanh": 1, "lstm": 2, "gru": 3}
+
     def __init__(self, hidden_size, activation="tanh", num_layers=1, bias=True,
                  batch_first=True, dropout=0, bidirectional=False,
                  rnn_mode="lstm", use_mask=False, return_sequences=True):
-        assert num_layers > 0, "num layers should be > 0"
-        assert 0 <= dropout < 1, "dropout shouldbe >=0 and <1"
-        super(CudnnRNN, self).__init__()
-        self.rnn_mode = rnn_mode
-        self.hidden_size = hidden_size
-        self.num_layers = num_layers
-        self.dropout = dropout
-        self.bidirectional = 1 if bidirectional else 0
-        self.return_sequences = return_sequences
-        self.batch_first = batch_first
-        self.use_mask = use_mask
-        # mode codes: 0 relu rnn, 1 tanh rnn, 2 lstm, 3 gru
-        self.cudnn_rnn_mode = {"lstm": 2, "vanilla": 1, "tanh": 1, "relu": 0,
-                               "gru": 3}[self.rnn_mode]
+        assert num_layers > 0, "num_layers must be positive"
+        assert 0 <= dropout < 1, "dropout must lie in [0, 1)"
+        super().__init__()
+        _keep(self, locals(), 'rnn_mode', 'hidden_size', 'num_layers',
+              'dropout', 'return_sequences', 'batch_first', 'use_mask')
+        self.bidirectional = int(bool(bidirectional))
+        self.cudnn_rnn_mode = self._modes[rnn_mode]
 
     def initialize(self, x, hx=None, cx=None, seq_lengths=None):
         if self.batch_first:
             x = x.transpose((1, 0, 2))
         self.input_size = x.shape[1]
-        self.handle = singa.CudnnRNNHandle(x.data, self.hidden_size,
-                                           mode=self.cudnn_rnn_mode,
-                                           num_layers=self.num_layers,
-                                           dropout=self.dropout,
-                                           bidirectional=self.bidirectional)
-        self.W = Tensor(shape=(self.handle.weights_size,), requires_grad=True,
-                        stores_grad=True, device=x.device)
-        k = 1 / self.hidden_size
-        self.W.uniform(-math.sqrt(k), math.sqrt(k))
+        self.handle = singa.CudnnRNNHandle(
+            x.data, self.hidden_size, mode=self.cudnn_rnn_mode,
+            num_layers=self.num_layers, dropout=self.dropout,
+            bidirectional=self.bidirectional)
+        bound = math.sqrt(1 / self.hidden_size)
+        self._new_param('W', (self.handle.weights_size,), x,
+                        lambda t: t.uniform(-bound, bound))
+
+    def _zero_state(self, x):
+        shape = (self.num_layers * (1 + self.bidirectional), x.shape[1],
+                 self.hidden_size)
+        return Tensor(shape=shape, requires_grad=False, stores_grad=False,
+                      device=x.device).set_value(0.0)
 
     def forward(self, x, hx=None, cx=None, seq_lengths=None):
         self.device_check(x, self.W)
         if self.batch_first:
             x = autograd.transpose(x, (1, 0, 2))
-        batch_size = x.shape[1]
-        directions = 2 if self.bidirectional else 1
-        state_shape = (self.num_layers * directions, batch_size,
-                       self.hidden_size)
-        if hx is None:
-            hx = Tensor(shape=state_shape, requires_grad=False,
-                        stores_grad=False, device=x.device).set_value(0.0)
-        if cx is None:
-            cx = Tensor(shape=state_shape, requires_grad=False,
-                        stores_grad=False, device=x.device).set_value(0.0)
+        hx = self._zero_state(x) if hx is None else hx
+        cx = self._zero_state(x) if cx is None else cx
+        options = dict(return_sequences=self.return_sequences)
         if self.use_mask:
-            assert type(seq_lengths) == Tensor, "wrong type for seq_lengths"
-            y = autograd._RNN(self.handle,
-                              return_sequences=self.return_sequences,
-                              use_mask=self.use_mask,
-                              seq_lengths=seq_lengths)(x, hx, cx, self.W)[0]
-        else:
-            y = autograd._RNN(self.handle,
-                              return_sequences=self.return_sequences)(
-                                  x, hx, cx, self.W)[0]
+            assert type(seq_lengths) == Tensor, \
+                "use_mask needs seq_lengths as a Tensor"
+            options.update(use_mask=True, seq_lengths=seq_lengths)
+        y = autograd._RNN(self.handle, **options)(x, hx, cx, self.W)[0]
         if self.return_sequences and self.batch_first:
             y = autograd.transpose(y, (1, 0, 2))
         return y
 
-    def get_params(self):
-        return {self.W.name: self.W}
-
     def set_params(self, parameters):
         self.set_attribute(self.W, parameters[self.W.name])
+
+
+# ---------------------------------------------------------------------------
+# normalisation over the feature axis (an addition over the reference's set)
+# ---------------------------------------------------------------------------
+class LayerNorm(Layer):
+    """Normalisation over the last dimension with a learned scale and bias;
+    one fused kernel per direction."""
+
+    def __init__(self, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+
+    def initialize(self, x):
+        d = x.shape[-1]
+        self._new_param('scale', (d,), x, _constant(1.0), x.dtype)
+        self._new_param('bias', (d,), x, _constant(0.0), x.dtype)
+
+    def forward(self, x):
+        self.device_check(x, self.scale, self.bias)
+        return autograd.layer_norm(x, self.scale, self.bias, self.eps)
+
+
+# ---------------------------------------------------------------------------
+# layers that only forward to an autograd function
+# ---------------------------------------------------------------------------
+def _functional(name, function, doc=None, **defaults):
+    """A parameterless layer class calling ``autograd.<function>`` with its
+    inputs followed by the values of its constructor options (``defaults``
+    gives their names, order and default values)."""
+    options = list(defaults)
+
+    def __init__(self, *args, **kwargs):
+        Layer.__init__(self)
+        given = dict(zip(options, args))
+        given.update(kwargs)
+        unknown = set(given) - set(options)
+        if unknown or len(args) > len(options):
+            raise TypeError("%s() got unexpected arguments" % name)
+        for key in options:
+            setattr(self, key, given.get(key, defaults[key]))
+
+    def forward(self, *inputs):
+        extra = [getattr(self, key) for key in options]
+        return getattr(autograd, function)(*inputs, *extra)
+
+    return LayerMeta(name, (Layer,), {
+        '__init__': __init__, 'forward': forward, '__doc__': doc,
+        '__module__': __name__})
+
+
+ReLU = _functional('ReLU', 'relu')
+Gelu = _functional('Gelu', 'gelu')
+Sigmoid = _functional('Sigmoid', 'sigmoid')
+SoftMax = _functional('SoftMax', 'softmax')
+Add = _functional('Add', 'add')
+Reshape = _functional('Reshape', 'reshape', "forward(x, shape)")
+Flatten = _functional('Flatten', 'flatten', axis=1)
+Cat = _functional('Cat', 'cat', "forward(list of tensors)", axis=0)
+SoftMaxCrossEntropy = _functional('SoftMaxCrossEntropy',
+                                  'softmax_cross_entropy')
+MeanSquareError = _functional('MeanSquareError', 'mse_loss')
+CrossEntropy = _functional('CrossEntropy', 'cross_entropy')
+BinaryCrossEntropy = _functional('BinaryCrossEntropy', 'binary_cross_entropy')
+Dropout = _functional(
+    'Dropout', 'dropout',
+    """Like the reference, ``ratio`` is passed positionally into
+    ``autograd.dropout(x, seed, ratio)`` and therefore lands in ``seed``; the
+    effective drop ratio is the operator's default 0.5 (reference
+    python/singa/layer.py:1522).""", ratio=0.5)
 
 
 # imported last: autograd imports tensor which must not import layer

@@ -2,15 +2,24 @@
 (``requires_grad``, ``stores_grad``, ``creator``, ``name``), numpy interop and
 the module-level math functions.
 
-API parity: reference python/singa/tensor.py (class Tensor :73-779, module
-functions :789-1841).  Behavioural notes kept from the reference: ``from_numpy``
-narrows float64 -> float32 and int64 -> int32; ``sum`` with an axis returns a
-tensor with that axis removed; ``PlaceHolder`` is an alias of ``Tensor``.
-"""
-import re
-from functools import reduce
+The arithmetic / comparison operators, the in-place operators and the unary
+math functions are generated from tables that pair each name with its core
+kernel entry points.  ``tensordot`` and ``einsum`` both lower to ONE (batched)
+matrix product: einsum classifies every label as batch / contracted / free,
+pre-reduces labels that appear in a single operand only, and lets the GEMM do
+the contraction, instead of materialising the broadcast product and summing
+it axis by axis.
 
+API parity: reference python/singa/tensor.py (class Tensor :73-779, module
+functions :789-1841).  Behavioural notes kept from the reference:
+``from_numpy`` narrows float64 -> float32 and int64 -> int32; ``sum`` with an
+axis returns a tensor with that axis removed; ``PlaceHolder`` is an alias of
+``Tensor``.
+"""
 import itertools
+import math
+import operator
+import re
 
 import numpy as np
 
@@ -22,13 +31,76 @@ float16 = singa.kFloat16
 float32 = singa.kFloat32
 bfloat16 = singa.kBFloat16
 CTensor = singa.Tensor
+
+# numpy element type -> tensor dtype (64-bit types are narrowed)
 _NP2DTYPE = {np.float32: float32, np.float64: float32, np.float16: float16,
              np.int32: int32, np.int64: int32}
+_DTYPE_ALIASES = {'int': singa.kInt, 'float': singa.kFloat32}
+_DTYPE_CODES = (singa.kInt, singa.kFloat16, singa.kFloat32, singa.kBFloat16,
+                singa.kDouble)
+
+
+def _axis_range(key, extent):
+    """[start, stop) selected on an axis of ``extent`` elements by an integer
+    or a unit-step slice."""
+    if isinstance(key, (int, np.integer)) and not isinstance(key, bool):
+        lo = int(key) + (extent if key < 0 else 0)
+        hi = lo + 1
+    elif isinstance(key, slice):
+        lo = key.start or 0
+        hi = key.stop or extent
+        lo += extent if lo < 0 else 0
+        hi += extent if hi < 0 else 0
+    else:
+        raise ValueError("an index is an integer or a unit-step slice, "
+                         "got %r" % (key,))
+    if not 0 <= lo < hi <= extent:
+        raise ValueError("index %r outside an axis of %d" % (key, extent))
+    return lo, hi
 
 
 class Tensor(object):
     tensor_count = 0
     _serial = itertools.count(1)
+    dtype_name = {float16: "float16", float32: "float32", int32: "int32",
+                  bfloat16: "bfloat16"}
+
+    def __init__(self, shape=(), device=None, dtype=None, data=None,
+                 requires_grad=True, stores_grad=False, creator=None,
+                 name=None):
+        device = device if device is not None else get_default_device()
+        from_array = isinstance(data, np.ndarray)
+        if dtype is None:
+            # a numpy array brings its own element type
+            dtype = _NP2DTYPE.get(data.dtype.type, float32) if from_array \
+                else float32
+        if from_array:
+            core = CTensor(list(data.shape), device, dtype)
+            copy_from_numpy(core, data)
+        elif isinstance(data, CTensor):
+            assert data.device().id() == device.id(), 'not the same device'
+            core = data
+        else:
+            core = CTensor(list(shape), device, dtype)
+        self._adopt(core, device, requires_grad, stores_grad, creator, name)
+
+    def _adopt(self, core, device=None, requires_grad=True, stores_grad=False,
+               creator=None, name=None):
+        """Bind this object to a core tensor and start its autograd record."""
+        self.data = core
+        self.shape = tuple(core.shape())
+        self.device = device if device is not None else core.device()
+        self.dtype = core.data_type()
+        self.requires_grad, self.stores_grad = requires_grad, stores_grad
+        self.name = name
+        if name is None:
+            self.name = 'Dummy#%d' % Tensor.tensor_count
+            Tensor.tensor_count += 1
+        if creator is None:
+            from . import autograd
+            creator = autograd.Dummy(self, name)
+        self.creator = creator
+        return self
 
     @property
     def uid(self):
@@ -41,133 +113,89 @@ class Tensor(object):
             u = self.__dict__["_uid"] = next(Tensor._serial)
         return u
 
-    def __init__(self, shape=(), device=None, dtype=None, data=None,
-                 requires_grad=True, stores_grad=False, creator=None,
-                 name=None):
-        if device is None:
-            device = get_default_device()
-        if dtype is None:
-            # a numpy array brings its own element type (float64 / int64 are
-            # narrowed to the 32-bit types the kernels support)
-            dtype = float32
-            if isinstance(data, np.ndarray):
-                dtype = _NP2DTYPE.get(data.dtype.type, float32)
-        if isinstance(data, np.ndarray):
-            self.data = CTensor(list(data.shape), device, dtype)
-            copy_from_numpy(self.data, data)
-        elif isinstance(data, CTensor):
-            self.data = data
-            assert data.device().id() == device.id(), 'not the same device'
-        else:
-            self.data = CTensor(list(shape), device, dtype)
-
-        self.shape = tuple(self.data.shape())
-        self.device = device
-        self.dtype = self.data.data_type()
-        self.requires_grad = requires_grad
-        self.stores_grad = stores_grad
-        if name is None:
-            self.name = 'Dummy#{}'.format(Tensor.tensor_count)
-            Tensor.tensor_count += 1
-        else:
-            self.name = name
-        if creator is None:
-            from . import autograd
-            self.creator = autograd.Dummy(self, name)
-        else:
-            self.creator = creator
-
+    # ---- indexing ------------------------------------------------------------------
     def __getitem__(self, keys):
-        if type(keys) != tuple:
-            keys = (keys,)
-        ret = self.clone()
-        axis_index = 0
-        for key in keys:
-            if type(key) == int:
-                key += self.shape[axis_index] if key < 0 else 0
-                if not (0 <= key < self.shape[axis_index]):
-                    raise ValueError("Invalid Index")
-                ret.data = singa.SliceOn(ret.data, key, key + 1, axis_index)
-            elif type(key) == slice:
-                start = key.start if key.start else 0
-                end = key.stop if key.stop else self.shape[axis_index]
-                start += self.shape[axis_index] if start < 0 else 0
-                end += self.shape[axis_index] if end < 0 else 0
-                if not (0 <= start < end <= self.shape[axis_index]):
-                    raise ValueError("Invalid Index")
-                ret.data = singa.SliceOn(ret.data, start, end, axis_index)
-            else:
-                raise ValueError("Invalid Index")
-            axis_index += 1
-        ret.shape = tuple(ret.data.shape())
-        return ret
+        keys = keys if isinstance(keys, tuple) else (keys,)
+        core = None
+        for axis, key in enumerate(keys):
+            lo, hi = _axis_range(key, self.shape[axis])
+            if (lo, hi) != (0, self.shape[axis]) or core is None:
+                core = singa.SliceOn(self.data if core is None else core,
+                                     lo, hi, axis)
+        return _wrap(core if core is not None else self.data.Clone())
 
     def __setitem__(self, keys, value):
         """``t[:] = other`` (whole-tensor assignment) as used by ``sum(out=)``."""
-        if keys == slice(None, None, None):
-            self.copy_from(value)
-        else:
+        if keys != slice(None, None, None):
             raise NotImplementedError("only t[:] = value is supported")
+        self.copy_from(value)
 
+    # ---- shape and layout ----------------------------------------------------------
     def is_dummy(self):
-        return bool(re.match(r'Dummy#\d+', self.name))
-
-    def ndim(self):
-        return self.data.nDim()
+        return re.match(r'Dummy#\d+', str(self.name)) is not None
 
     def is_empty(self):
         return self.ndim() == 0
-
-    def is_transpose(self):
-        return self.data.transpose()
 
     def transpose(self, axes=None):
         if axes is None:
             return _wrap(singa.DefaultTranspose(self.data))
         if len(axes) != len(self.shape):
-            raise ValueError('dimensions do not match')
+            raise ValueError('%d axes given for %d dimensions' % (
+                len(axes), len(self.shape)))
         return _wrap(singa.Transpose(self.data, list(axes)))
 
-    def size(self):
-        return self.data.Size()
-
-    def memsize(self):
-        return self.data.MemSize()
+    def T(self):
+        return self.transpose()
 
     def contiguous(self):
         return _wrap(singa.Contiguous(self.data))
 
     def reshape(self, shape):
         assert product(self.shape) == product(shape), \
-            'product of shape should be equal'
+            'reshape keeps the number of elements: %s -> %s' % (
+                self.shape, tuple(shape))
         return _wrap(singa.Reshape(self.data, list(shape)))
 
     def reset_like(self, t):
         self.data.ResetLike(t.data)
-        self.shape = t.shape
-        self.device = t.device
-        self.dtype = t.dtype
+        self.shape, self.device, self.dtype = t.shape, t.device, t.dtype
 
+    def repeat(self, repeats, axis):
+        nd = self.ndim()
+        if isinstance(repeats, int):
+            counts = [repeats]
+            # the core takes 9999 for "flatten first"
+            axis = 9999 if axis is None else axis + (nd if axis < 0 else 0)
+        elif isinstance(repeats, (tuple, list)):
+            if axis is None:
+                raise ValueError("per-element repeat counts need an axis")
+            counts = list(repeats)
+            axis += nd if axis < 0 else 0
+        else:
+            raise ValueError("repeats is an int or a sequence of ints, got "
+                             "%r" % (repeats,))
+        if min(counts, default=0) < 0:
+            raise ValueError("negative repeat count in %r" % (repeats,))
+        return _wrap(self.data.Repeat(counts, axis))
+
+    # ---- dtype and placement -----------------------------------------------------------
     @staticmethod
     def _dtype_code(dtype):
-        if dtype in (singa.kInt, singa.kFloat16, singa.kFloat32,
-                     singa.kBFloat16, singa.kDouble):
+        if dtype in _DTYPE_CODES:
             return dtype
-        if dtype == 'int':
-            return singa.kInt
-        if dtype == 'float':
-            return singa.kFloat32
-        raise TypeError("invalid data type %s" % dtype)
+        try:
+            return _DTYPE_ALIASES[dtype]
+        except (KeyError, TypeError):
+            raise TypeError("invalid data type %s" % dtype)
 
     def as_type(self, dtype):
-        dtype = self._dtype_code(dtype)
-        return _wrap(singa.Tensor(self.data.AsType(dtype)))
+        return _wrap(singa.Tensor(self.data.AsType(self._dtype_code(dtype))))
 
     def to_type(self, dtype):
         assert self.data.initialized()
-        dtype = self._dtype_code(dtype)
-        self.data.ToType(dtype)
-        self.dtype = dtype
+        self.dtype = self._dtype_code(dtype)
+        self.data.ToType(self.dtype)
         return self
 
     def to_device(self, device):
@@ -178,181 +206,46 @@ class Tensor(object):
         self.data.ToHost()
         self.device = get_default_device()
 
-    def l2(self):
-        return self.data.L2()
-
-    def l1(self):
-        return self.data.L1()
-
+    # ---- values ------------------------------------------------------------------------
     def set_value(self, x, inplace=True):
-        if not inplace:
-            raise NotImplementedError
+        _inplace_only(inplace)
         self.data.SetFloatValue(float(x))
         return self
 
     def copy_from_numpy(self, np_array, offset=0):
-        assert np_array.size == self.size(), 'tensor shape should be the same'
         copy_from_numpy(self.data, np_array)
 
     def copy_data(self, t):
-        assert isinstance(t, Tensor), 't must be a singa Tensor instance'
-        assert t.size() == self.size(), "tensor shape should be the same"
+        assert isinstance(t, Tensor), 'the source must be a Tensor'
+        assert t.size() == self.size(), \
+            "copy between tensors of %d and %d elements" % (t.size(),
+                                                            self.size())
         self.data.CopyData(t.data)
 
     def copy_from(self, t, offset=0):
-        if isinstance(t, Tensor):
-            self.copy_data(t)
-        elif isinstance(t, np.ndarray):
-            self.copy_from_numpy(t)
-        else:
-            raise ValueError("t should be Tensor or numpy array.")
+        for kind, load in ((Tensor, self.copy_data),
+                           (np.ndarray, self.copy_from_numpy)):
+            if isinstance(t, kind):
+                return load(t)
+        raise ValueError("cannot copy from a %s" % type(t).__name__)
 
     def clone(self):
         return _wrap(self.data.Clone())
 
-    def repeat(self, repeats, axis):
-        t_ndim = self.ndim()
-        if isinstance(repeats, int):
-            if repeats < 0:
-                raise ValueError(
-                    "'repeats' should not be negative: {}".format(repeats))
-            if axis is not None and axis < 0:
-                axis += t_ndim
-            return _wrap(self.data.Repeat([repeats],
-                                          9999 if axis is None else axis))
-        elif isinstance(repeats, (tuple, list)):
-            for rep in repeats:
-                if rep < 0:
-                    raise ValueError(
-                        "'repeats' should be int or sequence: {}".format(
-                            repeats))
-            if axis is None:
-                raise ValueError(
-                    "when axis us None, 'repeats' should be int: {}".format(
-                        repeats))
-            if axis < 0:
-                axis += t_ndim
-            return _wrap(self.data.Repeat(list(repeats), axis))
-        raise ValueError('repeats should be int or sequence')
-
-    def T(self):
-        return _wrap(singa.DefaultTranspose(self.data))
+    deepcopy = clone
 
     def copy(self):
         """Shallow copy sharing the underlying memory."""
         return _wrap(CTensor(self.data))
 
-    def deepcopy(self):
-        return self.clone()
-
-    def bernoulli(self, p, inplace=True):
-        if not inplace:
-            raise NotImplementedError
-        singa.Bernoulli(float(p), self.data)
-        return self
-
-    def gaussian(self, mean, std, inplace=True):
-        if not inplace:
-            raise NotImplementedError
-        singa.Gaussian(float(mean), float(std), self.data)
-        return self
-
-    def uniform(self, low, high, inplace=True):
-        if not inplace:
-            raise NotImplementedError
-        singa.Uniform(float(low), float(high), self.data)
-        return self
-
-    # deprecated row / column helpers (kept for old scripts)
-    def add_column(self, v):
-        singa.AddColumn(v.data, self.data)
-
-    def add_row(self, v):
-        singa.AddRow(v.data, self.data)
-
-    def div_column(self, v):
-        singa.DivColumn(v.data, self.data)
-
-    def div_row(self, v):
-        singa.DivRow(v.data, self.data)
-
-    def mult_column(self, v):
-        singa.MultColumn(v.data, self.data)
-
-    def mult_row(self, v):
-        singa.MultRow(v.data, self.data)
-
-    # in-place arithmetic
-    def __iadd__(self, x):
-        self.data += x.data if isinstance(x, Tensor) else float(x)
-        return self
-
-    def __isub__(self, x):
-        self.data -= x.data if isinstance(x, Tensor) else float(x)
-        return self
-
-    def __imul__(self, x):
-        self.data *= x.data if isinstance(x, Tensor) else float(x)
-        return self
-
-    def __itruediv__(self, x):
-        self.data /= x.data if isinstance(x, Tensor) else float(x)
-        return self
-
-    # binary arithmetic
-    def __add__(self, rhs):
-        if isinstance(rhs, Tensor):
-            return from_raw_tensor(singa.__add__(self.data, rhs.data))
-        return _call_singa_func(singa.AddFloat, self.data, float(rhs))
-
-    def __sub__(self, rhs):
-        if isinstance(rhs, Tensor):
-            return from_raw_tensor(singa.__sub__(self.data, rhs.data))
-        return _call_singa_func(singa.SubFloat, self.data, float(rhs))
-
-    def __mul__(self, rhs):
-        if isinstance(rhs, Tensor):
-            return from_raw_tensor(singa.__mul__(self.data, rhs.data))
-        return _call_singa_func(singa.MultFloat, self.data, float(rhs))
-
-    def __div__(self, rhs):
-        if isinstance(rhs, Tensor):
-            return from_raw_tensor(singa.__div__(self.data, rhs.data))
-        return _call_singa_func(singa.DivFloat, self.data, float(rhs))
-
-    def __truediv__(self, rhs):
-        return self.__div__(rhs)
-
+    # ---- operators that are not table-generated ------------------------------------------
     def __floordiv__(self, rhs):
-        tmp = self.__div__(rhs)
-        return _call_singa_func(singa.Floor, tmp.data)
-
-    def __lt__(self, rhs):
-        if isinstance(rhs, Tensor):
-            return from_raw_tensor(singa.__lt__(self.data, rhs.data))
-        return _call_singa_func(singa.LTFloat, self.data, float(rhs))
-
-    def __le__(self, rhs):
-        if isinstance(rhs, Tensor):
-            return from_raw_tensor(singa.__le__(self.data, rhs.data))
-        return _call_singa_func(singa.LEFloat, self.data, float(rhs))
-
-    def __gt__(self, rhs):
-        if isinstance(rhs, Tensor):
-            return from_raw_tensor(singa.__gt__(self.data, rhs.data))
-        return _call_singa_func(singa.GTFloat, self.data, float(rhs))
-
-    def __ge__(self, rhs):
-        if isinstance(rhs, Tensor):
-            return from_raw_tensor(singa.__ge__(self.data, rhs.data))
-        return _call_singa_func(singa.GEFloat, self.data, float(rhs))
+        return _wrap(singa.Floor((self / rhs).data))
 
     def __eq__(self, rhs):
-        if isinstance(rhs, Tensor):
-            return from_raw_tensor(singa.__eq__(self.data, rhs.data))
-        elif rhs is None:
+        if rhs is None:
             return False
-        return _call_singa_func(singa.EQFloat, self.data, float(rhs))
+        return _binary_eq(self, rhs)
 
     __hash__ = object.__hash__
 
@@ -360,30 +253,8 @@ class Tensor(object):
         # ``if self.b:`` in layer code asks "is there a tensor", not its value
         return True
 
-    def _rop(self, lhs, fn):
-        one = Tensor(self.shape, self.device, self.dtype)
-        one.set_value(float(lhs))
-        return fn(one)
-
-    def __radd__(self, lhs):
-        return self._rop(lhs, lambda one: one.__iadd__(self))
-
-    def __rsub__(self, lhs):
-        return self._rop(lhs, lambda one: one.__isub__(self))
-
-    def __rmul__(self, lhs):
-        return self._rop(lhs, lambda one: one.__imul__(self))
-
-    def __rdiv__(self, lhs):
-        return self._rop(lhs, lambda one: one.__itruediv__(self))
-
-    __rtruediv__ = __rdiv__
-
     def __neg__(self):
         return self * -1.0
-
-    dtype_name = {float16: "float16", float32: "float32", int32: "int32",
-                  bfloat16: "bfloat16"}
 
     def __repr__(self):
         return "%s, %s" % (np.array2string(to_numpy(self)),
@@ -393,185 +264,297 @@ class Tensor(object):
 PlaceHolder = Tensor
 
 
+def _inplace_only(inplace):
+    if not inplace:
+        raise NotImplementedError("only the in-place form exists")
+
+
 def _wrap(ct):
-    t = Tensor.__new__(Tensor)
-    t.data = ct
-    t.shape = tuple(ct.shape())
-    t.device = ct.device()
-    t.dtype = ct.data_type()
-    t.requires_grad = True
-    t.stores_grad = False
-    t.name = 'Dummy#{}'.format(Tensor.tensor_count)
-    Tensor.tensor_count += 1
-    from . import autograd
-    t.creator = autograd.Dummy(t, None)
-    return t
+    """A fresh user tensor around a core tensor."""
+    return Tensor.__new__(Tensor)._adopt(ct)
 
 
-def from_raw_tensor(t):
-    return _wrap(t)
+from_raw_tensor = _wrap
 
 
 def from_raw_tensors(tt):
-    return [from_raw_tensor(t) for t in list(tt)]
+    return [_wrap(t) for t in tt]
 
 
 def _call_singa_func(_singa_func, *args):
     return _wrap(_singa_func(*args))
 
 
+# ---------------------------------------------------------------------------
+# generated operators
+# ---------------------------------------------------------------------------
+def _binary(with_tensor, with_scalar):
+    def op(self, rhs):
+        if isinstance(rhs, Tensor):
+            return _wrap(with_tensor(self.data, rhs.data))
+        return _wrap(with_scalar(self.data, float(rhs)))
+    return op
+
+
+def _inplace(name):
+    def op(self, x):
+        # the core tensor implements the in-place protocol itself
+        self.data = getattr(self.data, name)(
+            x.data if isinstance(x, Tensor) else float(x))
+        return self
+    return op
+
+
+def _reflected(name):
+    def op(self, lhs):
+        # scalar (op) tensor: fill a tensor with the scalar, combine in place
+        filled = Tensor(self.shape, self.device, self.dtype)
+        filled.set_value(float(lhs))
+        return getattr(filled, name)(self)
+    return op
+
+
+for _name, _pair in {
+        '__add__': (singa.__add__, singa.AddFloat),
+        '__sub__': (singa.__sub__, singa.SubFloat),
+        '__mul__': (singa.__mul__, singa.MultFloat),
+        '__div__': (singa.__div__, singa.DivFloat),
+        '__truediv__': (singa.__div__, singa.DivFloat),
+        '__lt__': (singa.__lt__, singa.LTFloat),
+        '__le__': (singa.__le__, singa.LEFloat),
+        '__gt__': (singa.__gt__, singa.GTFloat),
+        '__ge__': (singa.__ge__, singa.GEFloat)}.items():
+    setattr(Tensor, _name, _binary(*_pair))
+_binary_eq = _binary(singa.__eq__, singa.EQFloat)
+
+def _core_query(method):
+    def fn(self):
+        return getattr(self.data, method)()
+    return fn
+
+
+def _random_fill(kernel):
+    def fn(self, *params, inplace=True):
+        _inplace_only(inplace)
+        kernel(*(float(v) for v in params), self.data)
+        return self
+    return fn
+
+
+def _with_vector(kernel):
+    # deprecated row / column helpers (kept for old scripts)
+    def fn(self, v):
+        kernel(v.data, self.data)
+    return fn
+
+
+for _name, _method in {'ndim': 'nDim', 'size': 'Size', 'memsize': 'MemSize',
+                       'is_transpose': 'transpose', 'l1': 'L1',
+                       'l2': 'L2'}.items():
+    setattr(Tensor, _name, _core_query(_method))
+
+for _name, _kernel in {'bernoulli': singa.Bernoulli,
+                       'gaussian': singa.Gaussian,
+                       'uniform': singa.Uniform}.items():
+    setattr(Tensor, _name, _random_fill(_kernel))
+
+for _name, _kernel in {'add_column': singa.AddColumn, 'add_row': singa.AddRow,
+                       'div_column': singa.DivColumn, 'div_row': singa.DivRow,
+                       'mult_column': singa.MultColumn,
+                       'mult_row': singa.MultRow}.items():
+    setattr(Tensor, _name, _with_vector(_kernel))
+
+for _name in ('__iadd__', '__isub__', '__imul__', '__itruediv__'):
+    setattr(Tensor, _name, _inplace(_name))
+
+for _name, _target in {'__radd__': '__iadd__', '__rsub__': '__isub__',
+                       '__rmul__': '__imul__', '__rdiv__': '__itruediv__',
+                       '__rtruediv__': '__itruediv__'}.items():
+    setattr(Tensor, _name, _reflected(_target))
+
+
+def _unary(kernel):
+    def fn(t):
+        return _wrap(kernel(t.data))
+    return fn
+
+
+abs = _unary(singa.Abs)
+exp = _unary(singa.Exp)
+ceil = _unary(singa.Ceil)
+log = _unary(singa.Log)
+sigmoid = _unary(singa.Sigmoid)
+sign = _unary(singa.Sign)
+sqrt = _unary(singa.Sqrt)
+square = _unary(singa.Square)
+tanh = _unary(singa.Tanh)
+relu = _unary(singa.ReLU)
+contiguous = _unary(singa.Contiguous)
+
+
+def _with_ret(operator, tensor_kernel, scalar_kernel):
+    """``f(lhs, rhs, ret=None)``: operator form, or write into ``ret``."""
+    def fn(lhs, rhs, ret=None):
+        if ret is None:
+            return operator(lhs, rhs)
+        if isinstance(rhs, Tensor):
+            tensor_kernel(lhs.data, rhs.data, ret.data)
+        else:
+            scalar_kernel(lhs.data, rhs, ret.data)
+        return ret
+    return fn
+
+
+add = _with_ret(lambda a, b: a + b, singa.Add, singa.AddFloatWithRet)
+sub = _with_ret(lambda a, b: a - b, singa.Sub, singa.SubFloatWithRet)
+eltwise_mult = _with_ret(lambda a, b: a * b, singa.EltwiseMult,
+                         singa.EltwiseMultFloatWithRet)
+div = _with_ret(lambda a, b: a / b, singa.Div, singa.DivFloatWithRet)
+
+
+# comparison functions: the operator forms under their reference names
+lt, le, gt, ge, eq = (operator.lt, operator.le, operator.gt, operator.ge,
+                      operator.eq)
+
+
+# ---------------------------------------------------------------------------
+# construction and conversion
+# ---------------------------------------------------------------------------
+def _filled(shape, device, dtype, value):
+    t = Tensor(shape, device if device is not None else get_default_device(),
+               dtype)
+    return t.set_value(value)
+
+
 def zeros_like(t):
-    ret = Tensor(t.shape, t.device, t.dtype)
-    ret.set_value(0.0)
-    return ret
+    return _filled(t.shape, t.device, t.dtype, 0.0)
 
 
 def ones_like(t):
-    ret = Tensor(t.shape, t.device, t.dtype)
-    ret.set_value(1.0)
-    return ret
+    return _filled(t.shape, t.device, t.dtype, 1.0)
+
+
+def zeros(shape, device=None):
+    return _filled(shape, device, None, 0.0)
+
+
+def ones(shape, device=None):
+    return _filled(shape, device, None, 1.0)
+
+
+def random(shape, device=None):
+    return Tensor(shape, device=device or get_default_device()).uniform(0, 1)
 
 
 def product(shape):
-    return reduce(lambda x, y: x * y, shape)
+    return math.prod(shape)
 
 
 def sizeof(dtype):
     return singa.SizeOf(dtype)
 
 
-def contiguous(tensor):
-    return _call_singa_func(singa.Contiguous, tensor.data)
-
-
 def reshape(tensor, shape):
-    return _call_singa_func(singa.Reshape, tensor.data, list(shape))
+    return _wrap(singa.Reshape(tensor.data, list(shape)))
 
 
 def transpose(t, axes=None):
     return t.transpose(axes)
 
 
+def repeat(t, repeats, axis=None):
+    return t.repeat(repeats, axis)
+
+
+def concatenate(tensors, axis):
+    return _wrap(singa.ConcatOn(singa.VecTensor([t.data for t in tensors]),
+                                axis))
+
+
 def copy_data_to_from(dst, src, size, dst_offset=0, src_offset=0):
     singa.CopyDataToFrom(dst.data, src.data, size, dst_offset, src_offset)
 
 
+_HOST_UPLOAD = {np.dtype(np.float32): ('CopyFloatDataFromHostPtr', None),
+                np.dtype(np.float64): ('CopyFloatDataFromHostPtr', np.float32),
+                np.dtype(np.float16): ('CopyHalfFloatDataFromHostPtr', None),
+                np.dtype(np.int32): ('CopyIntDataFromHostPtr', None),
+                np.dtype(np.int64): ('CopyIntDataFromHostPtr', np.int32)}
+
+
+def copy_from_numpy(data, np_array):
+    """Copy a numpy array into a core tensor of the same size."""
+    assert np_array.size == data.Size(), (
+        'array of %d elements into a tensor of %d' % (np_array.size,
+                                                      data.Size()))
+    try:
+        method, narrow = _HOST_UPLOAD[np_array.dtype]
+    except KeyError:
+        raise NotImplementedError('Not implemented yet for ', np_array.dtype)
+    flat = np_array.reshape(-1)
+    getattr(data, method)(flat if narrow is None else flat.astype(narrow))
+
+
 def from_numpy(np_array, dev=None):
-    assert type(np_array) is np.ndarray, 'Must input numpy array'
-    if np_array.dtype == np.float64:
-        np_array = np_array.astype(np.float32)
-    if np_array.dtype == np.int64:
-        np_array = np_array.astype(np.int32)
-    if np_array.dtype == np.float32:
-        dtype = float32
-    elif np_array.dtype == np.float16:
-        dtype = float16
-    else:
-        assert np_array.dtype == np.int32, \
-            'Only float and int tensors are supported'
-        dtype = int32
-    ret = Tensor(np_array.shape, dtype=dtype)
-    ret.copy_from_numpy(np_array)
+    """A host tensor holding the array's values, moved to ``dev`` if given."""
+    assert type(np_array) is np.ndarray, \
+        'from_numpy takes a numpy array, got %s' % type(np_array).__name__
+    kind = np_array.dtype.type
+    assert kind in _NP2DTYPE, 'no tensor dtype for numpy %s' % np_array.dtype
+    t = Tensor(np_array.shape, dtype=_NP2DTYPE[kind])
+    copy_from_numpy(t.data, np_array)
     if dev:
-        ret.to_device(dev)
-    return ret
+        t.to_device(dev)
+    return t
 
 
 def to_host(t):
-    ret = t.clone()
-    ret.to_host()
-    return ret
+    host = t.clone()
+    host.to_host()
+    return host
+
+
+_HOST_DOWNLOAD = {float32: 'GetFloatValue', float16: 'GetHalfFloatValue',
+                  int32: 'GetIntValue', bfloat16: 'GetFloatValue'}
 
 
 def to_numpy(t):
-    ct = t.data
-    if ct.data_type() == float32:
-        arr = ct.GetFloatValue()
-    elif ct.data_type() == float16:
-        arr = ct.GetHalfFloatValue()
-    elif ct.data_type() == int32:
-        arr = ct.GetIntValue()
-    elif ct.data_type() == bfloat16:
-        arr = ct.GetFloatValue()
-    else:
-        arr = ct.get_value()
-    return arr.reshape(t.shape)
+    getter = _HOST_DOWNLOAD.get(t.data.data_type(), 'get_value')
+    return getattr(t.data, getter)().reshape(t.shape)
 
 
-def abs(t):
-    return _call_singa_func(singa.Abs, t.data)
-
-
-def exp(t):
-    return _call_singa_func(singa.Exp, t.data)
-
-
-def ceil(t):
-    return _call_singa_func(singa.Ceil, t.data)
-
-
-def log(t):
-    return _call_singa_func(singa.Log, t.data)
-
-
-def sigmoid(t):
-    return _call_singa_func(singa.Sigmoid, t.data)
-
-
-def sign(t):
-    return _call_singa_func(singa.Sign, t.data)
-
-
-def sqrt(t):
-    return _call_singa_func(singa.Sqrt, t.data)
-
-
-def square(t):
-    return _call_singa_func(singa.Square, t.data)
-
-
-def tanh(t):
-    return _call_singa_func(singa.Tanh, t.data)
-
-
-def relu(t):
-    return _call_singa_func(singa.ReLU, t.data)
-
-
+# ---------------------------------------------------------------------------
+# reductions and products
+# ---------------------------------------------------------------------------
 def sum(t, axis=None, out=None):
-    """Sum over ``axis`` (None, int or tuple); the reduced axes are removed."""
-    t_ndim = t.ndim()
+    """Sum over ``axis`` (None, int or tuple); the reduced axes are removed.
+    One matrix-vector product against a vector of ones."""
+    nd = t.ndim()
     if axis is None:
-        one = Tensor(t.shape, t.device)
-        one.set_value(1.0)
-        ret = tensordot(t, one, t_ndim)
-    elif isinstance(axis, int):
-        if axis < 0:
-            axis += t_ndim
-        one = Tensor(shape=(int(t.shape[axis]),), device=t.device)
-        one.set_value(1.0)
-        ret = tensordot(t, one, axes=([axis], [0]))
+        over = list(range(nd))
+    elif isinstance(axis, (int, np.integer)):
+        over = [int(axis)]
     elif isinstance(axis, (tuple, list)):
-        l_axis = [a + t_ndim if a < 0 else a for a in axis]
-        one = Tensor(tuple(t.shape[x] for x in l_axis), t.device)
-        one.set_value(1.0)
-        ret = tensordot(t, one, (l_axis, list(range(one.ndim()))))
+        over = list(axis)
     else:
         raise ValueError("axis must be None, int or tuple")
+    over = [a + nd if a < 0 else a for a in over]
+    ones_ = _filled(tuple(t.shape[a] for a in over), t.device, t.dtype, 1.0)
+    total = tensordot(t, ones_, (over, list(range(len(over)))))
     if out is not None:
-        if out.shape != ret.shape:
-            raise ValueError('dimensions do not match')
-        out[:] = ret
-        return out
-    return ret
+        if out.shape != total.shape:
+            raise ValueError('out has shape %s, the sum %s' % (out.shape,
+                                                               total.shape))
+        out.copy_from(total)
+    return total if out is None else out
 
 
 def pow(t, x, out=None):
+    tensor_exponent = isinstance(x, Tensor)
     if out is None:
-        if isinstance(x, Tensor):
-            return _call_singa_func(singa.Pow, t.data, x.data)
-        return _call_singa_func(singa.PowFloat, t.data, x)
-    if isinstance(x, Tensor):
+        return _wrap(singa.Pow(t.data, x.data) if tensor_exponent
+                     else singa.PowFloat(t.data, x))
+    if tensor_exponent:
         singa.PowWithRet(t.data, x.data, out.data)
     else:
         singa.PowFloatWithRet(t.data, x, out.data)
@@ -579,210 +562,133 @@ def pow(t, x, out=None):
 
 
 def average(t, axis=None):
-    if t.ndim() > 1 and axis is not None:
-        return _call_singa_func(singa.Average, t.data, axis)
-    return singa.SumAsFloat(t.data) / t.size()
+    if axis is None or t.ndim() <= 1:
+        return singa.SumAsFloat(t.data) / t.size()
+    return _wrap(singa.Average(t.data, axis))
 
 
 def softmax(t, out=None):
     if out is None:
-        return _call_singa_func(singa.SoftMax, t.data)
+        return _wrap(singa.SoftMax(t.data))
     singa.SoftMax(t.data, out.data)
     return out
-
-
-def lt(t, x):
-    return t < x
-
-
-def le(t, x):
-    return t <= x
-
-
-def gt(t, x):
-    return t > x
-
-
-def ge(t, x):
-    return t >= x
-
-
-def eq(t, x):
-    return t == x
-
-
-def add(lhs, rhs, ret=None):
-    if ret is None:
-        return lhs + rhs
-    if isinstance(rhs, Tensor):
-        singa.Add(lhs.data, rhs.data, ret.data)
-    else:
-        singa.AddFloatWithRet(lhs.data, rhs, ret.data)
-    return ret
-
-
-def sub(lhs, rhs, ret=None):
-    if ret is None:
-        return lhs - rhs
-    if isinstance(rhs, Tensor):
-        singa.Sub(lhs.data, rhs.data, ret.data)
-    else:
-        singa.SubFloatWithRet(lhs.data, rhs, ret.data)
-    return ret
-
-
-def eltwise_mult(lhs, rhs, ret=None):
-    if ret is None:
-        return lhs * rhs
-    if isinstance(rhs, Tensor):
-        singa.EltwiseMult(lhs.data, rhs.data, ret.data)
-    else:
-        singa.EltwiseMultFloatWithRet(lhs.data, rhs, ret.data)
-    return ret
-
-
-def div(lhs, rhs, ret=None):
-    if ret is None:
-        return lhs / rhs
-    if isinstance(rhs, Tensor):
-        singa.Div(lhs.data, rhs.data, ret.data)
-    else:
-        singa.DivFloatWithRet(lhs.data, rhs, ret.data)
-    return ret
 
 
 def mult(A, B, C=None, alpha=1.0, beta=0.0):
     """C = alpha * A @ B + beta * C (matrix-vector, matrix-matrix or batched)."""
     if C is None:
-        return _call_singa_func(singa.Mult, A.data, B.data)
+        return _wrap(singa.Mult(A.data, B.data))
     singa.MultWithScale(alpha, A.data, B.data, beta, C.data)
     return C
 
 
-def einsum(ops, *args):
-    """Two-operand einsum built from repeat / transpose / multiply / sum."""
-    if len(ops) == 0:
-        raise ValueError("No input operands")
-    if len(args) != 2:
-        raise ValueError("Currently only two operands are supported")
-    inputops, outputops = ops.split('->')
-    inputops = inputops.split(',')
-    A, B = args
-    if A.ndim() != len(inputops[0]) or B.ndim() != len(inputops[1]):
-        raise ValueError("input dim doesn't match operands")
-    sums = sorted(list((set(inputops[0]) | set(inputops[1])) - set(outputops)))
-    broadcast_A = sorted(list(set(inputops[1]) - set(inputops[0])))
-    broadcast_B = sorted(list(set(inputops[0]) - set(inputops[1])))
-    outputall = sorted(list(set(inputops[0]) | set(inputops[1])))
-    sums = [outputall.index(x) for x in sums]
-    broadcast_idA = [inputops[1].find(x) for x in broadcast_A]
-    broadcast_idB = [inputops[0].find(x) for x in broadcast_B]
-    broadcast_a = [B.shape[x] for x in broadcast_idA]
-    broadcast_b = [A.shape[x] for x in broadcast_idB]
-    transpose_A = [(list(inputops[0]) + broadcast_A).index(x) for x in outputall]
-    transpose_B = [(list(inputops[1]) + broadcast_B).index(x) for x in outputall]
-    reshape_A = list(A.shape) + broadcast_a
-    reshape_B = list(B.shape) + broadcast_b
-    if len(broadcast_a) == 0:
-        broadcast_a = [1]
-    if len(broadcast_b) == 0:
-        broadcast_b = [1]
-    mult_A = repeat(A, product(broadcast_a))
-    mult_A = mult_A.reshape(reshape_A)
-    mult_A = transpose(mult_A, transpose_A)
-    mult_B = repeat(B, product(broadcast_b))
-    mult_B = mult_B.reshape(reshape_B)
-    mult_B = transpose(mult_B, transpose_B)
-    if mult_A.shape != mult_B.shape:
-        raise ValueError("Error: matrix dimension mismatch")
-    res = eltwise_mult(mult_A, mult_B)
-    for i in sorted(sums, reverse=True):
-        res = sum(res, axis=i)
-    transpose_res = [sorted(list(outputops)).index(x) for x in list(outputops)]
-    res = transpose(res, transpose_res)
-    return res
-
-
-def repeat(t, repeats, axis=None):
-    return t.repeat(repeats, axis)
+def _axes_list(axes, nd):
+    axes = list(axes) if isinstance(axes, (list, tuple)) else [axes]
+    return [int(a) + nd if a < 0 else int(a) for a in axes]
 
 
 def tensordot(A, B, axes=2):
-    """numpy.tensordot semantics, evaluated as one matrix product."""
-    if type(axes) == int:
-        axes_A = list(range(-axes, 0))
-        axes_B = list(range(0, axes))
+    """numpy.tensordot semantics, evaluated as one matrix product: the
+    contracted axes are moved to the end of ``A`` and the front of ``B``."""
+    nda, ndb = A.ndim(), B.ndim()
+    if isinstance(axes, (int, np.integer)):
+        con_a = list(range(nda - axes, nda))
+        con_b = list(range(axes))
     else:
-        axes_A, axes_B = axes
-    axes_A = list(axes_A) if isinstance(axes_A, (list, tuple)) else [axes_A]
-    axes_B = list(axes_B) if isinstance(axes_B, (list, tuple)) else [axes_B]
-    na, nb = len(axes_A), len(axes_B)
-    a_shape, nda = A.shape, A.ndim()
-    b_shape, ndb = B.shape, B.ndim()
-    equal = na == nb
-    if equal:
-        for k in range(na):
-            if a_shape[axes_A[k]] != b_shape[axes_B[k]]:
-                equal = False
-                break
-            if axes_A[k] < 0:
-                axes_A[k] += nda
-            if axes_B[k] < 0:
-                axes_B[k] += ndb
-    if not equal:
-        raise ValueError("shape-mismatch for sum")
+        con_a, con_b = _axes_list(axes[0], nda), _axes_list(axes[1], ndb)
+    if len(con_a) != len(con_b) or any(
+            A.shape[i] != B.shape[j] for i, j in zip(con_a, con_b)):
+        raise ValueError("contracted axes %s / %s differ in extent" % (
+            con_a, con_b))
+    keep_a = [i for i in range(nda) if i not in con_a]
+    keep_b = [j for j in range(ndb) if j not in con_b]
+    free_a = [A.shape[i] for i in keep_a]
+    free_b = [B.shape[j] for j in keep_b]
+    depth = product(A.shape[i] for i in con_a)
+    left = reshape(A.transpose(keep_a + con_a), (product(free_a), depth))
+    right = reshape(B.transpose(con_b + keep_b), (depth, product(free_b)))
+    return mult(left, right).reshape(tuple(free_a + free_b) or (1, 1))
 
-    notin = [k for k in range(nda) if k not in axes_A]
-    newaxes_a = notin + axes_A
-    N2 = 1
-    for axis in axes_A:
-        N2 *= a_shape[axis]
-    N1 = 1
-    for ax in notin:
-        N1 *= a_shape[ax]
-    newshape_a = (N1, N2)
-    olda = [a_shape[axis] for axis in notin]
-    notin = [k for k in range(ndb) if k not in axes_B]
-    newaxes_b = axes_B + notin
-    N2 = 1
-    for axis in axes_B:
-        N2 *= b_shape[axis]
-    N1 = 1
-    for bx in notin:
-        N1 *= b_shape[bx]
-    newshape_b = (N2, N1)
-    oldb = [b_shape[axis] for axis in notin]
 
-    A = transpose(A, newaxes_a)
-    B = transpose(B, newaxes_b)
-    at = reshape(A, newshape_a)
-    bt = reshape(B, newshape_b)
-    res = mult(at, bt)
-    if len(olda + oldb) == 0:
-        res = res.reshape((1, 1))
+def einsum(ops, *args):
+    """Two-operand einsum, e.g. ``einsum('bij,bjk->bik', x, y)``, as one
+    batched matrix product.
+
+    Labels present in both operands and the output index the batch; labels
+    present in both operands only are contracted by the GEMM; the remaining
+    output labels are the free rows (first operand) and columns (second);
+    a label that occurs in a single operand and not in the output is summed
+    away before the product."""
+    if not ops or len(args) != 2:
+        raise ValueError("einsum takes a subscript string and two operands")
+    spec_in, _, spec_out = ops.replace(' ', '').partition('->')
+    la, lb = spec_in.split(',')
+    A, B = args
+    if A.ndim() != len(la) or B.ndim() != len(lb):
+        raise ValueError("subscripts %r do not match operand ranks %d, %d" % (
+            spec_in, A.ndim(), B.ndim()))
+    if len(set(la)) != len(la) or len(set(lb)) != len(lb):
+        raise ValueError("repeated labels within one operand are not supported")
+    if not set(spec_out) <= set(la) | set(lb):
+        raise ValueError("output label missing from the operands")
+    extent = {}
+    for labels, t in ((la, A), (lb, B)):
+        for c, n in zip(labels, t.shape):
+            if extent.setdefault(c, n) != n:
+                raise ValueError("label %r has extents %d and %d" % (
+                    c, extent[c], n))
+
+    def presum(t, labels, other):
+        gone = [i for i, c in enumerate(labels)
+                if c not in other and c not in spec_out]
+        if gone:
+            t = sum(t, axis=tuple(gone))
+            labels = ''.join(c for i, c in enumerate(labels) if i not in gone)
+        return t, labels
+
+    A, la = presum(A, la, lb)
+    B, lb = presum(B, lb, la)
+    batch = [c for c in la if c in lb and c in spec_out]
+    inner = [c for c in la if c in lb and c not in spec_out]
+    rows = [c for c in la if c not in lb]
+    cols = [c for c in lb if c not in la]
+
+    def count(labels):
+        return product(extent[c] for c in labels)
+
+    left = A.transpose([la.index(c) for c in batch + rows + inner])
+    right = B.transpose([lb.index(c) for c in batch + inner + cols])
+    if not inner and not rows and not cols:
+        res = left.contiguous() * right.contiguous()       # pure Hadamard
     else:
-        res = res.reshape(tuple(olda + oldb))
+        left = reshape(left, (count(batch), count(rows), count(inner)))
+        right = reshape(right, (count(batch), count(inner), count(cols)))
+        res = mult(left, right)
+    natural = batch + rows + cols
+    res = reshape(res, tuple(extent[c] for c in natural) or (1,))
+    if list(spec_out) != natural:
+        res = res.transpose([natural.index(c) for c in spec_out])
     return res
 
 
+# ---------------------------------------------------------------------------
+# BLAS-1 style helpers and random fills
+# ---------------------------------------------------------------------------
 def axpy(alpha, x, y):
     singa.Axpy(float(alpha), x.data, y.data)
     return y
 
 
 def bernoulli(p, t):
-    singa.Bernoulli(float(p), t.data)
-    return t
+    return t.bernoulli(p)
 
 
 def gaussian(mean, std, t):
-    singa.Gaussian(float(mean), float(std), t.data)
-    return t
+    return t.gaussian(mean, std)
 
 
 def uniform(low, high, t):
-    singa.Uniform(float(low), float(high), t.data)
-    return t
+    return t.uniform(low, high)
 
 
 def add_column(alpha, v, beta, M):
@@ -795,58 +701,14 @@ def add_row(alpha, v, beta, M):
     return M
 
 
-def sum_columns(M):
-    assert M.ndim() == 2, 'M.nDim() is supposed to be 2'
-    ret = Tensor((M.shape[0], 1), M.data.device())
-    singa.SumColumns(M.data, ret.data)
-    return ret
+def _matrix_reduce(kernel, shape_of):
+    def fn(M):
+        assert M.ndim() == 2, 'expects a matrix, got %d dimensions' % M.ndim()
+        ret = Tensor(shape_of(M), M.data.device())
+        kernel(M.data, ret.data)
+        return ret
+    return fn
 
 
-def sum_rows(M):
-    assert M.ndim() == 2, 'M.nDim() is supposed to be 2'
-    ret = Tensor((1, M.shape[1]), M.data.device())
-    singa.SumRows(M.data, ret.data)
-    return ret
-
-
-def copy_from_numpy(data, np_array):
-    """Copy a numpy array into a core tensor of the same size."""
-    assert np_array.size == data.Size(), 'tensor shape should be the same'
-    if not np_array.ndim == 1:
-        np_array = np_array.flatten()
-    dt = np_array.dtype
-    if dt == np.float32:
-        data.CopyFloatDataFromHostPtr(np_array)
-    elif dt == np.float16:
-        data.CopyHalfFloatDataFromHostPtr(np_array)
-    elif dt == np.int32 or dt == np.int64:
-        data.CopyIntDataFromHostPtr(np_array.astype(np.int32))
-    elif dt == np.float64:
-        data.CopyFloatDataFromHostPtr(np_array.astype(np.float32))
-    else:
-        raise NotImplementedError('Not implemented yet for ', dt)
-
-
-def concatenate(tensors, axis):
-    ctensors = singa.VecTensor()
-    for t in tensors:
-        ctensors.append(t.data)
-    return _call_singa_func(singa.ConcatOn, ctensors, axis)
-
-
-def random(shape, device=None):
-    ret = Tensor(shape, device=device or get_default_device())
-    ret.uniform(0, 1)
-    return ret
-
-
-def zeros(shape, device=None):
-    ret = Tensor(shape, device=device or get_default_device())
-    ret.set_value(0.0)
-    return ret
-
-
-def ones(shape, device=None):
-    ret = Tensor(shape, device=device or get_default_device())
-    ret.set_value(1.0)
-    return ret
+sum_columns = _matrix_reduce(singa.SumColumns, lambda M: (M.shape[0], 1))
+sum_rows = _matrix_reduce(singa.SumRows, lambda M: (1, M.shape[1]))

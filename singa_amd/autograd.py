@@ -1471,12 +1471,9 @@ class Concat(Operator):
 
     def backward(self, dy):
         assert self.slice_point[-1] == dy.shape()[self.axis], "Shape mismatch."
-        dxs = []
-        last_offset = 0
-        for p in self.slice_point:
-            dxs.append(singa.SliceOn(dy, last_offset, p, self.axis))
-            last_offset = p
-        return tuple(dxs)
+        ends = self.slice_point
+        sizes = [e - b for b, e in zip([0] + ends[:-1], ends)]
+        return tuple(singa.SplitOn(dy, sizes, self.axis))
 
 
 def cat(xs, axis=0):
@@ -1552,13 +1549,8 @@ class Split(Operator):
         if self.parts is None:
             self.parts = [x_shape[self.axis] // self.num_output
                           ] * self.num_output
-        xs = []
-        _s = 0
-        for _l in self.parts:
-            xs.append(singa.SliceOn(x, _s, _s + _l, self.axis))
-            _s += _l
         self._like = (x_shape, x.device(), x.data_type())
-        return tuple(xs)
+        return tuple(singa.SplitOn(x, self.parts, self.axis))
 
     def backward(self, *dys):
         # outputs that nothing consumed have no gradient: they contribute zeros

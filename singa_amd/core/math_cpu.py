@@ -321,11 +321,11 @@ class CpuMath(object):
 
     def pack(self, plan, views, bucket):
         for off, v in zip(plan, views):
-            bucket[off:off + v.numel()].copy_(v)
+            bucket[off:off + v.numel()].copy_(v.reshape(-1))
 
     def unpack(self, plan, bucket, views, scale):
         for off, v in zip(plan, views):
-            src = bucket[off:off + v.numel()]
+            src = bucket[off:off + v.numel()].view(v.shape)
             v.copy_(src if scale == 1.0 else src.to(torch.float32) * scale)
 
     def sparsify_threshold(self, x, thr):
@@ -522,3 +522,34 @@ class CpuMath(object):
         dc_prev.copy_(dc * f)
         dgates.copy_(torch.cat([di * i * (1 - i), df * f * (1 - f),
                                 do * o * (1 - o), dg * (1 - g * g)], dim=1))
+
+    def gru_cell_fwd(self, gx, gh, brn, h_prev, h, acts, ghn):
+        """One GRU step from the (batch, 3H) input and recurrent projections
+        (gates r, z, n); ``brn`` is added to gh_n inside the reset-gated
+        term."""
+        H = h_prev.shape[1]
+        r = torch.sigmoid(gx[:, :H] + gh[:, :H])
+        z = torch.sigmoid(gx[:, H:2 * H] + gh[:, H:2 * H])
+        hn = gh[:, 2 * H:] if brn is None else gh[:, 2 * H:] + brn.view(1, H)
+        n = torch.tanh(gx[:, 2 * H:] + r * hn)
+        ghn.copy_(hn)
+        acts.copy_(torch.cat([r, z, n], dim=1))
+        h.copy_(n + z * (h_prev - n))
+
+    def gru_cell_bwd(self, dh, acts, ghn, h_prev, dgx, dgh, dh_prev):
+        H = h_prev.shape[1]
+        r, z, n = acts[:, :H], acts[:, H:2 * H], acts[:, 2 * H:]
+        dpre_n = dh * (1 - z) * (1 - n * n)
+        dr = dpre_n * ghn * r * (1 - r)
+        dz = dh * (h_prev - n) * z * (1 - z)
+        dgx.copy_(torch.cat([dr, dz, dpre_n], dim=1))
+        dgh.copy_(torch.cat([dr, dz, dpre_n * r], dim=1))
+        dh_prev.copy_(dh * z)
+
+    def rnn_act_bwd(self, mode, dh, h, d):
+        """d = dh * act'(h); mode 0 relu, 1 tanh."""
+        d.copy_(dh * (1 - h * h) if mode == 1 else dh * (h > 0).to(dh.dtype))
+
+    def lstm_seq_supported(self, batch, hidden, dtype):
+        """The single-launch sequence kernels exist on the GPU only."""
+        return False

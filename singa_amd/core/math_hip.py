@@ -965,3 +965,64 @@ class HipMath(object):
                              acts.data_ptr(), c_prev.data_ptr(), c.data_ptr(),
                              dgates.data_ptr(), dc_prev.data_ptr(),
                              c_prev.shape[0], c_prev.shape[1], self._s())
+
+    def gru_cell_fwd(self, gx, gh, brn, h_prev, h, acts, ghn):
+        """One GRU step from the (batch, 3H) input and recurrent projections
+        (gates r, z, n); ``brn`` (H,) or None is added to gh_n inside the
+        reset-gated term."""
+        self.k.gru_cell_fwd(_code(gx), gx.data_ptr(), gh.data_ptr(),
+                            0 if brn is None else brn.data_ptr(),
+                            h_prev.data_ptr(), h.data_ptr(), acts.data_ptr(),
+                            ghn.data_ptr(), h_prev.shape[0], h_prev.shape[1],
+                            self._s())
+
+    def gru_cell_bwd(self, dh, acts, ghn, h_prev, dgx, dgh, dh_prev):
+        self.k.gru_cell_bwd(_code(acts), dh.data_ptr(), acts.data_ptr(),
+                            ghn.data_ptr(), h_prev.data_ptr(), dgx.data_ptr(),
+                            dgh.data_ptr(), dh_prev.data_ptr(),
+                            h_prev.shape[0], h_prev.shape[1], self._s())
+
+    def rnn_act_bwd(self, mode, dh, h, d):
+        """d = dh * act'(h); mode 0 relu, 1 tanh."""
+        self.k.rnn_act_bwd(_code(h), int(mode), dh.data_ptr(), h.data_ptr(),
+                           d.data_ptr(), h.numel(), self._s())
+
+    def lstm_seq_supported(self, batch, hidden, dtype):
+        return dtype == torch.float32 and \
+            self.k.lstm_seq_supported(int(batch), int(hidden))
+
+    def lstm_seq_fwd(self, gx, R, h0, c0, hseq, cseq, acts, bar, reverse):
+        """Whole-sequence LSTM forward of one layer / direction in one launch;
+        fills hseq, cseq (T, B, H) and acts (T, B, 4H)."""
+        T, B, H = hseq.shape
+        for t in (gx, R, h0, c0, hseq, cseq, acts):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        assert tuple(gx.shape) == (T, B, 4 * H) and tuple(R.shape) == (4 * H, H)
+        assert tuple(h0.shape) == (B, H) == tuple(c0.shape)
+        assert tuple(acts.shape) == (T, B, 4 * H) and bar.numel() >= 2
+        self.k.lstm_seq_fwd(gx.data_ptr(), R.data_ptr(), h0.data_ptr(),
+                            c0.data_ptr(), hseq.data_ptr(), cseq.data_ptr(),
+                            acts.data_ptr(), bar.data_ptr(), B, H, T,
+                            1 if reverse else 0, self._s())
+
+    def lstm_seq_bwd(self, R, c0, cseq, acts, dy, dhy, dcy, dgates, dhx, dcx,
+                     bar, reverse):
+        """Whole-sequence LSTM backward: dy is a (T, B, H) view whose rows may
+        be strided (one direction of a bidirectional output); fills dgates
+        (T, B, 4H), dhx and dcx (B, H)."""
+        T, B, H = cseq.shape
+        for t in (R, c0, cseq, acts, dhy, dcy, dgates, dhx, dcx):
+            assert t.is_contiguous() and t.dtype == torch.float32
+        assert tuple(dy.shape) == (T, B, H) and dy.stride(2) == 1 and \
+            dy.stride(0) == B * dy.stride(1) and dy.dtype == torch.float32
+        assert tuple(dgates.shape) == (T, B, 4 * H) == tuple(acts.shape)
+        assert tuple(dhy.shape) == (B, H) == tuple(dcy.shape)
+        assert tuple(dhx.shape) == (B, H) == tuple(dcx.shape)
+        slabs = torch.empty(2 * (H // 8) * B * H, dtype=torch.float32,
+                            device=cseq.device)
+        self.k.lstm_seq_bwd(R.data_ptr(), c0.data_ptr(), cseq.data_ptr(),
+                            acts.data_ptr(), dy.data_ptr(), dy.stride(1),
+                            dhy.data_ptr(), dcy.data_ptr(), dgates.data_ptr(),
+                            dhx.data_ptr(), dcx.data_ptr(), slabs.data_ptr(),
+                            bar.data_ptr(), B, H, T, 1 if reverse else 0,
+                            self._s())

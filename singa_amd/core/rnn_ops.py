@@ -13,7 +13,12 @@ out for large GEMMs on the matrix cores:
 * backward computes the weight gradients of a layer with two GEMMs over all
   time steps (dW = dG^T X, dR = dG^T H_prev) and the input gradient with one;
 * everything a pass needs is launched from one graph node, so under hipGraph
-  replay a sequence costs no host work per step.
+  replay a sequence costs no host work per step;
+* each step is one recurrent GEMM plus ONE fused cell kernel (LSTM, GRU,
+  tanh / relu) in either direction;
+* a float32 LSTM without ``seq_lengths`` whose hidden size is a multiple of
+  32 up to 256 (batch <= 128) runs the whole time loop of a layer and
+  direction in ONE persistent launch, forward and backward.
 
 Weight layout (element offsets are published through ``weights_mapping`` with
 cuDNN's numbering: ``(linLayerID, pseudoLayer, is_bias) -> (offset, size)``,
@@ -22,6 +27,8 @@ GRU gates r, z, n): for every pseudo layer (layer * directions + direction)
 the input matrix block (G*H, in) then the recurrent block (G*H, H); after all
 matrices, for every pseudo layer the two bias blocks (G*H each).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -168,21 +175,25 @@ def _cell_fwd(X_, h, gx_t, hp, cp, R, bR, save, t):
         X_.mm(hp, R.t(), gx_t, 1.0)
         h_new = X_.un("relu" if mode == 0 else "tanh", gx_t)
         return h_new, None
-    # GRU: n = tanh(Wn x + bWn + r * (Rn h + bRn))
+    # GRU: n = tanh(Wn x + bWn + r * (Rn h + bRn)), one fused cell kernel
     gh = X_.new(hp.shape[0], 3 * H)
     X_.mm(hp, R.t(), gh)
-    if h.bias:
-        ghn = X_.bin("add", gh[:, 2 * H:], bR[2 * H:].view(1, H),
-                     save["ghn"][t])
-    else:
-        ghn = X_.copy(gh[:, 2 * H:], save["ghn"][t])
-    rz = X_.bin("add", gx_t[:, :2 * H], gh[:, :2 * H])
-    X_.un("sigmoid", rz, save["acts"][t][:, :2 * H])
-    r, z = save["acts"][t][:, :H], save["acts"][t][:, H:2 * H]
-    pre_n = X_.bin("add", gx_t[:, 2 * H:], X_.bin("mul", r, ghn))
-    n = X_.un("tanh", pre_n, save["acts"][t][:, 2 * H:])
-    h_new = X_.bin("add", n, X_.bin("mul", z, X_.bin("sub", hp, n)))
+    h_new = X_.new(*hp.shape)
+    X_.m.gru_cell_fwd(gx_t, gh, bR[2 * H:] if h.bias else None, hp, h_new,
+                      save["acts"][t], save["ghn"][t])
     return h_new, None
+
+
+def _contig(X_, t):
+    return t if t.is_contiguous() else X_.copy(t, X_.new(*t.shape))
+
+
+def _whole_sequence(X_, h, mask, dtype):
+    """True when the single-launch LSTM kernels cover this configuration
+    (``SINGA_LSTM_SEQ=0`` forces the per-step path)."""
+    return h.mode == 2 and mask is None and \
+        os.environ.get("SINGA_LSTM_SEQ", "1") != "0" and \
+        X_.m.lstm_seq_supported(h.batch_size, h.hidden_size, dtype)
 
 
 def _forward(h, x, hx, cx, W, lens, training):
@@ -227,6 +238,15 @@ def _forward(h, x, hx, cx, W, lens, training):
             hp = hx[p]
             cp = cx[p] if h.mode == 2 else None
             order = range(T) if d == 0 else range(T - 1, -1, -1)
+            if _whole_sequence(X_, h, mask, gx.dtype):
+                save["h0"], save["c0"] = _contig(X_, hp), _contig(X_, cp)
+                save["seq"] = True
+                X_.m.lstm_seq_fwd(gx, _contig(X_, R), save["h0"], save["c0"],
+                                  save["hseq"], save["cseq"], save["acts"],
+                                  h._bar, d == 1)
+                last = order[-1]
+                hp, cp = save["hseq"][last], save["cseq"][last]
+                order = ()
             for t in order:
                 h_new, c_new = _cell_fwd(X_, h, gx[t], hp, cp, R, bR, save, t)
                 if mask is not None:
@@ -266,43 +286,26 @@ def _forward(h, x, hx, cx, W, lens, training):
     return Y, hy, cy
 
 
-def _cell_bwd(X_, h, dh_new, dc_new, save, t, hp, cp, R):
-    """Gradients of one step: returns (dG_x row, dG_h row or None, dh_prev from
-    the point-wise part, dc_prev)."""
-    H, mode = h.hidden_size, h.mode
+def _cell_bwd(X_, h, dh_new, dc_new, save, t, hp, cp, dgx_t, dgh_t):
+    """Gradients of one step, one fused kernel: fills the gate-gradient rows
+    ``dgx_t`` (and ``dgh_t`` for GRU, whose recurrent projection sees a
+    different gradient for the n gate); returns (dh_prev from the point-wise
+    part or None, dc_prev or None)."""
+    mode = h.mode
     if mode == 2:
         c_t = save["cnew"][t] if save["cnew"] is not None else save["cseq"][t]
-        dg = X_.new(hp.shape[0], 4 * H)
         dcp = X_.new(*hp.shape)
-        X_.m.lstm_cell_bwd(dh_new, dc_new, save["acts"][t], cp, c_t, dg, dcp)
-        return dg, None, None, dcp
+        X_.m.lstm_cell_bwd(dh_new, dc_new, save["acts"][t], cp, c_t, dgx_t, dcp)
+        return None, dcp
     if mode in (0, 1):
         h_new = save["hnew"][t] if save["hnew"] is not None \
             else save["hseq"][t]
-        if mode == 1:
-            # dh * (1 - h^2)
-            d = X_.bin("mul", dh_new, X_.sc(
-                "add", X_.sc("mul", X_.bin("mul", h_new, h_new), -1.0), 1.0))
-        else:
-            d = X_.bin("relu_bwd", dh_new, h_new)
-        return d, None, None, None
-    acts = save["acts"][t]
-    r, z, n = acts[:, :H], acts[:, H:2 * H], acts[:, 2 * H:]
-    ghn = save["ghn"][t]
-    one = lambda a: X_.sc("add", X_.sc("mul", a, -1.0), 1.0)  # 1 - a
-    dn = X_.bin("mul", dh_new, one(z))
-    dz = X_.bin("mul", dh_new, X_.bin("sub", hp, n))
-    dhp = X_.bin("mul", dh_new, z)
-    dpre_n = X_.bin("mul", dn, one(X_.bin("mul", n, n)))
-    dr = X_.bin("mul", dpre_n, ghn)
-    dgx = X_.new(hp.shape[0], 3 * H)
-    dgh = X_.new(hp.shape[0], 3 * H)
-    X_.bin("mul", X_.bin("mul", dr, r), one(r), dgx[:, :H])
-    X_.bin("mul", X_.bin("mul", dz, z), one(z), dgx[:, H:2 * H])
-    X_.copy(dpre_n, dgx[:, 2 * H:])
-    X_.copy(dgx[:, :2 * H], dgh[:, :2 * H])
-    X_.bin("mul", dpre_n, r, dgh[:, 2 * H:])
-    return dgx, dgh, dhp, None
+        X_.m.rnn_act_bwd(mode, dh_new, h_new, dgx_t)
+        return None, None
+    dhp = X_.new(*hp.shape)
+    X_.m.gru_cell_bwd(dh_new, save["acts"][t], save["ghn"][t], hp, dgx_t,
+                      dgh_t, dhp)
+    return dhp, None
 
 
 def _backward(h, dy, dhy, dcy, W, dW):
@@ -334,7 +337,14 @@ def _backward(h, dy, dhy, dcy, W, dW):
             dh_state = X_.copy(dhy[p], X_.new(B, H))
             dc_state = X_.copy(dcy[p], X_.new(B, H)) if h.mode == 2 else None
             order = list(range(T)) if d == 0 else list(range(T - 1, -1, -1))
-            for i in range(T - 1, -1, -1):
+            steps = range(T - 1, -1, -1)
+            if save.get("seq"):
+                X_.m.lstm_seq_bwd(_contig(X_, R), save["c0"], save["cseq"],
+                                  save["acts"], dY[:, :, d * H:(d + 1) * H],
+                                  _contig(X_, dhy[p]), _contig(X_, dcy[p]),
+                                  dGx, dhx[p], dcx[p], h._bar, d == 1)
+                steps = ()
+            for i in steps:
                 t = order[i]
                 t_prev = order[i - 1] if i > 0 else None
                 hp = save["hseq"][t_prev] if t_prev is not None else save["h0"]
@@ -350,14 +360,10 @@ def _backward(h, dy, dhy, dcy, W, dW):
                 else:
                     dh_new = X_.bin("add", dh_state, dYd[t])
                     dc_new = dc_state
-                gx_row, gh_row, dhp_pt, dcp = _cell_bwd(
-                    X_, h, dh_new, dc_new, save, t, hp, cp, R)
-                X_.copy(gx_row, dGx[t])
-                if gh_row is not None:
-                    X_.copy(gh_row, dGh[t])
-                rec = gh_row if gh_row is not None else gx_row
+                dhp_pt, dcp = _cell_bwd(X_, h, dh_new, dc_new, save, t, hp, cp,
+                                        dGx[t], dGh[t])
                 dh_prev = X_.new(B, H)
-                X_.mm(rec, R, dh_prev)
+                X_.mm(dGh[t], R, dh_prev)
                 if dhp_pt is not None:
                     X_.bin("add", dh_prev, dhp_pt, dh_prev)
                 if mask is not None:
@@ -369,9 +375,10 @@ def _backward(h, dy, dhy, dcy, W, dW):
                 dh_state = dh_prev
                 if dcp is not None:
                     dc_state = dcp
-            X_.copy(dh_state, dhx[p])
-            if dcx is not None:
-                X_.copy(dc_state, dcx[p])
+            if not save.get("seq"):
+                X_.copy(dh_state, dhx[p])
+                if dcx is not None:
+                    X_.copy(dc_state, dcx[p])
             inp = save["inp"]
             g2 = dGx.view(T * B, G * H)
             X_.mm(g2.t(), inp.view(T * B, n_in), gW)
@@ -412,6 +419,10 @@ def _run_forward(x, hx, cx, W, h, lens, training):
     hy = Tensor(shape, dev, x.data_type())
     cy = Tensor(shape, dev, x.data_type())
     reads = [x, hx, cx, W] + ([lens] if lens is not None else [])
+    if getattr(h, "_bar", None) is None:
+        # barrier words of the single-launch LSTM kernels: arrival counter and
+        # give-up flag (non-zero after a launch = a wait hit its bound)
+        h._bar = torch.zeros(2, dtype=torch.int32, device=dev.torch_device)
     if lens is not None and getattr(h, "_steps", None) is None:
         h._steps = torch.arange(h.seq_length, dtype=torch.float32).view(
             h.seq_length, 1).to(dev.torch_device)

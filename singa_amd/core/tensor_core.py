@@ -1020,23 +1020,77 @@ def SliceOn(t, start, end, axis):
     return out
 
 
+# element types the multi-tensor pack / unpack kernels move
+_PACKABLE = (dtypes.kFloat32, dtypes.kFloat16, dtypes.kBFloat16)
+
+
+def _blockwise(shape, axis):
+    """True when pieces cut along ``axis`` are contiguous blocks of a
+    contiguous tensor of ``shape`` (every earlier axis has extent 1)."""
+    return Product(shape[:axis]) == 1 if axis > 0 else True
+
+
 def ConcatOn(tensors, axis):
+    """Concatenate along ``axis``: one multi-tensor pack kernel when the
+    pieces are contiguous blocks of the result, one strided copy per piece
+    otherwise."""
     tensors = list(tensors)
     axis = int(axis)
     shape = list(tensors[0]._shape)
     shape[axis] = sum(t._shape[axis] for t in tensors)
     out = Tensor(shape, tensors[0]._dev, tensors[0]._dtype)
     sizes = [t._shape[axis] for t in tensors]
+    packed = _blockwise(shape, axis) and len(tensors) > 1 and \
+        out._dtype in _PACKABLE and \
+        all(t._dtype == out._dtype for t in tensors)
+    if packed:
+        tensors = [t if t.is_contiguous() else Contiguous(t) for t in tensors]
 
     def body(*ts):
         o = ts[-1]
+        m = o._dev.math
+        if packed:
+            views = [s.view() for s in ts[:-1]]
+            m.pack(m.pack_plan(views), views, o.view().view(-1))
+            return
         ov = o.view()
         pos = 0
         for s, n in zip(ts[:-1], sizes):
-            o._dev.math.copy(s.view(), ov.narrow(axis, pos, n))
+            m.copy(s.view(), ov.narrow(axis, pos, n))
             pos += n
     _submit(out._dev, "ConcatOn", body, tensors, [out])
     return out
+
+
+def SplitOn(t, sizes, axis):
+    """The pieces of ``t`` along ``axis`` with the given extents, as new
+    tensors produced by ONE graph node (one multi-tensor unpack kernel when
+    the pieces are contiguous blocks)."""
+    axis = int(axis)
+    sizes = [int(n) for n in sizes]
+    assert sum(sizes) == t._shape[axis], "split sizes do not cover the axis"
+    outs = []
+    for n in sizes:
+        shape = list(t._shape)
+        shape[axis] = n
+        outs.append(Tensor(shape, t._dev, t._dtype))
+    packed = _blockwise(t._shape, axis) and len(sizes) > 1 and \
+        t._dtype in _PACKABLE
+    src = t if (not packed or t.is_contiguous()) else Contiguous(t)
+
+    def body(s, *os):
+        m = s._dev.math
+        if packed:
+            views = [o.view() for o in os]
+            m.unpack(m.pack_plan(views), s.view().reshape(-1), views, 1.0)
+            return
+        sv = s.view()
+        pos = 0
+        for o, n in zip(os, sizes):
+            m.copy(sv.narrow(axis, pos, n), o.view())
+            pos += n
+    _submit(t._dev, "SplitOn", body, [src], outs)
+    return outs
 
 
 def ConcatRows(tensors):

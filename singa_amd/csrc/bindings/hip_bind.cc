@@ -512,6 +512,61 @@ PYBIND11_MODULE(_hip, m) {
           "adaptive_update_multi");
   });
 
+  // ---- recurrent cells and the persistent LSTM ----------------------------------------------------------
+  m.def("gru_cell_fwd", [](int dt, uintptr_t gx, uintptr_t gh, uintptr_t brn,
+                           uintptr_t hp, uintptr_t h, uintptr_t acts,
+                           uintptr_t ghn, int64_t batch, int64_t hidden,
+                           uintptr_t s) {
+    check(sa_gru_cell_fwd(dt, CP(gx), CP(gh), CP(brn), CP(hp), P(h), P(acts),
+                          P(ghn), batch, hidden, S(s)),
+          "gru_cell_fwd");
+  });
+  m.def("gru_cell_bwd", [](int dt, uintptr_t dh, uintptr_t acts, uintptr_t ghn,
+                           uintptr_t hp, uintptr_t dgx, uintptr_t dgh,
+                           uintptr_t dhp, int64_t batch, int64_t hidden,
+                           uintptr_t s) {
+    check(sa_gru_cell_bwd(dt, CP(dh), CP(acts), CP(ghn), CP(hp), P(dgx), P(dgh),
+                          P(dhp), batch, hidden, S(s)),
+          "gru_cell_bwd");
+  });
+  m.def("rnn_act_bwd", [](int dt, int mode, uintptr_t dh, uintptr_t h,
+                          uintptr_t d, int64_t total, uintptr_t s) {
+    check(sa_rnn_act_bwd(dt, mode, CP(dh), CP(h), P(d), total, S(s)),
+          "rnn_act_bwd");
+  });
+  m.def("lstm_seq_supported", [](int64_t batch, int64_t hidden) {
+    return sa_lstm_seq_supported(batch, hidden) != 0;
+  });
+  m.def("lstm_seq_fwd", [](uintptr_t gx, uintptr_t R, uintptr_t h0,
+                           uintptr_t c0, uintptr_t hseq, uintptr_t cseq,
+                           uintptr_t acts, uintptr_t bar, int batch, int hidden,
+                           int steps, int reverse, uintptr_t s) {
+    LstmSeqArgs a{};
+    a.gx = (const float *)CP(gx); a.R = (const float *)CP(R);
+    a.h0 = (const float *)CP(h0); a.c0 = (const float *)CP(c0);
+    a.hseq = (float *)P(hseq); a.cseq = (float *)P(cseq);
+    a.acts = (float *)P(acts); a.bar = (unsigned *)P(bar);
+    a.batch = batch; a.hidden = hidden; a.steps = steps; a.reverse = reverse;
+    check(sa_lstm_seq(&a, 0, S(s)), "lstm_seq_fwd");
+  });
+  m.def("lstm_seq_bwd", [](uintptr_t R, uintptr_t c0, uintptr_t cseq,
+                           uintptr_t acts, uintptr_t dy, int64_t dy_stride,
+                           uintptr_t dhy, uintptr_t dcy, uintptr_t dgates,
+                           uintptr_t dhx, uintptr_t dcx, uintptr_t slabs,
+                           uintptr_t bar, int batch, int hidden, int steps,
+                           int reverse, uintptr_t s) {
+    LstmSeqArgs a{};
+    a.R = (const float *)CP(R); a.c0 = (const float *)CP(c0);
+    a.cseq = (float *)P(cseq); a.acts = (float *)P(acts);
+    a.dy = (const float *)CP(dy); a.dy_stride = dy_stride;
+    a.dhy = (const float *)CP(dhy); a.dcy = (const float *)CP(dcy);
+    a.dgates = (float *)P(dgates); a.dhx = (float *)P(dhx);
+    a.dcx = (float *)P(dcx); a.slabs = (float *)P(slabs);
+    a.bar = (unsigned *)P(bar);
+    a.batch = batch; a.hidden = hidden; a.steps = steps; a.reverse = reverse;
+    check(sa_lstm_seq(&a, 1, S(s)), "lstm_seq_bwd");
+  });
+
   // ---- fused attention ----------------------------------------------------------------------------------
   py::class_<AttnDesc>(m, "AttnDesc")
       .def(py::init([](uintptr_t q, uintptr_t k, uintptr_t v, uintptr_t mask,

@@ -300,6 +300,33 @@ int sa_lstm_cell_bwd(int dtype, const void *dh, const void *dc_next,
                      const void *acts, const void *c_prev, const void *c,
                      void *dgates, void *dc_prev, int64_t batch,
                      int64_t hidden, hipStream_t s);
+// GRU step: gx / gh are the (batch, 3H) input and recurrent projections (gates
+// r, z, n); saves the activated gates and gh_n + bRn for backward.
+int sa_gru_cell_fwd(int dtype, const void *gx, const void *gh, const void *brn,
+                    const void *h_prev, void *h, void *acts, void *ghn,
+                    int64_t batch, int64_t hidden, hipStream_t s);
+int sa_gru_cell_bwd(int dtype, const void *dh, const void *acts, const void *ghn,
+                    const void *h_prev, void *dgx, void *dgh, void *dh_prev,
+                    int64_t batch, int64_t hidden, hipStream_t s);
+// d = dh * act'(h); mode 0 relu, 1 tanh
+int sa_rnn_act_bwd(int dtype, int mode, const void *dh, const void *h, void *d,
+                   int64_t total, hipStream_t s);
+// Whole-sequence LSTM of one layer and direction in one launch (float32).
+// gx: (T, B, 4H) input projection incl. biases, gates i, f, o, g; R: (4H, H).
+// slabs: 2 * (H / 8) * B * H floats of workspace; bar: two zero-initialised
+// words (arrival counter, give-up flag: non-zero after the launch means a
+// barrier wait ran into its bound and the results are invalid).
+struct LstmSeqArgs {
+  const float *gx, *R, *h0, *c0;
+  float *hseq, *cseq, *acts;            // (T, B, H), (T, B, H), (T, B, 4H)
+  const float *dy, *dhy, *dcy;          // dy rows are dy_stride floats apart
+  float *dgates, *dhx, *dcx, *slabs;
+  unsigned *bar;
+  int64_t dy_stride;
+  int batch, hidden, steps, reverse;
+};
+int sa_lstm_seq_supported(int64_t batch, int64_t hidden);
+int sa_lstm_seq(const LstmSeqArgs *a, int backward, hipStream_t s);
 
 // ---- comm.hip -------------------------------------------------------------------------------------------------------
 // many small tensors <-> one flat bucket: tensor i (counts[i] elements at

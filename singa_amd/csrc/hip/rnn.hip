@@ -1,9 +1,24 @@
-// Fused recurrent cell kernels.  The gate pre-activations (batch, 4H), ordered
-// i, f, o, g, come from two MFMA GEMMs (x W_x and h W_h); one point-wise
-// kernel then produces c, h and the activated gates (saved for backward), and
-// one kernel maps (dh, dc) back to the gate gradients.  This replaces ~20
-// element-wise launches per time step of the composed cell and the pointwise
-// stage of cudnnRNNForwardTraining (reference src/model/operation/rnn.cc).
+// Recurrent kernels.
+//
+// Per-step cells: the gate pre-activations come from MFMA GEMMs (the input
+// projection of a whole sequence is one GEMM; the recurrent product runs per
+// step); ONE point-wise kernel per step then produces the new state and the
+// activated gates saved for backward, and ONE kernel maps the state gradients
+// back to gate gradients -- for LSTM (gates i, f, o, g), GRU (r, z, n) and the
+// tanh / relu cells.  This replaces ~10-20 element-wise launches per step.
+//
+// Persistent LSTM: for hidden sizes up to 256 the whole time loop of one layer
+// and direction runs inside ONE launch.  The hidden units are split over
+// H / 8 workgroups; each keeps its slice of the recurrent matrix in registers
+// as the MFMA B operand for all T steps (32 x 32 x 2 fp32 MFMA, K split over
+// the four waves), keeps its cell state in registers, and exchanges the new
+// hidden state (forward) or its partial dh products (backward) with the other
+// workgroups through L2 behind a counter barrier in global memory.  The
+// barrier wait is bounded: a workgroup that waits too long raises a flag that
+// releases every other wait, so the grid always drains.
+//
+// Takes the place of cudnnRNNForwardTraining / BackwardData (reference
+// src/model/operation/rnn.cc:27-806).
 #include "common.cuh"
 #include "kernels.h"
 
@@ -65,6 +80,337 @@ __global__ void lstm_bwd_kernel(const T *__restrict__ dh,
   }
 }
 
+
+// ---- GRU / tanh / relu cells ------------------------------------------------------------------------
+// gx: x W^T + bW (+ bR for r, z); gh: h R^T; n = tanh(gx_n + r * (gh_n + bRn)).
+template <typename T>
+__global__ void gru_fwd_kernel(const T *__restrict__ gx, const T *__restrict__ gh,
+                               const T *__restrict__ brn,
+                               const T *__restrict__ h_prev, T *__restrict__ h,
+                               T *__restrict__ acts, T *__restrict__ ghn,
+                               int64_t batch, int64_t H) {
+  const int64_t total = batch * H;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += step) {
+    const int64_t b = e / H, j = e - b * H;
+    const T *x = gx + b * 3 * H, *g = gh + b * 3 * H;
+    const float r = sigm(to_f<T>(x[j]) + to_f<T>(g[j]));
+    const float z = sigm(to_f<T>(x[H + j]) + to_f<T>(g[H + j]));
+    const float hn = to_f<T>(g[2 * H + j]) + (brn ? to_f<T>(brn[j]) : 0.f);
+    const float n = tanhf(to_f<T>(x[2 * H + j]) + r * hn);
+    const float hp = to_f<T>(h_prev[e]);
+    h[e] = from_f<T>(n + z * (hp - n));
+    T *a = acts + b * 3 * H;
+    a[j] = from_f<T>(r);
+    a[H + j] = from_f<T>(z);
+    a[2 * H + j] = from_f<T>(n);
+    ghn[e] = from_f<T>(hn);
+  }
+}
+
+template <typename T>
+__global__ void gru_bwd_kernel(const T *__restrict__ dh, const T *__restrict__ acts,
+                               const T *__restrict__ ghn,
+                               const T *__restrict__ h_prev, T *__restrict__ dgx,
+                               T *__restrict__ dgh, T *__restrict__ dh_prev,
+                               int64_t batch, int64_t H) {
+  const int64_t total = batch * H;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += step) {
+    const int64_t b = e / H, j = e - b * H;
+    const T *a = acts + b * 3 * H;
+    const float r = to_f<T>(a[j]), z = to_f<T>(a[H + j]), n = to_f<T>(a[2 * H + j]);
+    const float d = to_f<T>(dh[e]);
+    const float dpre_n = d * (1.f - z) * (1.f - n * n);
+    const float dr = dpre_n * to_f<T>(ghn[e]) * r * (1.f - r);
+    const float dz = d * (to_f<T>(h_prev[e]) - n) * z * (1.f - z);
+    T *ox = dgx + b * 3 * H, *oh = dgh + b * 3 * H;
+    ox[j] = oh[j] = from_f<T>(dr);
+    ox[H + j] = oh[H + j] = from_f<T>(dz);
+    ox[2 * H + j] = from_f<T>(dpre_n);
+    oh[2 * H + j] = from_f<T>(dpre_n * r);
+    dh_prev[e] = from_f<T>(d * z);
+  }
+}
+
+// d = dh * act'(h) for h = tanh(.) (mode 1) or relu(.) (mode 0)
+template <typename T>
+__global__ void rnn_act_bwd_kernel(const T *__restrict__ dh, const T *__restrict__ h,
+                                   T *__restrict__ d, int mode, int64_t total) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += step) {
+    const float hv = to_f<T>(h[e]), g = to_f<T>(dh[e]);
+    d[e] = from_f<T>(mode == 1 ? g * (1.f - hv * hv) : (hv > 0.f ? g : 0.f));
+  }
+}
+
+// ---- persistent LSTM ---------------------------------------------------------------------------------
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kSeqUnits = 8;      // hidden units owned by one workgroup
+constexpr int kSeqMaxTiles = 4;   // batch tiles of 32 rows (batch <= 128)
+constexpr unsigned kSpinLimit = 1u << 21;
+
+__device__ __forceinline__ float ld_agent(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Everything one workgroup hands to another is written with device-scope
+// stores (written through to the level all XCDs see) and read with
+// device-scope loads (never served from this CU's L1), so the barrier itself
+// needs no cache write-back or invalidate: waiting for the stores to complete
+// before signalling is enough.
+__device__ __forceinline__ void st_agent(float *p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// bar[0]: arrivals so far; bar[1]: non-zero once any wait has given up.
+__device__ __forceinline__ void grid_arrive(unsigned *bar) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // stores complete
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void grid_wait(unsigned *bar, unsigned target) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
+           target) {
+      if (__hip_atomic_load(bar + 1, __ATOMIC_RELAXED,
+                            __HIP_MEMORY_SCOPE_AGENT) != 0)
+        break;
+      if (++spins > kSpinLimit) {
+        __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
+// row of the 32x32 MFMA accumulator held in register r of this lane
+__device__ __forceinline__ int acc_row(int r, int lane) {
+  return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+}
+
+// Forward: workgroup w owns hidden units [8w, 8w+8): the 32 gate columns
+// (gate q, unit u) -> column 8q + u.  Per step it computes the (batch x 32)
+// tile h_{t-1} R_w^T, adds the input projection, applies the cell and
+// publishes its 8 columns of h_t.
+template <int HM>
+__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(LstmSeqArgs a) {
+  constexpr int H = 32 * HM, KS = H / 4, KR = KS / 2;
+  __shared__ float part[4][32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, kh = lane >> 5;
+  const int j0 = blockIdx.x * kSeqUnits;
+  const unsigned groups = gridDim.x;
+  const int B = a.batch, T = a.steps;
+  const int tiles = (B + 31) / 32;
+
+  float breg[KR];
+  {
+    const float *row = a.R + (size_t)((n >> 3) * H + j0 + (n & 7)) * H +
+                       wave * KS + kh;
+#pragma unroll
+    for (int i = 0; i < KR; ++i) breg[i] = row[2 * i];
+  }
+  const int pb = tid >> 3, pj = tid & 7;   // point-wise element of this thread
+  float cst[kSeqMaxTiles];
+#pragma unroll
+  for (int mt = 0; mt < kSeqMaxTiles; ++mt) {
+    const int b = mt * 32 + pb;
+    cst[mt] = (mt < tiles && b < B) ? a.c0[(size_t)b * H + j0 + pj] : 0.f;
+  }
+
+  for (int s = 0; s < T; ++s) {
+    const int t = a.reverse ? T - 1 - s : s;
+    const float *hprev =
+        s == 0 ? a.h0 : a.hseq + (size_t)(a.reverse ? t + 1 : t - 1) * B * H;
+    // the input projection does not depend on the recurrence: fetch it
+    // before waiting for the other workgroups
+    float pre[kSeqMaxTiles][4];
+#pragma unroll
+    for (int mt = 0; mt < kSeqMaxTiles; ++mt) {
+      const int b = mt * 32 + pb;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        pre[mt][q] = (mt < tiles && b < B)
+                         ? a.gx[((size_t)t * B + b) * 4 * H + q * H + j0 + pj]
+                         : 0.f;
+    }
+    if (s > 0) grid_wait(a.bar, groups * (unsigned)s);
+#pragma unroll
+    for (int mt = 0; mt < kSeqMaxTiles; ++mt) {
+      if (mt >= tiles) break;
+      const int m = min(mt * 32 + n, B - 1);
+      const float *hp = hprev + (size_t)m * H + wave * KS + kh;
+      float areg[KR];
+#pragma unroll
+      for (int i = 0; i < KR; ++i)
+        areg[i] = s == 0 ? hp[2 * i] : ld_agent(hp + 2 * i);
+      f32x16 acc = {0};
+#pragma unroll
+      for (int i = 0; i < KR; ++i)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[i], breg[i], acc, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[wave][acc_row(r, lane)][n] = acc[r];
+      __syncthreads();
+      const int b = mt * 32 + pb;
+      if (b < B) {
+        float g4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = q * kSeqUnits + pj;
+          g4[q] = pre[mt][q] + part[0][pb][c] + part[1][pb][c] +
+                  part[2][pb][c] + part[3][pb][c];
+        }
+        const float i_ = sigm(g4[0]), f_ = sigm(g4[1]), o_ = sigm(g4[2]);
+        const float g_ = tanhf(g4[3]);
+        const float cn = f_ * cst[mt] + i_ * g_;
+        cst[mt] = cn;
+        const size_t e = ((size_t)t * B + b) * H + j0 + pj;
+        st_agent(a.hseq + e, o_ * tanhf(cn));
+        a.cseq[e] = cn;
+        float *ar = a.acts + ((size_t)t * B + b) * 4 * H + j0 + pj;
+        ar[0] = i_;
+        ar[H] = f_;
+        ar[2 * H] = o_;
+        ar[3 * H] = g_;
+      }
+      __syncthreads();
+    }
+    grid_arrive(a.bar);
+  }
+}
+
+// Backward: the workgroup turns (dh, dc) of its 8 units into the 32 gate
+// gradients it owns, multiplies that (batch x 32) tile by its 32 rows of R to
+// get its share of dh_{t-1} for ALL units, and writes the share into its own
+// slab; after the barrier every workgroup sums the slabs for its units.
+// Slabs are double-buffered on the step parity.
+template <int HM>
+__global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(LstmSeqArgs a) {
+  constexpr int H = 32 * HM, NT = HM, NTW = (NT + 3) / 4;
+  __shared__ float dgs[32][33];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, kh = lane >> 5;
+  const int j0 = blockIdx.x * kSeqUnits;
+  const unsigned groups = gridDim.x;
+  const int B = a.batch, T = a.steps;
+  const int tiles = (B + 31) / 32;
+  const size_t slab = (size_t)B * H;            // one workgroup's share
+  const size_t bank = (size_t)groups * slab;    // one parity
+
+  float breg[NTW][16];
+#pragma unroll
+  for (int u = 0; u < NTW; ++u) {
+    const int nt = wave + 4 * u;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int kk = 2 * i + kh;
+      breg[u][i] = nt < NT ? a.R[(size_t)((kk >> 3) * H + j0 + (kk & 7)) * H +
+                                 nt * 32 + n]
+                           : 0.f;
+    }
+  }
+  const int pb = tid >> 3, pj = tid & 7;
+  float dcst[kSeqMaxTiles];
+#pragma unroll
+  for (int mt = 0; mt < kSeqMaxTiles; ++mt) {
+    const int b = mt * 32 + pb;
+    dcst[mt] = (mt < tiles && b < B) ? a.dcy[(size_t)b * H + j0 + pj] : 0.f;
+  }
+
+  for (int s = 0; s < T; ++s) {
+    const int fi = T - 1 - s;                   // position in forward order
+    const int t = a.reverse ? T - 1 - fi : fi;
+    const int tp = a.reverse ? t + 1 : t - 1;   // step that fed this one
+    if (s > 0) grid_wait(a.bar, groups * (unsigned)s);
+    const float *shares = a.slabs + (size_t)((s + 1) & 1) * bank;
+    float *mine = a.slabs + (size_t)(s & 1) * bank + blockIdx.x * slab;
+#pragma unroll
+    for (int mt = 0; mt < kSeqMaxTiles; ++mt) {
+      if (mt >= tiles) break;
+      const int b = mt * 32 + pb;
+      float dg[4] = {0.f, 0.f, 0.f, 0.f};
+      if (b < B) {
+        const size_t e = ((size_t)t * B + b) * H + j0 + pj;
+        float dhv = a.dy[((size_t)t * B + b) * a.dy_stride + j0 + pj];
+        if (s == 0) {
+          dhv += a.dhy[(size_t)b * H + j0 + pj];
+        } else {
+          const float *p = shares + (size_t)b * H + j0 + pj;
+          for (unsigned w = 0; w < groups; ++w) dhv += ld_agent(p + w * slab);
+        }
+        const float *ar = a.acts + ((size_t)t * B + b) * 4 * H + j0 + pj;
+        const float i_ = ar[0], f_ = ar[H], o_ = ar[2 * H], g_ = ar[3 * H];
+        const float cprev = fi > 0 ? a.cseq[((size_t)tp * B + b) * H + j0 + pj]
+                                   : a.c0[(size_t)b * H + j0 + pj];
+        const float tc = tanhf(a.cseq[e]);
+        const float dcv = dcst[mt] + dhv * o_ * (1.f - tc * tc);
+        dg[0] = dcv * g_ * i_ * (1.f - i_);
+        dg[1] = dcv * cprev * f_ * (1.f - f_);
+        dg[2] = dhv * tc * o_ * (1.f - o_);
+        dg[3] = dcv * i_ * (1.f - g_ * g_);
+        dcst[mt] = dcv * f_;
+        float *out = a.dgates + ((size_t)t * B + b) * 4 * H + j0 + pj;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[q * H] = dg[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dgs[pb][q * kSeqUnits + pj] = dg[q];
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < NTW; ++u) {
+        const int nt = wave + 4 * u;
+        if (nt < NT) {
+          f32x16 acc = {0};
+#pragma unroll
+          for (int i = 0; i < 16; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(dgs[n][2 * i + kh],
+                                                       breg[u][i], acc, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int bb = mt * 32 + acc_row(r, lane);
+            if (bb < B) st_agent(mine + (size_t)bb * H + nt * 32 + n, acc[r]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    grid_arrive(a.bar);
+  }
+  grid_wait(a.bar, groups * (unsigned)T);
+  const float *shares = a.slabs + (size_t)((T + 1) & 1) * bank;
+#pragma unroll
+  for (int mt = 0; mt < kSeqMaxTiles; ++mt) {
+    const int b = mt * 32 + pb;
+    if (mt < tiles && b < B) {
+      const float *p = shares + (size_t)b * H + j0 + pj;
+      float v = 0.f;
+      for (unsigned w = 0; w < groups; ++w) v += ld_agent(p + w * slab);
+      a.dhx[(size_t)b * H + j0 + pj] = v;
+      a.dcx[(size_t)b * H + j0 + pj] = dcst[mt];
+    }
+  }
+}
+
+template <int HM>
+static void launch_lstm_seq(const LstmSeqArgs &a, bool backward, hipStream_t s) {
+  const dim3 grid(32 * HM / kSeqUnits), block(256);
+  if (backward)
+    hipLaunchKernelGGL((lstm_seq_bwd_kernel<HM>), grid, block, 0, s, a);
+  else
+    hipLaunchKernelGGL((lstm_seq_fwd_kernel<HM>), grid, block, 0, s, a);
+}
+
 }  // namespace sa
 
 using namespace sa;
@@ -95,4 +441,71 @@ int sa_lstm_cell_bwd(int dtype, const void *dh, const void *dc_next,
                        (T *)dgates, (T *)dc_prev, batch, hidden);
   });
   return 0;
+}
+
+
+int sa_gru_cell_fwd(int dtype, const void *gx, const void *gh, const void *brn,
+                    const void *h_prev, void *h, void *acts, void *ghn,
+                    int64_t batch, int64_t hidden, hipStream_t s) {
+  const int64_t total = batch * hidden;
+  if (total <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((gru_fwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256),
+                       0, s, (const T *)gx, (const T *)gh, (const T *)brn,
+                       (const T *)h_prev, (T *)h, (T *)acts, (T *)ghn, batch,
+                       hidden);
+  });
+  return 0;
+}
+
+int sa_gru_cell_bwd(int dtype, const void *dh, const void *acts, const void *ghn,
+                    const void *h_prev, void *dgx, void *dgh, void *dh_prev,
+                    int64_t batch, int64_t hidden, hipStream_t s) {
+  const int64_t total = batch * hidden;
+  if (total <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((gru_bwd_kernel<T>), dim3(grid_for(total, 256)), dim3(256),
+                       0, s, (const T *)dh, (const T *)acts, (const T *)ghn,
+                       (const T *)h_prev, (T *)dgx, (T *)dgh, (T *)dh_prev, batch,
+                       hidden);
+  });
+  return 0;
+}
+
+int sa_rnn_act_bwd(int dtype, int mode, const void *dh, const void *h, void *d,
+                   int64_t total, hipStream_t s) {
+  if (total <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((rnn_act_bwd_kernel<T>), dim3(grid_for(total, 256)),
+                       dim3(256), 0, s, (const T *)dh, (const T *)h, (T *)d, mode,
+                       total);
+  });
+  return 0;
+}
+
+// The persistent kernels need: float32, hidden a multiple of 32 up to 256
+// (and one of the instantiated sizes), batch <= 128.
+int sa_lstm_seq_supported(int64_t batch, int64_t hidden) {
+  if (batch < 1 || batch > 32 * kSeqMaxTiles) return 0;
+  switch (hidden) {
+    case 32: case 64: case 96: case 128: case 192: case 256: return 1;
+    default: return 0;
+  }
+}
+
+int sa_lstm_seq(const LstmSeqArgs *args, int backward, hipStream_t s) {
+  const LstmSeqArgs &a = *args;
+  if (!sa_lstm_seq_supported(a.batch, a.hidden) || a.steps < 1) return -3;
+  // barrier counter and give-up flag start at zero for every launch
+  if (hipMemsetAsync(a.bar, 0, 2 * sizeof(unsigned), s) != hipSuccess) return -1;
+  switch (a.hidden / 32) {
+    case 1: launch_lstm_seq<1>(a, backward != 0, s); break;
+    case 2: launch_lstm_seq<2>(a, backward != 0, s); break;
+    case 3: launch_lstm_seq<3>(a, backward != 0, s); break;
+    case 4: launch_lstm_seq<4>(a, backward != 0, s); break;
+    case 6: launch_lstm_seq<6>(a, backward != 0, s); break;
+    case 8: launch_lstm_seq<8>(a, backward != 0, s); break;
+    default: return -3;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }

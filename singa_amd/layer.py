@@ -19,6 +19,7 @@ and the layer classes).  ``CudnnRNN`` keeps its reference name and is backed by
 the fused HIP recurrent kernels.
 """
 import math
+import os
 from collections import OrderedDict
 from functools import wraps
 
@@ -633,8 +634,8 @@ class RNN(RNN_Base):
 class LSTM(RNN_Base):
     """LSTM unrolled over a list of per-step inputs.  Parameters keep the
     reference layout (8 weight matrices + 8 bias vectors: Wx_/Wh_/Bx_/Bh_ for
-    gates i, f, o, g); each time step runs as two GEMMs over the concatenated
-    gate weights plus one fused cell kernel."""
+    gates i, f, o, g).  ``forward`` runs the whole sequence as one operator;
+    ``forward_unrolled`` / ``step_forward`` give the step-by-step forms."""
 
     _gates = ("i", "f", "o", "g")
 
@@ -661,6 +662,20 @@ class LSTM(RNN_Base):
         xs = list(xs)
         self.device_check(*xs, h, c)
         self.device_check(xs[0], *self._own('param'))
+        for x in xs:
+            assert x.shape[0] == xs[0].shape[0], "batch size changed mid-sequence"
+        if os.environ.get("SINGA_LSTM_UNROLLED") == "1":
+            return self.forward_unrolled(xs, (h, c))
+        # the whole sequence is one operator (one GEMM for the input
+        # projection of all steps, single-launch recurrence on the GPU)
+        handles = vars(self).setdefault('_handles', {})
+        out, c = rnn_cells.lstm_sequence(xs, h, c, self._own('param'), handles)
+        return out, out[-1], c
+
+    def forward_unrolled(self, xs, h0_c0):
+        """The same computation as a chain of per-step operators."""
+        h, c = h0_c0
+        xs = list(xs)
         # gate-concatenated views of the parameters, built once per call
         Wx = autograd.cat(self._family("Wx_"), 1)
         Wh = autograd.cat(self._family("Wh_"), 1)
@@ -668,7 +683,6 @@ class LSTM(RNN_Base):
                          autograd.cat(self._family("Bh_"), 0))
         out = []
         for x in xs:
-            assert x.shape[0] == xs[0].shape[0], "batch size changed mid-sequence"
             h, c = self._fused_step(x, h, c, Wx, Wh, B)
             out.append(h)
         return out, h, c

@@ -62,7 +62,32 @@ CASES = [("lstm", 1, False), ("lstm", 2, True), ("gru", 1, False),
 
 @pytest.mark.parametrize("kind,layers,bidir", CASES)
 def test_rnn_forward_backward(dev, kind, layers, bidir):
-    T, B, n_in, H = 5, 3, 4, 6
+    _check_against_torch(dev, kind, layers, bidir, 5, 3, 4, 6)
+
+
+# the shapes of the character-level example (batch 32, 64 steps, hidden 128),
+# a hidden size / batch that needs two row tiles and masked tile edges, and the
+# smallest hidden size of the single-launch LSTM kernels
+LARGE = [("lstm", 1, False, 64, 32, 128, 128), ("lstm", 2, True, 64, 32, 128, 128),
+         ("lstm", 1, True, 17, 40, 24, 256), ("lstm", 1, False, 9, 5, 7, 32),
+         ("gru", 1, True, 64, 32, 128, 128), ("tanh", 1, True, 64, 32, 128, 128),
+         ("relu", 1, False, 64, 32, 128, 128)]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,layers,bidir,T,B,n_in,H", LARGE)
+def test_rnn_example_sized_gpu(gpu_dev, kind, layers, bidir, T, B, n_in, H):
+    handle = _check_against_torch(gpu_dev, kind, layers, bidir, T, B, n_in, H,
+                                  tol=4.0, scale=0.3)
+    if kind == "lstm":
+        # the single-launch kernels ran and no barrier wait hit its bound
+        assert all(s.get("seq") for per_dir in handle.reserve["layers"]
+                   for s in per_dir)
+        assert handle._bar.cpu().tolist()[1] == 0
+
+
+def _check_against_torch(dev, kind, layers, bidir, T, B, n_in, H, tol=1.0,
+                         scale=1.0):
     D = 2 if bidir else 1
     x = RS.randn(T, B, n_in).astype(np.float32)
     hx = RS.randn(layers * D, B, H).astype(np.float32) * 0.5
@@ -72,6 +97,10 @@ def test_rnn_forward_backward(dev, kind, layers, bidir):
                                   1 if bidir else 0)
     torch.manual_seed(0)
     net = _torch_net(kind, n_in, H, layers, bidir)
+    if kind == "relu" and scale != 1.0:
+        with torch.no_grad():       # keep 64 un-squashed steps bounded
+            for p_ in net.parameters():
+                p_.mul_(scale)
     W_np = np.zeros(handle.weights_size, np.float32)
     _fill_weights(handle, net, W_np)
     assert handle.weights_size == sum(p.numel() for p in net.parameters())
@@ -88,12 +117,15 @@ def test_rnn_forward_backward(dev, kind, layers, bidir):
     else:
         yt, hn = net(xt, h0)
     np.testing.assert_allclose(tensor.to_numpy(tensor.from_raw_tensor(y)),
-                               yt.detach().numpy(), rtol=1e-4, atol=1e-5)
+                               yt.detach().numpy(), rtol=1e-4 * tol,
+                               atol=1e-5 * tol)
     np.testing.assert_allclose(tensor.to_numpy(tensor.from_raw_tensor(hy)),
-                               hn.detach().numpy(), rtol=1e-4, atol=1e-5)
+                               hn.detach().numpy(), rtol=1e-4 * tol,
+                               atol=1e-5 * tol)
     if kind == "lstm":
         np.testing.assert_allclose(tensor.to_numpy(tensor.from_raw_tensor(cy)),
-                                   cn.detach().numpy(), rtol=1e-4, atol=1e-5)
+                                   cn.detach().numpy(), rtol=1e-4 * tol,
+                                   atol=1e-5 * tol)
     # backward with random upstream gradients on y, hy (and cy)
     dy = RS.randn(*yt.shape).astype(np.float32)
     dhy = RS.randn(*hn.shape).astype(np.float32)
@@ -106,13 +138,18 @@ def test_rnn_forward_backward(dev, kind, layers, bidir):
     dx, dhx, dcx, dW = singa.RNNBackward(y, T_(dy), T_(dhy), T_(dcy), tW.data,
                                          thx.data, tcx.data, tx.data, handle)
     n = lambda c: tensor.to_numpy(tensor.from_raw_tensor(c))
-    np.testing.assert_allclose(n(dx), xt.grad.numpy(), rtol=1e-3, atol=1e-4)
-    np.testing.assert_allclose(n(dhx), h0.grad.numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(n(dx), xt.grad.numpy(), rtol=1e-3 * tol,
+                               atol=1e-4 * tol)
+    np.testing.assert_allclose(n(dhx), h0.grad.numpy(), rtol=1e-3 * tol,
+                               atol=1e-4 * tol)
     if kind == "lstm":
-        np.testing.assert_allclose(n(dcx), c0.grad.numpy(), rtol=1e-3,
-                                   atol=1e-4)
-    np.testing.assert_allclose(n(dW), _torch_grads(handle, net), rtol=1e-3,
-                               atol=1e-4)
+        np.testing.assert_allclose(n(dcx), c0.grad.numpy(), rtol=1e-3 * tol,
+                                   atol=1e-4 * tol)
+    # weight gradients sum T * B products: compare against their own scale
+    ref = _torch_grads(handle, net)
+    np.testing.assert_allclose(n(dW), ref, rtol=1e-3 * tol,
+                               atol=1e-4 * tol * max(1.0, np.abs(ref).max()))
+    return handle
 
 
 @pytest.mark.parametrize("kind", ["lstm", "gru"])
@@ -190,3 +227,53 @@ def test_cudnn_rnn_layer_trains(dev, mode, return_sequences):
     g = tensor.to_numpy(grads[id(rnn.W)])
     assert g.shape == (rnn.handle.weights_size,)
     assert np.isfinite(g).all() and np.abs(g).sum() > 0
+
+
+def _lstm_layer_run(dev, unrolled, T, B, n_in, H):
+    autograd.training = True
+    rs = np.random.RandomState(11)
+    xs = [tensor.Tensor(device=dev, data=rs.randn(B, n_in).astype(np.float32))
+          for _ in range(T)]
+    h0 = tensor.Tensor(device=dev, data=rs.randn(B, H).astype(np.float32))
+    c0 = tensor.Tensor(device=dev, data=rs.randn(B, H).astype(np.float32))
+    h0.requires_grad = c0.requires_grad = True
+    h0.stores_grad = c0.stores_grad = True
+    lstm = layer.LSTM(n_in, H)
+    lstm.initialize(xs, (h0, c0))
+    for name, p in sorted(lstm.get_params().items()):
+        p.copy_from_numpy(rs.randn(*p.shape).astype(np.float32) * 0.2)
+    run = lstm.forward_unrolled if unrolled else lstm.forward
+    out, h, c = run(xs, (h0, c0))
+    w = [rs.randn(B, H).astype(np.float32) for _ in range(T + 1)]
+    total = autograd.mul(c, tensor.Tensor(device=dev, data=w[T]))
+    for o, wt in zip(out, w):
+        total = autograd.add(total, autograd.mul(
+            o, tensor.Tensor(device=dev, data=wt)))
+    total = autograd.add(total, autograd.mul(h, h))   # h is out[-1] again
+    loss = autograd.reshape(autograd.reduce_sum(total, None, 0), (1,))
+    grads = {p.name: tensor.to_numpy(g) for p, g in autograd.backward(loss)}
+    return [tensor.to_numpy(o) for o in out] + [tensor.to_numpy(c)], grads
+
+
+@pytest.mark.parametrize("T,B,n_in,H", [(4, 3, 5, 6), (7, 2, 3, 32)])
+def test_lstm_layer_sequence_operator_matches_unrolled(dev, T, B, n_in, H):
+    """``layer.LSTM.forward`` (one operator for the whole sequence) equals the
+    chain of per-step operators, outputs and every gradient."""
+    y_seq, g_seq = _lstm_layer_run(dev, False, T, B, n_in, H)
+    y_ref, g_ref = _lstm_layer_run(dev, True, T, B, n_in, H)
+    for a, b in zip(y_seq, y_ref):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-5)
+    assert len(g_seq) == len(g_ref) == 18          # 16 parameters, h0, c0
+    for (ka, a), (kb, b) in zip(sorted(g_seq.items()), sorted(g_ref.items())):
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_lstm_layer_sequence_example_sized_gpu(gpu_dev):
+    y_seq, g_seq = _lstm_layer_run(gpu_dev, False, 64, 32, 101, 128)
+    y_ref, g_ref = _lstm_layer_run(gpu_dev, True, 64, 32, 101, 128)
+    for a, b in zip(y_seq, y_ref):
+        np.testing.assert_allclose(a, b, rtol=1e-3, atol=1e-4)
+    for (ka, a), (kb, b) in zip(sorted(g_seq.items()), sorted(g_ref.items())):
+        np.testing.assert_allclose(a, b, rtol=2e-3,
+                                   atol=2e-4 * max(1.0, np.abs(b).max()))

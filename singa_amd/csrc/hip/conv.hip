@@ -1031,6 +1031,8 @@ int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                 const void *bias, void *y, hipStream_t s) {
   if (!geom_ok(g)) return -2;
   if (sa_dwconv_applies(g)) return sa_dwconv_fwd(dtype, g, x, w, bias, y, s);
+  if (sa_conv3x3_applies(dtype, g, g->C))
+    return sa_conv3x3_fwd(g, x, w, bias, y, s);
   ConvArgs a = make_args(*g, CONV_FWD);
   a.a = w; a.b = x; a.out = y; a.bias = bias;
   a.a_elems = (int64_t)g->K * a.Cg * a.RS;
@@ -1059,6 +1061,8 @@ int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
   if (addend == dx) return -2;
   if (sa_dwconv_applies(g))
     return sa_dwconv_bwd_data(dtype, g, dy, w, addend, dx, s);
+  if (sa_conv3x3_applies(dtype, g, g->K))
+    return sa_conv3x3_bwd_data(g, dy, w, addend, dx, s);
   ConvArgs base = make_args(*g, CONV_BWD_DATA);
   base.a = w; base.b = dy; base.out = dx;
   base.a_elems = (int64_t)g->K * base.Cg * base.RS;

@@ -172,6 +172,16 @@ int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
 int sa_conv_bwd_bias(int dtype, const void *dy, void *db, int N, int K,
                      int PQ, hipStream_t s);
 
+// ---- conv3x3.hip ------------------------------------------------------------------------------
+// Direct halo-tile kernel for float32 3x3 / stride 1 / pad 1 convolutions
+// (forward and backward-data); the sa_conv_* entry points route to it.
+// reduce_channels: C for forward, K for backward-data.
+bool sa_conv3x3_applies(int dtype, const ConvGeom *g, int reduce_channels);
+int sa_conv3x3_fwd(const ConvGeom *g, const void *x, const void *w,
+                   const void *bias, void *y, hipStream_t s);
+int sa_conv3x3_bwd_data(const ConvGeom *g, const void *dy, const void *w,
+                        const void *addend, void *dx, hipStream_t s);
+
 // ---- depthwise.hip ----------------------------------------------------------------------------
 // groups == C == K.  The sa_conv_* entry points route such geometries here
 // themselves; the filter gradient has kernels for 3x3, 5x5 and 7x7 windows.

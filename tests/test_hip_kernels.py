@@ -493,6 +493,41 @@ def test_conv1x1_16bit_gemm_path(maths, dt, N, C, H, W, K):
     close(dx, rdx + add.float())
 
 
+@pytest.mark.parametrize("N,C,K,HW", [(2, 16, 64, 56), (3, 24, 96, 28),
+                                      (2, 64, 40, 14), (1, 8, 128, 56),
+                                      (2, 72, 64, 28)])
+def test_conv3x3_float32_halo_path(maths, N, C, K, HW):
+    """float32 3x3 / stride 1 / pad 1 convolutions on 56 / 28 / 14 pixel rows
+    run on the direct halo-tile kernel (forward with bias, backward-data with
+    and without the fused addend); channel counts exercise several 8-channel
+    chunks and a partial 64-channel output tile."""
+    hm, cm, dev = maths
+    x = rnd(N, C, HW, HW, seed=50)
+    w = rnd(K, C, 3, 3, seed=51, lo=-0.3, hi=0.3)
+    b = rnd(K, seed=52)
+
+    def close(got, ref):
+        ref = ref.numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got.cpu().numpy(), ref, atol=2e-5 * scale,
+                                   rtol=1e-4)
+
+    ry = torch.empty(N, K, HW, HW)
+    cm.conv_fwd(x, w, b, ry, (1, 1), (1, 1), 1)
+    y = torch.empty(N, K, HW, HW, device=dev.torch_device)
+    hm.conv_fwd(g(x, dev), g(w, dev), g(b, dev), y, (1, 1), (1, 1), 1)
+    close(y, ry)
+    dy = rnd(N, K, HW, HW, seed=53)
+    add = rnd(N, C, HW, HW, seed=54)
+    rdx = torch.empty(N, C, HW, HW)
+    cm.conv_bwd_data(dy, w, rdx, (1, 1), (1, 1), 1)
+    dx = torch.empty(N, C, HW, HW, device=dev.torch_device)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (1, 1), (1, 1), 1)
+    close(dx, rdx)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (1, 1), (1, 1), 1, g(add, dev))
+    close(dx, rdx + add)
+
+
 @pytest.mark.parametrize("shape", [(8, 16, 14, 14), (32, 64, 7, 7), (16, 10),
                                    (4, 3, 33, 17)])
 def test_batchnorm(maths, shape):

@@ -65,6 +65,7 @@ def _is_linear(shp, st):
 
 _CONV_AUTOTUNE = os.environ.get("SINGA_CONV_AUTOTUNE", "1") != "0"
 _CONV1X1_GEMM = os.environ.get("SINGA_CONV1X1_GEMM", "1") != "0"
+_CONV3X3_GEMM = os.environ.get("SINGA_CONV3X3_GEMM", "1") != "0"
 
 class HipMath(object):
     name = "hip"
@@ -517,6 +518,25 @@ class HipMath(object):
                 and w.shape[2] == 1 and w.shape[3] == 1 and groups == 1 and
                 tuple(stride) == (1, 1) and tuple(pad) == (0, 0))
 
+    @staticmethod
+    def _window16(x, w, stride, pad, groups):
+        """16-bit 3x3 / stride 1 / pad 1 convolution: nine shifted GEMMs per
+        image accumulated inside one launch of the tiled 16-bit kernel."""
+        return (_CONV3X3_GEMM and x.dtype in (torch.float16, torch.bfloat16)
+                and w.shape[2] == 3 and w.shape[3] == 3 and groups == 1 and
+                tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and
+                x.is_contiguous())
+
+    def _conv3x3_h16(self, mode, act, w, addend, out):
+        """Run the nine-tap GEMM; False when the geometry does not fit."""
+        N, _, H, W = act.shape
+        K, C = w.shape[0], w.shape[1]
+        wt = torch.empty(9 * K * C, dtype=w.dtype, device=w.device)
+        return self.k.conv3x3_h16(
+            _code(act), mode, N, C, K, H, W, act.data_ptr(), w.data_ptr(),
+            wt.data_ptr(), addend.data_ptr() if addend is not None else 0,
+            out.data_ptr(), self._s())
+
     def conv_fwd(self, x, w, b, y, stride, pad, groups):
         w = self._contig(w)
         if b is None and self._pointwise16(x, w, stride, pad, groups):
@@ -525,6 +545,9 @@ class HipMath(object):
                                   x.data_ptr(), w.data_ptr(), 0, y.data_ptr(),
                                   self._s()):
                 return
+        if b is None and self._window16(x, w, stride, pad, groups) and \
+                self._conv3x3_h16(0, x, w, None, y):
+            return
         g = self._geom(x.shape, w.shape, y.shape, stride, pad, groups)
         scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)
             g, y, w.shape[0] // groups, y.shape[0] * y.shape[2] * y.shape[3],
@@ -553,6 +576,14 @@ class HipMath(object):
                                   dy.data_ptr(), w.data_ptr(),
                                   ad.data_ptr() if ad is not None else 0,
                                   dx.data_ptr(), self._s()):
+                return
+        if self._window16(dy, w, stride, pad, groups):
+            ad = None
+            if addend is not None:
+                assert addend.shape == dx.shape and addend.dtype == dx.dtype \
+                    and addend.data_ptr() != dx.data_ptr()
+                ad = self._contig(addend)
+            if self._conv3x3_h16(1, dy, w, ad, dx):
                 return
         g = self._geom(dx.shape, w.shape, dy.shape, stride, pad, groups)
         scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)

@@ -256,6 +256,15 @@ PYBIND11_MODULE(_hip, m) {
     check(rc, "conv1x1_h16");
     return true;
   });
+  m.def("conv3x3_h16", [](int dt, int mode, int n_img, int C, int K, int H,
+                          int W, uintptr_t act, uintptr_t w, uintptr_t wt,
+                          uintptr_t addend, uintptr_t out, uintptr_t s) {
+    const int rc = sa_conv3x3_h16(dt, mode, n_img, C, K, H, W, CP(act), CP(w),
+                                  P(wt), CP(addend), P(out), S(s));
+    if (rc == -3) return false;
+    check(rc, "conv3x3_h16");
+    return true;
+  });
   m.def("conv_bwd_data", [](int dt, const ConvGeom &g, uintptr_t dy,
                             uintptr_t w, uintptr_t dx, uintptr_t s) {
     check(sa_conv_bwd_data(dt, &g, CP(dy), CP(w), P(dx), S(s)),

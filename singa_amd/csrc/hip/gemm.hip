@@ -17,6 +17,9 @@
 //
 // Replaces cublasSgemm / cublasHgemm / cublasSgemmStridedBatched / cublasSgemv
 // of the reference (tensor_math_cuda.h:1129-1272).
+#include <algorithm>
+#include <type_traits>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -698,6 +701,232 @@ static void launch_h16_auto(const GemmArgs &g, bool a_kc, bool b_kc,
   else launch_h16_fast<T>(g, a_kc, b_kc, batch, s);
 }
 
+// ---------------------------------------------------------------------------
+// 16-bit 3x3 / stride 1 / pad 1 convolution as a nine-tap GEMM per image
+// ---------------------------------------------------------------------------
+// out[n] (M x HW) = sum over taps (r, s) of  Wt[tap] (M x Kc) * shift(act[n], r, s)
+// where shift() is act[n] (Kc x HW, positions contiguous) read (r - 1) rows and
+// (s - 1) columns away, zero outside the image.  The reduction loop of the
+// tiled 16-bit kernel simply runs over (tap, 64-channel block): the weight
+// tile comes from the tap's slice of the re-laid-out filter [tap][M][Kc]
+// (reduction index contiguous, ds_read_b128 fragments) and the activation tile
+// is the same [channel][position] block for every tap, fetched at a different
+// byte offset.  A one-column shift is a 2-byte offset: such pieces are read as
+// five aligned dwords and funnel-shifted into four.  Positions whose tap falls
+// outside the image are cleared with a per-thread element mask (a thread's
+// pieces always cover the same eight positions, so the four border bit sets
+// are computed once).  16-bit LDS images, transposing LDS reads for the
+// position-contiguous activations, float accumulation, 16-bit output.
+struct ConvTapArgs {
+  const void *wt;      // [9][M][Kc]
+  const void *act;     // [n][Kc][H * W]
+  const void *addend;  // [n][M][H * W] or null
+  void *out;           // [n][M][H * W]
+  int M, Kc, H, W;
+};
+
+template <typename T, int WVM, int WVN, int TM, int TN>
+__global__ void __launch_bounds__(64 * WVM * WVN)
+conv3x3_h16_kernel(ConvTapArgs a, int ntm, int ntn) {
+  using namespace h16;
+  using frag = typename Half16<T>::frag;
+  constexpr int NT = 64 * WVM * WVN;
+  constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
+  using OpA = Operand<true, BM, NT>;
+  using OpB = Operand<false, BN, NT>;
+  constexpr int kImgA = BM * BK * 2, kImgB = BN * BK * 2;
+  constexpr int CPR = OpB::CPR, PERB = OpB::PER;
+  __shared__ __attribute__((aligned(16))) char smem[2][kImgA + kImgB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WVN, wn = wid % WVN;
+  int pid_m, pid_n;
+  {
+    const int w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (w >= ntm * ntn) return;
+    pid_m = w % ntm;
+    pid_n = w / ntm;
+  }
+  const int m0 = pid_m * BM, n0 = pid_n * BN;
+  const int H = a.H, W = a.W, HW = H * W, Kc = a.Kc, M = a.M;
+
+  const T *act = (const T *)a.act + (int64_t)blockIdx.z * Kc * HW;
+  T *out = (T *)a.out + (int64_t)blockIdx.z * M * HW;
+  const T *addend =
+      a.addend ? (const T *)a.addend + (int64_t)blockIdx.z * M * HW : nullptr;
+  OpA opa{__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wt), 0,
+                                            9 * M * Kc * 2, 0x00020000),
+          Kc, 1, m0, Kc};
+  const int limit_b = Kc * HW * 2;
+  const rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<T *>(act), 0, limit_b, 0x00020000);
+
+  // the eight positions all of this thread's activation pieces cover
+  const int chb = tid % CPR, krb = tid / CPR;
+  const int pb = n0 + 8 * chb;
+  unsigned top = 0, bottom = 0, left = 0, right = 0, beyond = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = pb + i;
+    if (p >= HW) {
+      beyond |= 1u << i;
+    } else {
+      const int h = p / W, w = p - h * W;
+      if (h == 0) top |= 1u << i;
+      if (h == H - 1) bottom |= 1u << i;
+      if (w == 0) left |= 1u << i;
+      if (w == W - 1) right |= 1u << i;
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[OpA::PER], rb[PERB];
+  int oa[OpA::PER];
+  const int ntc = Kc / BK;
+  const int steps = 9 * ntc;
+
+  auto fetch = [&](int t) {
+    const int tap = t / ntc, kc = (t - tap * ntc) * BK;
+    const int r = tap / 3, sft = tap - 3 * r;
+    opa.plan(tid, kc, oa);
+#pragma unroll
+    for (int j = 0; j < OpA::PER; ++j)
+      if (oa[j] != kOobOff) oa[j] += tap * M * Kc * 2;
+    opa.load(oa, ra);
+    const unsigned inv = beyond | (r == 0 ? top : 0u) | (r == 2 ? bottom : 0u) |
+                         (sft == 0 ? left : 0u) | (sft == 2 ? right : 0u);
+    unsigned keep[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      keep[d] = (((inv >> (2 * d)) & 1u) ? 0u : 0x0000ffffu) |
+                (((inv >> (2 * d + 1)) & 1u) ? 0u : 0xffff0000u);
+    const int shift = (r - 1) * W + (sft - 1);
+#pragma unroll
+    for (int j = 0; j < PERB; ++j) {
+      const int kr = krb + (NT / CPR) * j;
+      const int byte = ((kc + kr) * HW + pb + shift) * 2;
+      // first aligned dword touched; an odd shift needs five dwords
+      const int b0 = sft == 1 ? byte : byte - 2;
+      const int ndw = sft == 1 ? 4 : 5;
+      u32x4 lo;
+      unsigned hi = 0;
+      if (b0 >= 0 && b0 + 4 * ndw <= limit_b) {
+        lo = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, b0, 0, 0));
+        if (sft != 1)
+          hi = __builtin_bit_cast(
+              unsigned,
+              __builtin_amdgcn_raw_buffer_load_b32(rsrc_b, b0 + 16, 0, 0));
+      } else {
+        // the piece hangs over an end of the image block: dword by dword, each
+        // one range-checked on its own (offsets below zero are out of range)
+        // (each offset is redirected on its own so that the loads cannot be
+        // fused back into one wide load, which is range-checked as a whole)
+        auto dw = [&](int o) {
+          const int at = (o >= 0 && o + 4 <= limit_b) ? o : kOobOff;
+          return __builtin_bit_cast(
+              unsigned, __builtin_amdgcn_raw_buffer_load_b32(rsrc_b, at, 0, 0));
+        };
+        lo.x = dw(b0); lo.y = dw(b0 + 4); lo.z = dw(b0 + 8); lo.w = dw(b0 + 12);
+        if (sft != 1) hi = dw(b0 + 16);
+      }
+      u32x4 v = lo;
+      if (sft != 1) {
+        v.x = __builtin_amdgcn_alignbit(lo.y, lo.x, 16);
+        v.y = __builtin_amdgcn_alignbit(lo.z, lo.y, 16);
+        v.z = __builtin_amdgcn_alignbit(lo.w, lo.z, 16);
+        v.w = __builtin_amdgcn_alignbit(hi, lo.w, 16);
+      }
+      v.x &= keep[0]; v.y &= keep[1]; v.z &= keep[2]; v.w &= keep[3];
+      rb[j] = v;
+    }
+  };
+
+  fetch(0);
+  OpA::store(tid, smem[0], ra);
+  OpB::store(tid, smem[0] + kImgA, rb);
+  __syncthreads();
+  for (int t = 0; t < steps; ++t) {
+    const char *as = smem[t & 1], *bs = smem[t & 1] + kImgA;
+    if (t + 1 < steps) fetch(t + 1);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      frag fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = __builtin_bit_cast(
+            frag, OpA::frag(as, (wm * TM + i) * 32, ks, lane));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = __builtin_bit_cast(
+            frag, OpB::frag(bs, (wn * TN + j) * 32, ks, lane));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = Half16<T>::mma(fa[i], fb[j], acc[i][j]);
+    }
+    if (t + 1 < steps) {
+      OpA::store(tid, smem[(t + 1) & 1], ra);
+      OpB::store(tid, smem[(t + 1) & 1] + kImgA, rb);
+    }
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+      if (col >= HW) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) +
+                        4 * (lane >> 5);
+        if (row >= M) continue;
+        float v = acc[i][j][r];
+        if (addend) v += to_f<T>(addend[(int64_t)row * HW + col]);
+        out[(int64_t)row * HW + col] = from_f<T>(v);
+      }
+    }
+}
+
+// Filter re-layout for the nine-tap GEMM.  mode 0 (forward): w is [M][Kc][9],
+// wt[tap][m][k] = w[m][k][tap].  mode 1 (backward-data): w is the forward
+// filter [Kc][M][9] seen from dY's side, wt[tap][m][k] = w[k][m][8 - tap].
+template <typename T>
+__global__ void conv3x3_h16_prep_kernel(const T *__restrict__ w,
+                                        T *__restrict__ wt, int M, int Kc,
+                                        int mode) {
+  const int64_t total = (int64_t)9 * M * Kc;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += step) {
+    const int k = (int)(e % Kc);
+    const int m = (int)((e / Kc) % M);
+    const int tap = (int)(e / ((int64_t)Kc * M));
+    wt[e] = mode == 0 ? w[((int64_t)m * Kc + k) * 9 + tap]
+                      : w[((int64_t)k * M + m) * 9 + (8 - tap)];
+  }
+}
+
+template <typename T, int WVM, int WVN, int TM, int TN>
+static void launch_conv3x3_h16(const ConvTapArgs &a, int n_img, hipStream_t s) {
+  constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
+  const int ntm = (a.M + BM - 1) / BM, ntn = (a.H * a.W + BN - 1) / BN;
+  const dim3 grid((unsigned)(((int64_t)ntm * ntn + 7) / 8 * 8), 1,
+                  (unsigned)n_img);
+  hipLaunchKernelGGL((conv3x3_h16_kernel<T, WVM, WVN, TM, TN>), grid,
+                     dim3(64 * WVM * WVN), 0, s, a, ntm, ntn);
+}
+
 template <int BM, int BN>
 void launch_f32(const GemmArgs &g, int amode, int bmode, dim3 grid,
                 hipStream_t s) {
@@ -914,4 +1143,37 @@ int sa_conv1x1_h16(int dtype, int mode, int64_t n_img, int64_t C, int64_t K,
   if (dtype == kF16) launch_h16_auto<__half>(g, a_kc, false, n_img, s);
   else launch_h16_auto<__hip_bfloat16>(g, a_kc, false, n_img, s);
   return 0;
+}
+
+// 16-bit 3x3 / stride 1 / pad 1 convolution, forward (mode 0) and
+// backward-data (mode 1), as a nine-tap GEMM per image.  `wt` is workspace of
+// 9 * C * K elements for the re-laid-out filter.  Returns -3 when the geometry
+// does not fit (caller uses the implicit-GEMM convolution kernel).
+int sa_conv3x3_h16(int dtype, int mode, int n_img, int C, int K, int H, int W,
+                   const void *act, const void *w, void *wt,
+                   const void *addend, void *out, hipStream_t s) {
+  if (dtype != kF16 && dtype != kBF16) return -1;
+  if (n_img <= 0) return 0;
+  const int M = mode == 0 ? K : C, Kc = mode == 0 ? C : K;
+  auto al16 = [](const void *p) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  };
+  const int64_t HW = (int64_t)H * W;
+  if (Kc % 64 != 0 || M < 8 || W % 2 != 0 || H < 2 || W < 4 ||
+      !al16(act) || !al16(out) || !al16(wt) ||
+      (int64_t)std::max(M, Kc) * HW >= ((int64_t)1 << 29) ||
+      (int64_t)9 * M * Kc >= ((int64_t)1 << 29))
+    return -3;
+  ConvTapArgs a{wt, act, addend, out, M, Kc, H, W};
+  const int64_t total = (int64_t)9 * M * Kc;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    if constexpr (!std::is_same<T, float>::value) {
+      hipLaunchKernelGGL((conv3x3_h16_prep_kernel<T>),
+                         dim3(grid_for(total, 256)), dim3(256), 0, s,
+                         (const T *)w, (T *)wt, M, Kc, mode);
+      if (M <= 64) launch_conv3x3_h16<T, 1, 4, 2, 1>(a, n_img, s);
+      else launch_conv3x3_h16<T, 2, 2, 2, 2>(a, n_img, s);
+    }
+  });
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -119,6 +119,13 @@ int sa_gemm_splitk_reduce(int dtype, const float *part, int splits, int64_t M,
 int sa_conv1x1_h16(int dtype, int mode, int64_t n_img, int64_t C, int64_t K,
                    int64_t HW, const void *act, const void *w,
                    const void *addend, void *out, hipStream_t s);
+// 16-bit 3x3 / stride 1 / pad 1 convolution as a nine-tap GEMM per image:
+// mode 0 forward (act = x, out = y), mode 1 backward-data (act = dy, out = dx,
+// optional addend of dx's shape).  wt: workspace of 9 * C * K elements.
+// Returns -3 when the geometry does not fit.
+int sa_conv3x3_h16(int dtype, int mode, int n_img, int C, int K, int H, int W,
+                   const void *act, const void *w, void *wt,
+                   const void *addend, void *out, hipStream_t s);
 
 // device-to-device copy / zero-fill as kernels (4-byte aligned pointers)
 int sa_copy_bytes(void *dst, const void *src, int64_t bytes, hipStream_t s);

@@ -493,6 +493,46 @@ def test_conv1x1_16bit_gemm_path(maths, dt, N, C, H, W, K):
     close(dx, rdx + add.float())
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,C,K,H,W", [(2, 64, 64, 56, 56), (2, 128, 96, 28, 28),
+                                       (3, 64, 256, 14, 14), (1, 192, 40, 9, 12),
+                                       (2, 64, 64, 7, 8)])
+def test_conv3x3_16bit_tap_gemm_path(maths, dt, N, C, K, H, W):
+    """16-bit 3x3 / stride 1 / pad 1 convolutions without bias run as nine
+    shifted GEMMs per image on the tiled 16-bit kernel (forward and
+    backward-data, with and without the fused addend); reference: fp32
+    convolution on the same rounded inputs."""
+    hm, cm, dev = maths
+    x = rnd(N, C, H, W, seed=60).to(dt)
+    w = rnd(K, C, 3, 3, seed=61, lo=-0.3, hi=0.3).to(dt)
+    eps = 2 ** -10 if dt == torch.float16 else 2 ** -7
+
+    def close(got, ref):
+        ref = ref.numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got.float().cpu().numpy(), ref,
+                                   atol=eps * scale, rtol=2 * eps)
+
+    ry = torch.empty(N, K, H, W)
+    cm.conv_fwd(x.float(), w.float(), None, ry, (1, 1), (1, 1), 1)
+    y = torch.empty(N, K, H, W, device=dev.torch_device, dtype=dt)
+    assert hm._conv3x3_h16(0, g(x, dev), g(w, dev), None, y)
+    close(y, ry)
+    y.zero_()
+    hm.conv_fwd(g(x, dev), g(w, dev), None, y, (1, 1), (1, 1), 1)
+    close(y, ry)
+    dy = rnd(N, K, H, W, seed=62).to(dt)
+    add = rnd(N, C, H, W, seed=63).to(dt)
+    rdx = torch.empty(N, C, H, W)
+    cm.conv_bwd_data(dy.float(), w.float(), rdx, (1, 1), (1, 1), 1)
+    dx = torch.empty_like(x, device=dev.torch_device)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (1, 1), (1, 1), 1)
+    close(dx, rdx)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (1, 1), (1, 1), 1,
+                     g(add, dev))
+    close(dx, rdx + add.float())
+
+
 @pytest.mark.parametrize("N,C,K,HW", [(2, 16, 64, 56), (3, 24, 96, 28),
                                       (2, 64, 40, 14), (1, 8, 128, 56),
                                       (2, 72, 64, 28)])

@@ -66,6 +66,7 @@ def _is_linear(shp, st):
 _CONV_AUTOTUNE = os.environ.get("SINGA_CONV_AUTOTUNE", "1") != "0"
 _CONV1X1_GEMM = os.environ.get("SINGA_CONV1X1_GEMM", "1") != "0"
 _CONV3X3_GEMM = os.environ.get("SINGA_CONV3X3_GEMM", "1") != "0"
+_CONV3X3_GEMM_MIN_HW = int(os.environ.get("SINGA_CONV3X3_GEMM_MIN_HW", "400"))
 
 class HipMath(object):
     name = "hip"
@@ -525,7 +526,9 @@ class HipMath(object):
         return (_CONV3X3_GEMM and x.dtype in (torch.float16, torch.bfloat16)
                 and w.shape[2] == 3 and w.shape[3] == 3 and groups == 1 and
                 tuple(stride) == (1, 1) and tuple(pad) == (1, 1) and
-                x.is_contiguous())
+                x.is_contiguous() and
+                # small images leave the 128-position tiles mostly empty
+                x.shape[2] * x.shape[3] >= _CONV3X3_GEMM_MIN_HW)
 
     def _conv3x3_h16(self, mode, act, w, addend, out):
         """Run the nine-tap GEMM; False when the geometry does not fit."""

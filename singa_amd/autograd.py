@@ -197,13 +197,16 @@ class Operator(object):
         for x in xs:
             assert isinstance(x, Tensor), (
                 "%s takes Tensors, got %s" % (self.name, type(x).__name__))
-        self.requires_grad = any(x.requires_grad for x in xs)
         # inputs whose gradient nobody consumes (data fed to the network):
         # ops may return None for them instead of computing it
         self.x_needs_grad = tuple(
             x.stores_grad or
             (x.requires_grad and not isinstance(x.creator, Dummy))
             for x in xs)
+        # an op fed only by such inputs has nothing to back-propagate, and
+        # neither has anything computed from its outputs alone (e.g. an
+        # attention mask derived from the input ids)
+        self.requires_grad = any(self.x_needs_grad)
         self.src = [(x.creator, x.uid, x if x.stores_grad else None,
                      x.stores_grad) for x in xs]
         produced = self.forward(*(x.data for x in xs))

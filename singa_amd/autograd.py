@@ -1437,12 +1437,15 @@ def squeeze(x, axis=[]):
 
 
 class Transpose(Operator):
+    """Permute the axes; ``perm=None`` reverses them (the ONNX default)."""
 
-    def __init__(self, perm):
+    def __init__(self, perm=None):
         super(Transpose, self).__init__()
-        self.perm = list(perm)
+        self.perm = None if perm is None else list(perm)
 
     def forward(self, x):
+        if self.perm is None:
+            self.perm = list(range(len(x.shape()) - 1, -1, -1))
         return singa.Transpose(x, self.perm)
 
     def backward(self, dy):
@@ -1671,7 +1674,8 @@ class Pad(Operator):
         self.mode = mode
         if self.mode not in ("constant", "reflect", "edge"):
             assert False, ('Only support three modes: constant, reflect, edge')
-        self.constant = constant
+        # an omitted constant_value input means zero
+        self.constant = 0. if constant is None else constant
         self.pads = pads
         self.pad_width = ()
 

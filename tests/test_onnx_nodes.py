@@ -1,0 +1,584 @@
+"""Hand-written ONNX node vectors: one or more (inputs, attributes, expected
+numpy output) cases for every entry of ``SingaBackend._rename_operators``, run
+through ``sonnx.run_node`` (the single-node protocol of the ONNX backend test
+suite).  The case names and attribute combinations follow the official node
+tests the reference enables (reference test/python/test_onnx_backend.py:39-103:
+auto_pad, Slice steps and negative axes, Pad modes, Gather negative axes,
+uneven Split, Clip bounds, keepdims, variadic broadcasting ...); the expected
+values are computed here with numpy from the operator specification, because
+the ``onnx`` package with the official data files is not installed: ONNX
+conformance is "parity unpinned" against the official suite.
+"""
+import numpy as np
+import pytest
+
+from singa_amd import sonnx, tensor
+from singa_amd.onnx_proto import TensorProto, helper
+
+RS = np.random.RandomState(77)
+
+
+def f32(*shape, lo=-1.0, hi=1.0):
+    return (RS.rand(*shape) * (hi - lo) + lo).astype(np.float32)
+
+
+def i64(v):
+    return np.asarray(v, np.int64)
+
+
+CASES = []
+
+
+def case(name, op, inputs, expected, rtol=1e-5, atol=1e-5, **attrs):
+    CASES.append(pytest.param(op, inputs, attrs, expected, rtol, atol,
+                              id=name))
+
+
+# ---------------------------------------------------------------------------
+# element-wise unary
+# ---------------------------------------------------------------------------
+_x = f32(3, 4, 5)
+_pos = f32(3, 4, 5, lo=0.1, hi=3.0)
+_unit = f32(3, 4, 5, lo=-0.9, hi=0.9)
+_ge1 = f32(3, 4, 5, lo=1.1, hi=4.0)
+for _name, _op, _in, _fn in [
+        ("relu", "Relu", _x, lambda a: np.maximum(a, 0)),
+        ("sigmoid", "Sigmoid", _x, lambda a: 1 / (1 + np.exp(-a))),
+        ("cos", "Cos", _x, np.cos), ("cosh", "Cosh", _x, np.cosh),
+        ("sin", "Sin", _x, np.sin), ("sinh", "Sinh", _x, np.sinh),
+        ("tan", "Tan", _x, np.tan), ("tanh", "Tanh", _x, np.tanh),
+        ("acos", "Acos", _unit, np.arccos), ("acosh", "Acosh", _ge1, np.arccosh),
+        ("asin", "Asin", _unit, np.arcsin), ("asinh", "Asinh", _x, np.arcsinh),
+        ("atan", "Atan", _x, np.arctan), ("atanh", "Atanh", _unit, np.arctanh),
+        ("sign", "Sign", _x, np.sign), ("sqrt", "Sqrt", _pos, np.sqrt),
+        ("log", "Log", _pos, np.log), ("identity", "Identity", _x, lambda a: a),
+        ("softplus", "Softplus", _x, lambda a: np.log(np.exp(a) + 1)),
+        ("softsign", "Softsign", _x, lambda a: a / (1 + np.abs(a))),
+        ("neg", "Neg", _x, np.negative),
+        ("reciprocal", "Reciprocal", _pos, np.reciprocal),
+        ("ceil", "Ceil", _x * 3, np.ceil), ("floor", "Floor", _x * 3, np.floor),
+        ("abs", "Abs", _x, np.abs), ("exp", "Exp", _x, np.exp),
+        ("round", "Round", np.array([0.1, 0.5, 0.9, 1.2, 1.5, 1.8, 2.3, 2.5,
+                                     2.7, -1.1, -1.5, -1.9, -2.0, -2.5, -2.8],
+                                    np.float32), np.round),
+        ("erf", "Erf", _x, lambda a: np.vectorize(__import__("math").erf)(a)
+         .astype(np.float32)),
+        ("gelu", "Gelu", _x, lambda a: (0.5 * a * (1 + np.vectorize(
+            __import__("math").erf)(a / np.sqrt(2)))).astype(np.float32))]:
+    case("test_" + _name, _op, [_in], [_fn(_in)], rtol=1e-4, atol=1e-5)
+case("test_relu_example", "Relu", [np.array([-1, 0, 1], np.float32)],
+     [np.array([0, 0, 1], np.float32)])
+
+# activations with attributes
+case("test_leakyrelu", "LeakyRelu", [_x], [np.where(_x > 0, _x, 0.1 * _x)],
+     alpha=0.1)
+case("test_leakyrelu_default", "LeakyRelu", [_x],
+     [np.where(_x > 0, _x, 0.01 * _x)])
+case("test_elu", "Elu", [_x], [np.where(_x > 0, _x, 2.0 * (np.exp(_x) - 1))],
+     alpha=2.0)
+case("test_elu_default", "Elu", [_x],
+     [np.where(_x > 0, _x, 1.0 * (np.exp(_x) - 1))])
+case("test_selu", "Selu", [_x],
+     [3.0 * np.where(_x > 0, _x, 2.0 * (np.exp(_x) - 1))], alpha=2.0,
+     gamma=3.0)
+case("test_selu_default", "Selu", [_x],
+     [1.0507009873554805 * np.where(
+         _x > 0, _x, 1.6732632423543772 * (np.exp(_x) - 1))], rtol=1e-4)
+case("test_hardsigmoid", "HardSigmoid", [_x * 3],
+     [np.clip(0.5 * _x * 3 + 0.6, 0, 1)], alpha=0.5, beta=0.6)
+case("test_hardsigmoid_default", "HardSigmoid", [_x * 3],
+     [np.clip(0.2 * _x * 3 + 0.5, 0, 1)])
+_slope = f32(5, lo=0.0, hi=0.5)
+case("test_prelu_broadcast", "PRelu", [_x, _slope],
+     [np.where(_x > 0, _x, _x * _slope)])
+_slope_full = f32(3, 4, 5, lo=0.0, hi=0.5)
+case("test_prelu_example", "PRelu", [_x, _slope_full],
+     [np.where(_x > 0, _x, _x * _slope_full)])
+
+# ---------------------------------------------------------------------------
+# element-wise binary / variadic, with broadcasting
+# ---------------------------------------------------------------------------
+_a, _b = f32(3, 4, 5), f32(3, 4, 5, lo=0.5, hi=2.0)
+_row = f32(5, lo=0.5, hi=2.0)
+_col = f32(4, 1, lo=0.5, hi=2.0)
+for _name, _op, _fn in [("add", "Add", np.add), ("sub", "Sub", np.subtract),
+                        ("mul", "Mul", np.multiply), ("div", "Div", np.divide)]:
+    case("test_" + _name, _op, [_a, _b], [_fn(_a, _b)])
+    case("test_%s_bcast" % _name, _op, [_a, _row], [_fn(_a, _row)])
+    case("test_%s_bcast_column" % _name, _op, [_a, _col], [_fn(_a, _col)])
+case("test_pow", "Pow", [_pos, _b], [np.power(_pos, _b)], rtol=1e-4)
+case("test_pow_bcast_scalar", "Pow", [_pos, np.array([2.0], np.float32)],
+     [np.power(_pos, 2.0)], rtol=1e-4)
+case("test_pow_bcast_array", "Pow", [_pos, _row], [np.power(_pos, _row)],
+     rtol=1e-4)
+case("test_matmul_2d", "MatMul", [f32(3, 4), f32(4, 3)], None)
+case("test_matmul_3d", "MatMul", [f32(2, 3, 4), f32(2, 4, 3)], None)
+case("test_matmul_4d", "MatMul", [f32(1, 2, 3, 4), f32(1, 2, 4, 3)], None)
+for _name, _op, _fn in [("sum", "Sum", lambda *a: sum(a)),
+                        ("mean", "Mean", lambda *a: sum(a) / len(a)),
+                        ("max", "Max", lambda *a: np.maximum.reduce(
+                            np.broadcast_arrays(*a))),
+                        ("min", "Min", lambda *a: np.minimum.reduce(
+                            np.broadcast_arrays(*a)))]:
+    case("test_%s_one_input" % _name, _op, [_a], [_a])
+    case("test_%s_two_inputs" % _name, _op, [_a, _b], [_fn(_a, _b)])
+    case("test_%s_example" % _name, _op, [_a, _b, _x], [_fn(_a, _b, _x)])
+case("test_max_bcast", "Max", [_a, _row], [np.maximum(_a, _row)])
+case("test_min_bcast", "Min", [_a, _row], [np.minimum(_a, _row)])
+
+# comparisons and logic (outputs are 0 / 1 in the tensor's float type)
+_ia = RS.randint(0, 3, (3, 4, 5)).astype(np.float32)
+_ib = RS.randint(0, 3, (3, 4, 5)).astype(np.float32)
+_irow = RS.randint(0, 3, (5,)).astype(np.float32)
+for _name, _op, _fn in [("equal", "Equal", np.equal), ("less", "Less", np.less),
+                        ("greater", "Greater", np.greater)]:
+    case("test_" + _name, _op, [_ia, _ib], [_fn(_ia, _ib).astype(np.float32)])
+    case("test_%s_bcast" % _name, _op, [_ia, _irow],
+         [_fn(_ia, _irow).astype(np.float32)])
+_ba = (RS.rand(3, 4) > 0.5).astype(np.float32)
+_bb = (RS.rand(3, 4) > 0.5).astype(np.float32)
+_bcol = (RS.rand(4) > 0.5).astype(np.float32)
+for _name, _op, _fn in [("and", "And", np.logical_and),
+                        ("or", "Or", np.logical_or),
+                        ("xor", "Xor", np.logical_xor)]:
+    case("test_%s2d" % _name, _op, [_ba, _bb],
+         [_fn(_ba, _bb).astype(np.float32)])
+    case("test_%s_bcast3v1d" % _name, _op, [_ba, _bcol],
+         [_fn(_ba, _bcol).astype(np.float32)])
+case("test_not_2d", "Not", [_ba], [np.logical_not(_ba).astype(np.float32)])
+_c = (RS.rand(3, 4) > 0.5).astype(np.float32)
+case("test_where_example", "Where", [_c, f32(3, 4), f32(3, 4)], None)
+case("test_where_bcast", "Where", [_c, f32(3, 4), f32(4)], None)
+
+# ---------------------------------------------------------------------------
+# shape manipulation
+# ---------------------------------------------------------------------------
+_s = f32(2, 3, 4)
+case("test_reshape_reordered_all_dims", "Reshape", [_s, i64([4, 2, 3])],
+     [_s.reshape(4, 2, 3)])
+case("test_reshape_negative_dim", "Reshape", [_s, i64([2, -1, 2])],
+     [_s.reshape(2, 6, 2)])
+case("test_reshape_zero_dim", "Reshape", [_s, i64([2, 0, 4, 1])],
+     [_s.reshape(2, 3, 4, 1)])
+case("test_reshape_one_dim", "Reshape", [_s, i64([24])], [_s.reshape(24)])
+case("test_reshape_extended_dims", "Reshape", [_s, i64([2, 3, 2, 2])],
+     [_s.reshape(2, 3, 2, 2)])
+case("test_flatten_axis1", "Flatten", [f32(2, 3, 4, 5)], None, axis=1)
+case("test_flatten_axis2", "Flatten", [f32(2, 3, 4, 5)], None, axis=2)
+case("test_flatten_axis3", "Flatten", [f32(2, 3, 4, 5)], None, axis=3)
+case("test_flatten_axis0", "Flatten", [f32(2, 3, 4, 5)], None, axis=0)
+case("test_flatten_default_axis", "Flatten", [f32(2, 3, 4, 5)], None)
+case("test_flatten_negative_axis1", "Flatten", [f32(2, 3, 4, 5)], None,
+     axis=-1)
+case("test_squeeze", "Squeeze", [f32(1, 3, 1, 5)], None, axes=[0])
+case("test_squeeze_two_axes", "Squeeze", [f32(1, 3, 1, 5)], None, axes=[0, 2])
+case("test_squeeze_negative_axes", "Squeeze", [f32(1, 3, 1, 5)], None,
+     axes=[-2])
+case("test_unsqueeze_axis_0", "Unsqueeze", [f32(3, 4, 5)], None, axes=[0])
+case("test_unsqueeze_axis_1", "Unsqueeze", [f32(3, 4, 5)], None, axes=[1])
+case("test_unsqueeze_two_axes", "Unsqueeze", [f32(3, 4, 5)], None,
+     axes=[1, 4])
+case("test_unsqueeze_negative_axes", "Unsqueeze", [f32(1, 3, 1, 5)], None,
+     axes=[-2])
+case("test_transpose_default", "Transpose", [_s], [_s.transpose()])
+for _perm in [(0, 2, 1), (1, 0, 2), (1, 2, 0), (2, 0, 1), (2, 1, 0)]:
+    case("test_transpose_all_permutations_%d%d%d" % _perm, "Transpose", [_s],
+         [_s.transpose(_perm)], perm=list(_perm))
+_c1, _c2 = f32(2, 3, 4), f32(2, 3, 4)
+for _ax in (0, 1, 2, -1, -2):
+    case("test_concat_3d_axis_%s" % str(_ax).replace("-", "negative_"),
+         "Concat", [_c1, _c2], [np.concatenate([_c1, _c2], _ax)], axis=_ax)
+_sp = f32(6, 4)
+case("test_split_equal_parts_2d", "Split", [_sp], list(np.split(_sp, 2, 1)),
+     axis=1)
+case("test_split_equal_parts_default_axis", "Split", [_sp],
+     list(np.split(_sp, 3, 0)))
+case("test_split_variable_parts_2d", "Split", [_sp],
+     [_sp[:, :1], _sp[:, 1:]], axis=1, split=[1, 3])
+case("test_split_variable_parts_default_axis", "Split", [_sp],
+     [_sp[:2], _sp[2:]], split=[2, 4])
+case("test_split_negative_axis", "Split", [_sp], list(np.split(_sp, 2, -1)),
+     axis=-1)
+_sl = f32(20, 10, 5)
+case("test_slice", "Slice", [_sl, i64([0, 0]), i64([3, 10]), i64([0, 1]),
+                             i64([1, 1])], [_sl[0:3, 0:10]])
+case("test_slice_default_axes", "Slice",
+     [_sl, i64([0, 0, 3]), i64([20, 10, 4])], [_sl[:, :, 3:4]])
+case("test_slice_default_steps", "Slice",
+     [_sl, i64([0, 0, 3]), i64([20, 10, 4]), i64([0, 1, 2])],
+     [_sl[:, :, 3:4]])
+case("test_slice_neg", "Slice", [_sl, i64([0]), i64([-1]), i64([1]),
+                                 i64([1])], [_sl[:, 0:-1]])
+case("test_slice_end_out_of_bounds", "Slice",
+     [_sl, i64([1]), i64([1000]), i64([1]), i64([1])], [_sl[:, 1:1000]])
+case("test_slice_negative_axes", "Slice",
+     [_sl, i64([0, 0, 3]), i64([20, 10, 4]), i64([0, -2, -1])],
+     [_sl[:, :, 3:4]])
+case("test_slice_neg_steps", "Slice",
+     [_sl, i64([20, 10, 4]), i64([0, 0, 1]), i64([0, 1, 2]),
+      i64([-1, -3, -2])], [_sl[20:0:-1, 10:0:-3, 4:1:-2]])
+case("test_slice_steps", "Slice",
+     [_sl, i64([1, 0]), i64([19, 10]), i64([0, 1]), i64([3, 2])],
+     [_sl[1:19:3, 0:10:2]])
+_g = f32(5, 4, 3, 2)
+case("test_gather_0", "Gather", [_g, i64([0, 1, 3])],
+     [np.take(_g, [0, 1, 3], 0)], axis=0)
+case("test_gather_1", "Gather", [_g, i64([0, 1, 3])],
+     [np.take(_g, [0, 1, 3], 1)], axis=1)
+_g33 = f32(3, 3)
+case("test_gather_2d_indices", "Gather", [_g33, i64([[0, 2]])],
+     [np.take(_g33, [[0, 2]], 1)], axis=1)
+case("test_gather_negative_indices", "Gather",
+     [np.arange(10, dtype=np.float32), i64([0, -9, -10])],
+     [np.arange(10, dtype=np.float32)[[0, -9, -10]]], axis=0)
+case("test_gather_negative_axis", "Gather", [_g, i64([1, 0])],
+     [np.take(_g, [1, 0], -2)], axis=-2)
+_t = f32(2, 3)
+case("test_tile", "Tile", [_t, i64([2, 3])], [np.tile(_t, (2, 3))])
+case("test_tile_precomputed", "Tile", [_t, i64([1, 1])], [_t])
+_e = f32(3, 1)
+case("test_expand_dim_changed", "Expand", [_e, i64([2, 1, 6])],
+     [_e * np.ones((2, 1, 6), np.float32)])
+case("test_expand_dim_unchanged", "Expand", [_e, i64([3, 4])],
+     [np.tile(_e, 4)])
+_p = f32(1, 3, 4, 5)
+case("test_constant_pad", "Pad", [_p, i64([0, 0, 1, 3, 0, 0, 2, 4]),
+                                  np.array(1.2, np.float32)],
+     [np.pad(_p, ((0, 0), (0, 0), (1, 2), (3, 4)), constant_values=1.2)],
+     mode="constant")
+case("test_constant_pad_default_value", "Pad",
+     [_p, i64([0, 1, 0, 0, 0, 0, 2, 0])],
+     [np.pad(_p, ((0, 0), (1, 0), (0, 2), (0, 0)))])
+case("test_reflect_pad", "Pad", [_p, i64([0, 0, 1, 1, 0, 0, 1, 1])],
+     [np.pad(_p, ((0, 0), (0, 0), (1, 1), (1, 1)), mode="reflect")],
+     mode="reflect")
+case("test_edge_pad", "Pad", [_p, i64([0, 0, 1, 1, 0, 0, 1, 1])],
+     [np.pad(_p, ((0, 0), (0, 0), (1, 1), (1, 1)), mode="edge")], mode="edge")
+_d = f32(2, 8, 3, 4)
+
+
+def _depth_to_space(x, b, mode):
+    n, c, h, w = x.shape
+    if mode == "DCR":
+        t = x.reshape(n, b, b, c // (b * b), h, w).transpose(0, 3, 4, 1, 5, 2)
+    else:
+        t = x.reshape(n, c // (b * b), b, b, h, w).transpose(0, 1, 4, 2, 5, 3)
+    return t.reshape(n, c // (b * b), h * b, w * b)
+
+
+case("test_depthtospace_dcr_mode", "DepthToSpace", [_d],
+     [_depth_to_space(_d, 2, "DCR")], blocksize=2, mode="DCR")
+case("test_depthtospace_crd_mode", "DepthToSpace", [_d],
+     [_depth_to_space(_d, 2, "CRD")], blocksize=2, mode="CRD")
+case("test_depthtospace_example", "DepthToSpace", [_d],
+     [_depth_to_space(_d, 2, "DCR")], blocksize=2)
+_sd = f32(2, 2, 4, 6)
+case("test_spacetodepth", "SpaceToDepth", [_sd],
+     [_sd.reshape(2, 2, 2, 2, 3, 2).transpose(0, 3, 5, 1, 2, 4)
+      .reshape(2, 8, 2, 3)], blocksize=2)
+_u = f32(1, 2, 2, 3)
+case("test_upsample_nearest", "Upsample",
+     [_u, np.array([1.0, 1.0, 2.0, 3.0], np.float32)],
+     [_u.repeat(2, 2).repeat(3, 3)], mode="nearest")
+case("test_shape", "Shape", [f32(3, 4, 5)], [i64([3, 4, 5])])
+case("test_shape_example", "Shape", [f32(2, 3)], [i64([2, 3])])
+_nz = np.array([[1, 0], [1, 1]], np.float32)
+case("test_nonzero_example", "NonZero", [_nz],
+     [np.array(np.nonzero(_nz), np.int64)])
+
+# ---------------------------------------------------------------------------
+# reductions, softmax, normalisation
+# ---------------------------------------------------------------------------
+_r = f32(3, 2, 2)
+for _op, _fn in (("ReduceSum", np.sum), ("ReduceMean", np.mean)):
+    _n = _op.lower().replace("reduce", "reduce_")
+    case("test_%s_default_axes_keepdims_random" % _n, _op, [_r],
+         [_fn(_r, axis=None, keepdims=True)], keepdims=1)
+    case("test_%s_do_not_keepdims_random" % _n, _op, [_r],
+         [_fn(_r, axis=1, keepdims=False)], axes=[1], keepdims=0)
+    case("test_%s_keepdims_random" % _n, _op, [_r],
+         [_fn(_r, axis=1, keepdims=True)], axes=[1], keepdims=1)
+    case("test_%s_negative_axes_keepdims_random" % _n, _op, [_r],
+         [_fn(_r, axis=-2, keepdims=True)], axes=[-2], keepdims=1)
+    case("test_%s_two_axes" % _n, _op, [_r],
+         [_fn(_r, axis=(0, 2), keepdims=False)], axes=[0, 2], keepdims=0)
+
+
+def _softmax(x, axis):
+    # opset 11: flatten to 2-d at `axis`, softmax over the second dimension
+    shp = x.shape
+    rows = int(np.prod(shp[:axis])) if axis > 0 else 1
+    t = x.reshape(rows, -1)
+    t = np.exp(t - t.max(1, keepdims=True))
+    return (t / t.sum(1, keepdims=True)).reshape(shp)
+
+
+_sm = f32(3, 4, 5)
+case("test_softmax_example", "Softmax",
+     [np.array([[-1, 0, 1]], np.float32)],
+     [_softmax(np.array([[-1, 0, 1]], np.float32), 1)])
+case("test_softmax_large_number", "Softmax",
+     [np.array([[0, 1, 2, 3], [10000, 10001, 10002, 10003]], np.float32)],
+     [_softmax(np.array([[0, 1, 2, 3], [10000, 10001, 10002, 10003]],
+                        np.float32), 1)])
+case("test_softmax_axis_0", "Softmax", [_sm], [_softmax(_sm, 0)], axis=0)
+case("test_softmax_axis_1", "Softmax", [_sm], [_softmax(_sm, 1)], axis=1)
+case("test_softmax_axis_2", "Softmax", [_sm], [_softmax(_sm, 2)], axis=2)
+case("test_softmax_default_axis", "Softmax", [_sm], [_softmax(_sm, 1)])
+case("test_softmax_negative_axis", "Softmax", [_sm], [_softmax(_sm, 2)],
+     axis=-1)
+_gp = f32(2, 3, 5, 5)
+case("test_globalaveragepool", "GlobalAveragePool", [_gp],
+     [_gp.mean((2, 3), keepdims=True)])
+_bx = f32(2, 3, 4, 5)
+_bs, _bb2 = f32(3, lo=0.5, hi=1.5), f32(3)
+_bm, _bv = f32(3), f32(3, lo=0.5, hi=1.5)
+case("test_batchnorm_example", "BatchNormalization",
+     [_bx, _bs, _bb2, _bm, _bv],
+     [(_bx - _bm[None, :, None, None]) /
+      np.sqrt(_bv[None, :, None, None] + 1e-5) * _bs[None, :, None, None] +
+      _bb2[None, :, None, None]], rtol=1e-4, atol=1e-4)
+_ln = f32(4, 6)
+_lg, _lb = f32(6, lo=0.5, hi=1.5), f32(6)
+case("test_layer_normalization_default_axis", "LayerNormalization",
+     [_ln, _lg, _lb],
+     [(_ln - _ln.mean(-1, keepdims=True)) /
+      np.sqrt(_ln.var(-1, keepdims=True) + 1e-5) * _lg + _lb], rtol=1e-4,
+     atol=1e-5)
+case("test_dropout_default", "Dropout", [_x], [_x])
+case("test_dropout_default_ratio", "Dropout", [_x], [_x], ratio=0.3)
+
+# ---------------------------------------------------------------------------
+# Gemm, Conv, pooling
+# ---------------------------------------------------------------------------
+_ga, _gb, _gc = f32(3, 5), f32(5, 4), f32(1, 4)
+case("test_gemm_default_no_bias", "Gemm", [_ga, _gb], [_ga @ _gb], rtol=1e-4)
+case("test_gemm_default_matrix_bias", "Gemm", [_ga, _gb, f32(3, 4) * 0 + _gc],
+     [_ga @ _gb + _gc], rtol=1e-4)
+case("test_gemm_default_vector_bias", "Gemm", [_ga, _gb, _gc],
+     [_ga @ _gb + _gc], rtol=1e-4)
+case("test_gemm_alpha", "Gemm", [_ga, _gb, _gc * 0], [0.5 * (_ga @ _gb)],
+     rtol=1e-4, alpha=0.5)
+case("test_gemm_beta", "Gemm", [_ga, _gb, _gc], [_ga @ _gb + 0.5 * _gc],
+     rtol=1e-4, beta=0.5)
+case("test_gemm_transposeA", "Gemm", [_ga.T.copy(), _gb, _gc],
+     [_ga @ _gb + _gc], rtol=1e-4, transA=1)
+case("test_gemm_transposeB", "Gemm", [_ga, _gb.T.copy(), _gc],
+     [_ga @ _gb + _gc], rtol=1e-4, transB=1)
+case("test_gemm_all_attributes", "Gemm", [_ga.T.copy(), _gb.T.copy(), _gc],
+     [0.25 * (_ga @ _gb) + 0.35 * _gc], rtol=1e-4, alpha=0.25, beta=0.35,
+     transA=1, transB=1)
+
+
+def _conv_ref(x, w, b, stride, pads, group=1):
+    import torch
+    import torch.nn.functional as F
+    xt = torch.from_numpy(x)
+    # pads: top, left, bottom, right
+    xt = F.pad(xt, (pads[1], pads[3], pads[0], pads[2]))
+    y = F.conv2d(xt, torch.from_numpy(w),
+                 None if b is None else torch.from_numpy(b), stride, 0, 1,
+                 group)
+    return y.numpy()
+
+
+def _pool_ref(x, k, stride, pads, is_max):
+    import torch
+    import torch.nn.functional as F
+    xt = torch.from_numpy(x)
+    if is_max:
+        xt = F.pad(xt, (pads[1], pads[3], pads[0], pads[2]),
+                   value=float("-inf"))
+        return F.max_pool2d(xt, k, stride).numpy()
+    # average over the window cells inside the image (count_include_pad = 0)
+    ones = torch.ones_like(xt)
+    xt = F.pad(xt, (pads[1], pads[3], pads[0], pads[2]))
+    ones = F.pad(ones, (pads[1], pads[3], pads[0], pads[2]))
+    s = F.avg_pool2d(xt, k, stride, divisor_override=1)
+    n = F.avg_pool2d(ones, k, stride, divisor_override=1)
+    return (s / n).numpy()
+
+
+def _same_pads(size, k, stride, upper):
+    pads = []
+    for n, kk, s in zip(size, k, stride):
+        out = -(-n // s)
+        total = max((out - 1) * s + kk - n, 0)
+        small, big = total // 2, total - total // 2
+        pads.append((small, big) if upper else (big, small))
+    return [pads[0][0], pads[1][0], pads[0][1], pads[1][1]]
+
+
+_cx, _cw, _cb = f32(1, 2, 7, 7), f32(3, 2, 3, 3), f32(3)
+case("test_basic_conv_with_padding", "Conv", [_cx, _cw],
+     [_conv_ref(_cx, _cw, None, 1, [1, 1, 1, 1])], rtol=1e-4, atol=1e-4,
+     kernel_shape=[3, 3], pads=[1, 1, 1, 1])
+case("test_basic_conv_without_padding", "Conv", [_cx, _cw],
+     [_conv_ref(_cx, _cw, None, 1, [0, 0, 0, 0])], rtol=1e-4, atol=1e-4,
+     kernel_shape=[3, 3], pads=[0, 0, 0, 0])
+case("test_conv_with_bias", "Conv", [_cx, _cw, _cb],
+     [_conv_ref(_cx, _cw, _cb, 1, [1, 1, 1, 1])], rtol=1e-4, atol=1e-4,
+     kernel_shape=[3, 3], pads=[1, 1, 1, 1])
+case("test_conv_with_strides_padding", "Conv", [_cx, _cw],
+     [_conv_ref(_cx, _cw, None, 2, [1, 1, 1, 1])], rtol=1e-4, atol=1e-4,
+     kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
+case("test_conv_with_strides_no_padding", "Conv", [_cx, _cw],
+     [_conv_ref(_cx, _cw, None, 2, [0, 0, 0, 0])], rtol=1e-4, atol=1e-4,
+     kernel_shape=[3, 3], pads=[0, 0, 0, 0], strides=[2, 2])
+case("test_conv_with_asymmetric_padding", "Conv", [_cx, _cw],
+     [_conv_ref(_cx, _cw, None, 1, [1, 0, 0, 1])], rtol=1e-4, atol=1e-4,
+     kernel_shape=[3, 3], pads=[1, 0, 0, 1])
+case("test_conv_with_autopad_same_upper", "Conv", [_cx, _cw],
+     [_conv_ref(_cx, _cw, None, 2, _same_pads((7, 7), (3, 3), (2, 2), True))],
+     rtol=1e-4, atol=1e-4, kernel_shape=[3, 3], strides=[2, 2],
+     auto_pad="SAME_UPPER")
+_cx8 = f32(1, 2, 8, 8)
+case("test_conv_with_autopad_same_lower", "Conv", [_cx8, _cw],
+     [_conv_ref(_cx8, _cw, None, 2, _same_pads((8, 8), (3, 3), (2, 2),
+                                               False))],
+     rtol=1e-4, atol=1e-4, kernel_shape=[3, 3], strides=[2, 2],
+     auto_pad="SAME_LOWER")
+_gw = f32(4, 1, 3, 3)
+case("test_conv_with_group", "Conv", [_cx, _gw],
+     [_conv_ref(_cx, _gw, None, 1, [1, 1, 1, 1], 2)], rtol=1e-4, atol=1e-4,
+     kernel_shape=[3, 3], pads=[1, 1, 1, 1], group=2)
+_px = f32(1, 3, 8, 8)
+for _op, _is_max in (("MaxPool", True), ("AveragePool", False)):
+    _n = _op.lower()
+    case("test_%s_2d_default" % _n, _op, [_px],
+         [_pool_ref(_px, 2, 1, [0, 0, 0, 0], _is_max)], kernel_shape=[2, 2])
+    case("test_%s_2d_strides" % _n, _op, [_px],
+         [_pool_ref(_px, 3, 2, [0, 0, 0, 0], _is_max)], kernel_shape=[3, 3],
+         strides=[2, 2])
+    case("test_%s_2d_pads" % _n, _op, [_px],
+         [_pool_ref(_px, 3, 1, [1, 1, 1, 1], _is_max)], kernel_shape=[3, 3],
+         pads=[1, 1, 1, 1])
+    # SAME_* with an odd total padding: the extra cell is a replicated border
+    # cell here (as in the reference, python/singa/utils.py handle_odd_pad_fwd),
+    # which equals the specification's "excluded from the average" for the
+    # 2 x 2 / stride 1 window of the official case; wider windows deviate
+    case("test_%s_2d_same_upper" % _n, _op, [_px],
+         [_pool_ref(_px, 2, 1, _same_pads((8, 8), (2, 2), (1, 1), True),
+                    _is_max)], kernel_shape=[2, 2], auto_pad="SAME_UPPER")
+    case("test_%s_2d_same_lower" % _n, _op, [_px],
+         [_pool_ref(_px, 2, 1, _same_pads((8, 8), (2, 2), (1, 1), False),
+                    _is_max)], kernel_shape=[2, 2], auto_pad="SAME_LOWER")
+    case("test_%s_2d_same_upper_even_padding" % _n, _op,
+         [np.ascontiguousarray(_px[:, :, :7, :7])],
+         [_pool_ref(_px[:, :, :7, :7].copy(), 3, 2,
+                    _same_pads((7, 7), (3, 3), (2, 2), True), _is_max)],
+         kernel_shape=[3, 3], strides=[2, 2], auto_pad="SAME_UPPER")
+    case("test_%s_2d_precomputed_strides" % _n, _op, [_px],
+         [_pool_ref(_px, 2, 2, [0, 0, 0, 0], _is_max)], kernel_shape=[2, 2],
+         strides=[2, 2])
+
+# ---------------------------------------------------------------------------
+# Clip, Cast, OneHot, ConstantOfShape, ScatterElements
+# ---------------------------------------------------------------------------
+_cl = f32(3, 4, 5, lo=-3, hi=3)
+case("test_clip", "Clip", [_cl, np.array(-1.0, np.float32),
+                           np.array(1.0, np.float32)], [np.clip(_cl, -1, 1)])
+case("test_clip_default_min", "Clip", [_cl, np.array(-1.0, np.float32)],
+     [np.clip(_cl, -1, None)])
+case("test_clip_default_inbounds", "Clip", [_cl], [_cl])
+case("test_clip_example", "Clip",
+     [np.array([-2, 0, 2], np.float32), np.array(-1.0, np.float32),
+      np.array(1.0, np.float32)], [np.array([-1, 0, 1], np.float32)])
+_cf = f32(3, 4, lo=-5, hi=5)
+case("test_cast_FLOAT_to_INT32", "Cast", [_cf], [_cf.astype(np.int32)],
+     to=TensorProto.INT32)
+case("test_cast_INT32_to_FLOAT", "Cast", [_cf.astype(np.int32)],
+     [_cf.astype(np.int32).astype(np.float32)], to=TensorProto.FLOAT)
+_oi = i64([[1, 9], [2, 4]])
+
+
+def _one_hot(idx, depth, axis, off, on):
+    eye = np.where(np.eye(depth)[idx % depth] > 0, on, off).astype(np.float32)
+    if axis not in (-1, idx.ndim):
+        eye = np.moveaxis(eye, -1, axis)
+    return eye
+
+
+case("test_onehot_without_axis", "OneHot",
+     [np.array([0, 7, 8], np.int64), i64([12]),
+      np.array([2, 5], np.float32)],
+     [_one_hot(np.array([0, 7, 8]), 12, -1, 2, 5)])
+case("test_onehot_with_axis", "OneHot",
+     [_oi, i64([10]), np.array([1, 3], np.float32)],
+     [_one_hot(_oi, 10, 1, 1, 3)], axis=1)
+case("test_onehot_with_negative_axis", "OneHot",
+     [_oi, i64([10]), np.array([1, 3], np.float32)],
+     [_one_hot(_oi, 10, -2, 1, 3)], axis=-2)
+case("test_constantofshape_float_ones", "ConstantOfShape", [i64([4, 3, 2])],
+     [np.ones((4, 3, 2), np.float32)],
+     value=helper.make_tensor("value", TensorProto.FLOAT, [1], [1.0]))
+case("test_constantofshape_int_zeros", "ConstantOfShape", [i64([10, 6])],
+     [np.zeros((10, 6), np.int32)],
+     value=helper.make_tensor("value", TensorProto.INT32, [1], [0]))
+_sc = np.zeros((3, 3), np.float32)
+_si = i64([[1, 0, 2], [0, 2, 1]])
+_su = np.array([[1.0, 1.1, 1.2], [2.0, 2.1, 2.2]], np.float32)
+_sw = _sc.copy()
+for _i in range(2):
+    for _j in range(3):
+        _sw[_si[_i, _j], _j] = _su[_i, _j]
+case("test_scatter_elements_without_axis", "ScatterElements",
+     [_sc, _si, _su], [_sw])
+_sc1 = np.array([[1, 2, 3, 4, 5]], np.float32)
+case("test_scatter_elements_with_axis", "ScatterElements",
+     [_sc1, i64([[1, 3]]), np.array([[1.1, 2.1]], np.float32)],
+     [np.array([[1, 1.1, 3, 2.1, 5]], np.float32)], axis=1)
+case("test_scatter_elements_with_negative_indices", "ScatterElements",
+     [_sc1, i64([[1, -3]]), np.array([[1.1, 2.1]], np.float32)],
+     [np.array([[1, 1.1, 2.1, 4, 5]], np.float32)], axis=1)
+
+
+def _expected_default(op, inputs, attrs):
+    """Expected outputs of the cases declared with ``None``."""
+    if op == "MatMul":
+        return [np.matmul(inputs[0], inputs[1])]
+    if op == "Where":
+        return [np.where(inputs[0] > 0, inputs[1], inputs[2])]
+    if op == "Flatten":
+        x, axis = inputs[0], attrs.get("axis", 1)
+        axis = axis + x.ndim if axis < 0 else axis
+        rows = int(np.prod(x.shape[:axis])) if axis > 0 else 1
+        return [x.reshape(rows, -1)]
+    if op == "Squeeze":
+        return [np.squeeze(inputs[0], tuple(attrs["axes"]))]
+    if op == "Unsqueeze":
+        x = inputs[0]
+        nd = x.ndim + len(attrs["axes"])
+        for a in sorted(a + nd if a < 0 else a for a in attrs["axes"]):
+            x = np.expand_dims(x, a)
+        return [x]
+    if op == "Gather":
+        return [np.take(inputs[0], inputs[1], attrs.get("axis", 0))]
+    raise AssertionError("no default expectation for " + op)
+
+
+@pytest.mark.parametrize("op,inputs,attrs,expected,rtol,atol", CASES)
+def test_node(dev, op, inputs, attrs, expected, rtol, atol):
+    names = ["in%d" % i for i in range(len(inputs))]
+    if expected is None:
+        expected = _expected_default(op, inputs, attrs)
+    outs = ["out%d" % i for i in range(len(expected))]
+    node = helper.make_node(op, names, outs, **attrs)
+    got = sonnx.run_node(node, [np.asarray(a) for a in inputs], dev)
+    assert list(got.keys()) == outs
+    for name, want in zip(outs, expected):
+        have = tensor.to_numpy(got[name])
+        want = np.asarray(want)
+        assert tuple(have.shape) == tuple(want.shape), (
+            "%s: shape %s, expected %s" % (op, have.shape, want.shape))
+        np.testing.assert_allclose(have.astype(np.float64),
+                                   want.astype(np.float64), rtol=rtol,
+                                   atol=atol)
+
+
+def test_every_imported_operator_has_a_vector():
+    covered = {p.values[0] for p in CASES}
+    # FusedAttention is this importer's own fused node (tests/test_attention.py)
+    missing = set(sonnx.SingaBackend._rename_operators) - covered - \
+        {"FusedAttention"}
+    assert not missing, "operators without a node vector: %s" % sorted(missing)

@@ -2254,7 +2254,7 @@ class _Pooling2d(Operator):
         dx = singa.PoolingBackward(self.handle, dy, self.cache[0],
                                    self.cache[1])
         if self.odd_padding != (0, 0, 0, 0):
-            dx = utils.handle_odd_pad_bwd(dx, self.odd_padding)
+            dx = utils.handle_odd_pad_bwd(dx, self.odd_padding, True)
         return dx
 
 

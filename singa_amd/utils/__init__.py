@@ -56,9 +56,37 @@ def handle_odd_pad_fwd(x, odd_padding, is_pool=False):
     return x
 
 
-def handle_odd_pad_bwd(dx, odd_padding):
-    """Drop the rows / columns that handle_odd_pad_fwd added."""
+def _fold_border(dx, axis, count, at_start):
+    """Reverse of ``_replicate_border`` for gradients: cut the replicated
+    cells off and add their gradient onto the border cells they copied."""
+    shape = list(dx.shape())
+    n = shape[axis]
+    if at_start:
+        extra, body = singa.SliceOn(dx, 0, count, axis), \
+            singa.SliceOn(dx, count, n, axis)
+        first = 0
+    else:
+        extra, body = singa.SliceOn(dx, n - count, n, axis), \
+            singa.SliceOn(dx, 0, n - count, axis)
+        first = n - 2 * count
+    kept = list(body.shape())
+    starts, ends = [0] * len(kept), list(kept)
+    starts[axis], ends[axis] = first, first + count
+    return singa.__add__(body, singa.EmbedND(extra, kept, starts, ends, None,
+                                             0.0))
+
+
+def handle_odd_pad_bwd(dx, odd_padding, is_pool=False):
+    """Drop the rows / columns that handle_odd_pad_fwd added.  For pooling the
+    added cells were copies of border cells, so their gradient belongs to
+    those cells (a maximum found in the copy must not lose its gradient)."""
     top, bottom, left, right = (int(p) for p in odd_padding)
+    if is_pool:
+        for axis, at_start, count in ((3, False, right), (3, True, left),
+                                      (2, False, bottom), (2, True, top)):
+            if count:
+                dx = _fold_border(dx, axis, count, at_start)
+        return dx
     n, c, h, w = dx.shape()
     return singa.SliceND(dx, [0, 0, top, left], [n, c, h - bottom, w - right])
 

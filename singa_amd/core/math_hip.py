@@ -11,6 +11,7 @@ the graph's private pool).
 Contract parity: reference src/core/tensor/tensor_math.h:86-485 and
 tensor_math_cuda.h (the CUDA specialisations this backend stands in for).
 """
+import json
 import math
 import os
 
@@ -64,6 +65,18 @@ def _is_linear(shp, st):
 
 
 _CONV_AUTOTUNE = os.environ.get("SINGA_CONV_AUTOTUNE", "1") != "0"
+
+
+def _world_size():
+    d = torch.distributed
+    return d.get_world_size() if d.is_available() and d.is_initialized() \
+        else 1
+
+
+def _rank():
+    d = torch.distributed
+    return d.get_rank() if d.is_available() and d.is_initialized() else 0
+
 _CONV1X1_GEMM = os.environ.get("SINGA_CONV1X1_GEMM", "1") != "0"
 _CONV3X3_GEMM = os.environ.get("SINGA_CONV3X3_GEMM", "1") != "0"
 _CONV3X3_GEMM_MIN_HW = int(os.environ.get("SINGA_CONV3X3_GEMM_MIN_HW", "400"))
@@ -74,6 +87,7 @@ class HipMath(object):
     def __init__(self, dev):
         self.dev = dev
         self.k = dev.kernels
+        HipMath._kernel_file = getattr(self.k, "__file__", "") or ""
         self.conv_prof = None
 
     # ---- plumbing -----------------------------------------------------------
@@ -463,38 +477,118 @@ class HipMath(object):
     # Launch-plan autotuning (the role of cuDNN's algorithm search in the
     # reference, convolution.cc:514-640): the first time a (pass, geometry,
     # dtype) is seen outside stream capture, every candidate tile edge / split
-    # target is timed on the real operands and the fastest one is cached for
-    # the life of the process.  SINGA_CONV_AUTOTUNE=0 keeps the heuristic.
+    # target is timed on the real operands and the fastest one is kept.
+    # Plans persist in a JSON file keyed by GPU architecture and kernel build
+    # (SINGA_CONV_PLAN_CACHE: path, or 0 for no file), so later processes --
+    # and shapes first met under stream capture -- start from measured plans.
+    # With several ranks only rank 0 consults the file or measures; every
+    # rank takes rank 0's choice through a broadcast, so all ranks launch
+    # identical kernels.  SINGA_CONV_AUTOTUNE=0 keeps the heuristic.
     _conv_plans = {}
     _CONV_CANDIDATES = ((64, 512), (64, 1024), (64, 2048), (128, 256),
                         (128, 512), (128, 1024), (128, 2048))
+    _plan_file = None          # (path, {key string: [tile, split]}) once read
+    _kernel_file = ""          # path of the loaded kernel library
+
+    @classmethod
+    def _plan_store(cls):
+        """The persisted plans of this architecture and kernel build."""
+        if cls._plan_file is None:
+            path = os.environ.get("SINGA_CONV_PLAN_CACHE")
+            if path is None:
+                path = os.path.join(
+                    os.environ.get("XDG_CACHE_HOME",
+                                   os.path.expanduser("~/.cache")),
+                    "singa_amd", "conv_plans.json")
+            plans = {}
+            if path not in ("", "0"):
+                try:
+                    with open(path) as f:
+                        blob = json.load(f)
+                    if blob.get("build") == cls._build_id():
+                        plans = dict(blob.get("plans", {}))
+                except (OSError, ValueError):
+                    plans = {}
+            cls._plan_file = (path, plans)
+        return cls._plan_file
+
+    @staticmethod
+    def _build_id():
+        """Architecture plus size and time stamp of the kernel library: plans
+        measured with other kernels are not reused."""
+        so = HipMath._kernel_file
+        try:
+            st = os.stat(so)
+            stamp = "%d-%d" % (st.st_size, int(st.st_mtime))
+        except OSError:
+            stamp = "unknown"
+        arch = torch.cuda.get_device_properties(0).gcnArchName \
+            if torch.cuda.is_available() else "cpu"
+        return "%s/%s" % (arch, stamp)
+
+    @classmethod
+    def _persist_plan(cls, name, plan):
+        path, plans = cls._plan_store()
+        plans[name] = list(plan)
+        if path in ("", "0"):
+            return
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            tmp = "%s.%d.tmp" % (path, os.getpid())
+            with open(tmp, "w") as f:
+                json.dump({"build": cls._build_id(), "plans": plans}, f)
+            os.replace(tmp, path)
+        except OSError:
+            pass                      # a read-only home: keep the process cache
+
+    def _measure_plan(self, g, launch):
+        best, best_t = (0, 0), None
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        stream = torch.cuda.current_stream()
+        for cand in ((0, 0),) + self._CONV_CANDIDATES:
+            g.tile, g.split_target = cand
+            launch(g)                      # warm up / page in code
+            e0.record(stream)
+            for _ in range(3):
+                launch(g)
+            e1.record(stream)
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best_t is None or t < best_t * 0.97:   # prefer the default
+                best, best_t = cand, t
+        return best
 
     def _tuned(self, mode, g, key, launch):
         """Set g.tile / g.split_target for this launch.  ``launch(g)`` runs the
         convolution once (it only overwrites the output)."""
         if key[4] > 1 and key[4] == key[0][1] == key[1][0]:
             return  # depthwise kernels have no launch plan to choose
-        plan = self._conv_plans.get((mode,) + key)
+        full = (mode,) + key
+        plan = self._conv_plans.get(full)
         if plan is None:
-            if not _CONV_AUTOTUNE or torch.cuda.is_current_stream_capturing():
+            if not _CONV_AUTOTUNE:
                 return
-            best, best_t = (0, 0), None
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            stream = torch.cuda.current_stream()
-            for cand in ((0, 0),) + self._CONV_CANDIDATES:
-                g.tile, g.split_target = cand
-                launch(g)                      # warm up / page in code
-                e0.record(stream)
-                for _ in range(3):
-                    launch(g)
-                e1.record(stream)
-                e1.synchronize()
-                t = e0.elapsed_time(e1)
-                if best_t is None or t < best_t * 0.97:   # prefer the default
-                    best, best_t = cand, t
-            plan = best
-            self._conv_plans[(mode,) + key] = plan
+            capturing = torch.cuda.is_current_stream_capturing()
+            ranks = _world_size()
+            if ranks > 1 and capturing:
+                return        # no collective inside a capture: heuristic plan
+            name = repr(full)
+            if ranks <= 1 or _rank() == 0:
+                stored = self._plan_store()[1].get(name)
+                if stored is not None:
+                    plan = (int(stored[0]), int(stored[1]))
+                elif not capturing:
+                    plan = self._measure_plan(g, launch)
+                    self._persist_plan(name, plan)
+            if ranks > 1:
+                word = torch.tensor(list(plan or (0, 0)), dtype=torch.int32,
+                                    device=self.dev.torch_device)
+                torch.distributed.broadcast(word, 0)
+                plan = tuple(int(v) for v in word.tolist())
+            if plan is None:
+                return        # first met under capture, nothing stored
+            self._conv_plans[full] = plan
         g.tile, g.split_target = plan
 
     def _split_scratch(self, g, out, rows, cols, groups):

@@ -477,7 +477,7 @@ bool Decode(const std::string &data, std::vector<uint8_t> *pixels, int *width,
   if (n < 4 || p[0] != 0xff || p[1] != 0xd8) return Fail(error, "no SOI marker");
   uint16_t qt[4][64];
   bool have_qt[4] = {false, false, false, false};
-  HuffDec hdc[4], hac[4];
+  HuffDec hdc[4] = {}, hac[4] = {};   // zero tables: nothing is "present"
   std::vector<Component> comps;
   int W = 0, H = 0, restart = 0, hmax = 1, vmax = 1;
   size_t pos = 2;
@@ -528,6 +528,9 @@ bool Decode(const std::string &data, std::vector<uint8_t> *pixels, int *width,
       if ((nc != 1 && nc != 3) || sl < static_cast<size_t>(6 + 3 * nc) ||
           W == 0 || H == 0)
         return Fail(error, "unsupported frame header");
+      // a malformed header must not be able to request gigabytes of planes
+      if (static_cast<uint64_t>(W) * static_cast<uint64_t>(H) > (1ull << 28))
+        return Fail(error, "image larger than 2^28 pixels");
       comps.resize(nc);
       for (int c = 0; c < nc; ++c) {
         comps[c].id = s[6 + 3 * c];
@@ -547,18 +550,30 @@ bool Decode(const std::string &data, std::vector<uint8_t> *pixels, int *width,
       restart = (s[0] << 8) | s[1];
     } else if (m == 0xda) {
       if (comps.empty()) return Fail(error, "scan before frame header");
+      if (sl < 1) return Fail(error, "empty scan header");
       const int ns = s[0];
       if (ns != static_cast<int>(comps.size()) || sl < static_cast<size_t>(4 + 2 * ns))
         return Fail(error, "non-interleaved scans are not supported");
+      // every frame component must be selected exactly once (duplicate
+      // component ids would leave one with tables nobody checked)
+      std::vector<int> selected(comps.size(), 0);
       for (int k = 0; k < ns; ++k) {
         Component *c = nullptr;
-        for (auto &cc : comps)
-          if (cc.id == s[1 + 2 * k]) c = &cc;
+        for (size_t ci = 0; ci < comps.size(); ++ci)
+          if (comps[ci].id == s[1 + 2 * k] && !selected[ci]) {
+            c = &comps[ci];
+            selected[ci] = 1;
+            break;
+          }
         if (!c) return Fail(error, "scan names an unknown component");
         c->td = s[2 + 2 * k] >> 4;
         c->ta = s[2 + 2 * k] & 15;
-        if (c->td > 3 || c->ta > 3 || !hdc[c->td].present ||
-            !hac[c->ta].present || !have_qt[c->tq])
+      }
+      for (size_t ci = 0; ci < comps.size(); ++ci) {
+        const Component &c = comps[ci];
+        if (!selected[ci]) return Fail(error, "scan omits a component");
+        if (c.td > 3 || c.ta > 3 || !hdc[c.td].present || !hac[c.ta].present ||
+            !have_qt[c.tq])
           return Fail(error, "scan refers to a missing table");
       }
       if (comps.size() == 1) { comps[0].h = comps[0].v = 1; hmax = vmax = 1; }

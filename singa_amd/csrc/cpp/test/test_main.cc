@@ -941,6 +941,42 @@ static void TestJpeg() {
   EXPECT(!jpeg::Decode(bytes.substr(0, bytes.size() / 2), &o, &w, &h, &c,
                        nullptr, &err));
   EXPECT(!err.empty());
+  // malformed headers are rejected before any table or plane is touched
+  auto find_marker = [&](const std::string &b, int marker) {
+    for (size_t i = 2; i + 3 < b.size();) {
+      if ((uint8_t)b[i] != 0xff) return std::string::npos;
+      const int m = (uint8_t)b[i + 1];
+      if (m == marker) return i;
+      i += 2 + (((uint8_t)b[i + 2] << 8) | (uint8_t)b[i + 3]);
+    }
+    return std::string::npos;
+  };
+  const size_t sof = find_marker(bytes, 0xc0), sos = find_marker(bytes, 0xda);
+  EXPECT(sof != std::string::npos && sos != std::string::npos);
+  {
+    std::string dup = bytes;          // two frame components with one id
+    dup[sof + 4 + 6 + 3] = dup[sof + 4 + 6];
+    err.clear();
+    EXPECT(!jpeg::Decode(dup, &o, &w, &h, &c, nullptr, &err) && !err.empty());
+  }
+  {
+    std::string huge = bytes;         // 65535 x 65535 pixels
+    for (int k = 1; k <= 4; ++k) huge[sof + 4 + k] = (char)0xff;
+    err.clear();
+    EXPECT(!jpeg::Decode(huge, &o, &w, &h, &c, nullptr, &err) && !err.empty());
+  }
+  {
+    std::string notab = bytes;        // the scan selects Huffman table 3
+    notab[sos + 4 + 2] = (char)0x33;
+    err.clear();
+    EXPECT(!jpeg::Decode(notab, &o, &w, &h, &c, nullptr, &err) && !err.empty());
+  }
+  {
+    std::string empty = bytes.substr(0, sos);   // scan header of length 2
+    empty += std::string("\xff\xda\x00\x02", 4);
+    err.clear();
+    EXPECT(!jpeg::Decode(empty, &o, &w, &h, &c, nullptr, &err) && !err.empty());
+  }
 }
 
 // `--jpeg-decode in.jpg out.ppm` / `--jpeg-encode in.ppm out.jpg [quality]` /

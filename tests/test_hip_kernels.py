@@ -828,3 +828,101 @@ def test_byte_copy_of_unsupported_dtypes(maths):
         dst = torch.zeros_like(src)
         hm.copy(src, dst)
         assert torch.equal(src.cpu(), dst.cpu())
+
+
+def test_conv_plans_persist_and_reload(maths, tmp_path, monkeypatch):
+    """A measured launch plan is written to the plan file and a fresh cache
+    (a new process) takes it from there instead of measuring again."""
+    hm, cm, dev = maths
+    from singa_amd.core import math_hip
+    path = str(tmp_path / "plans.json")
+    monkeypatch.setenv("SINGA_CONV_PLAN_CACHE", path)
+    monkeypatch.setattr(math_hip.HipMath, "_plan_file", None)
+    monkeypatch.setattr(math_hip.HipMath, "_conv_plans", {})
+    x = g(rnd(2, 16, 12, 12, seed=70), dev)
+    w = g(rnd(32, 16, 3, 3, seed=71), dev)
+    y = torch.empty(2, 32, 10, 10, device=dev.torch_device)
+    hm.conv_fwd(x, w, None, y, (1, 1), (0, 0), 1)
+    import json
+    blob = json.load(open(path))
+    assert blob["build"] == math_hip.HipMath._build_id()
+    assert len(blob["plans"]) == 1
+    (name, plan), = blob["plans"].items()
+    # plant a recognisable plan: the next "process" must launch with it
+    blob["plans"][name] = [64, 2048]
+    json.dump(blob, open(path, "w"))
+    monkeypatch.setattr(math_hip.HipMath, "_plan_file", None)
+    monkeypatch.setattr(math_hip.HipMath, "_conv_plans", {})
+    calls = []
+    monkeypatch.setattr(math_hip.HipMath, "_measure_plan",
+                        lambda self, g_, launch: calls.append(1) or (0, 0))
+    y2 = torch.empty_like(y)
+    hm.conv_fwd(x, w, None, y2, (1, 1), (0, 0), 1)
+    assert not calls
+    assert list(math_hip.HipMath._conv_plans.values()) == [(64, 2048)]
+    np.testing.assert_allclose(y2.cpu().numpy(), y.cpu().numpy(), rtol=1e-5,
+                               atol=1e-5)
+    # a plan file written by another kernel build is ignored
+    blob["build"] = "other"
+    json.dump(blob, open(path, "w"))
+    monkeypatch.setattr(math_hip.HipMath, "_plan_file", None)
+    assert math_hip.HipMath._plan_store()[1] == {}
+
+
+def test_extreme_and_nonfinite_inputs(maths):
+    """The kernels are compiled with fast-math flags; the reductions that take
+    extreme or non-finite values in practice are pinned here: soft-max with
+    -inf mask entries and huge logits, cross-entropy with saturated logits,
+    batch / layer normalisation of constant inputs (zero variance), relu and
+    clamp on infinities."""
+    hm, cm, dev = maths
+    d = dev.torch_device
+    ninf = float("-inf")
+    x = torch.tensor([[0.0, ninf, 1.0, ninf], [1e30, 1.0, -1e30, 0.0],
+                      [88.0, 89.0, 90.0, 91.0], [-200.0, -201.0, -199.0, -500.0]])
+    out = torch.empty_like(x, device=d)
+    hm.softmax(x.to(d), out)
+    want = torch.softmax(x, 1)
+    got = out.cpu()
+    assert torch.isfinite(got).all()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-5, atol=1e-7)
+    # saturated logits: the loss is the log-sum-exp gap, never inf / nan
+    logits = torch.tensor([[1e4, -1e4, 0.0], [-1e4, 1e4, 0.0], [50.0, 60.0, 70.0]])
+    t = torch.tensor([0, 0, 2], dtype=torch.int32)
+    p = torch.empty(3, 3, device=d)
+    loss = torch.empty(1, device=d)
+    hm.softmax_ce_fused_fwd(logits.to(d), t.to(d), p, loss)
+    ref = torch.nn.functional.cross_entropy(logits, t.long(), reduction="sum")
+    got = float(loss.cpu()[0])
+    assert np.isfinite(got)
+    ref_v = float(ref)
+    assert got == pytest.approx(ref_v, rel=1e-5) or \
+        got == pytest.approx(ref_v / 3, rel=1e-5)
+    assert torch.isfinite(p.cpu()).all()
+    # constant input: variance exactly zero
+    xc = torch.full((4, 3, 5, 5), 2.5)
+    C = 3
+    y = torch.empty_like(xc, device=d)
+    mean, istd = torch.empty(C, device=d), torch.empty(C, device=d)
+    rm, rv = torch.zeros(C, device=d), torch.ones(C, device=d)
+    hm.bn_fwd_train(xc.to(d), torch.ones(C, device=d), torch.zeros(C, device=d),
+                    rm, rv, 0.1, 1e-5, y, mean, istd)
+    assert torch.isfinite(y.cpu()).all()
+    np.testing.assert_allclose(y.cpu().numpy(), 0.0, atol=1e-3)
+    np.testing.assert_allclose(mean.cpu().numpy(), 2.5, rtol=1e-6)
+    xr = torch.full((6, 64), -3.0)
+    yr = torch.empty_like(xr, device=d)
+    mu, rstd = torch.empty(6, device=d), torch.empty(6, device=d)
+    hm.layernorm_fwd(xr.to(d), torch.ones(64, device=d),
+                     torch.zeros(64, device=d), yr, mu, rstd, 1e-5)
+    assert torch.isfinite(yr.cpu()).all()
+    np.testing.assert_allclose(yr.cpu().numpy(), 0.0, atol=1e-3)
+    # element-wise ops keep infinities where the maths says so
+    v = torch.tensor([ninf, -1.0, 0.0, 2.0, float("inf")])
+    o = torch.empty_like(v, device=d)
+    hm.unary("relu", v.to(d), o)
+    np.testing.assert_array_equal(o.cpu().numpy(),
+                                  np.array([0, 0, 0, 2, np.inf], np.float32))
+    hm.clamp(v.to(d), -1.5, 1.5, o)
+    np.testing.assert_array_equal(o.cpu().numpy(),
+                                  np.array([-1.5, -1, 0, 1.5, 1.5], np.float32))

@@ -496,8 +496,10 @@ int sa_lstm_seq_supported(int64_t batch, int64_t hidden) {
 int sa_lstm_seq(const LstmSeqArgs *args, int backward, hipStream_t s) {
   const LstmSeqArgs &a = *args;
   if (!sa_lstm_seq_supported(a.batch, a.hidden) || a.steps < 1) return -3;
-  // barrier counter and give-up flag start at zero for every launch
-  if (hipMemsetAsync(a.bar, 0, 2 * sizeof(unsigned), s) != hipSuccess) return -1;
+  // barrier counter and give-up flag start at zero for every launch (an
+  // ordinary kernel: a memset node is not reliably ordered against the
+  // kernel nodes of a captured graph)
+  zero_async(a.bar, 2 * sizeof(unsigned), s);
   switch (a.hidden / 32) {
     case 1: launch_lstm_seq<1>(a, backward != 0, s); break;
     case 2: launch_lstm_seq<2>(a, backward != 0, s); break;

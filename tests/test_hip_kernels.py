@@ -892,12 +892,14 @@ def test_extreme_and_nonfinite_inputs(maths):
     p = torch.empty(3, 3, device=d)
     loss = torch.empty(1, device=d)
     hm.softmax_ce_fused_fwd(logits.to(d), t.to(d), p, loss)
-    ref = torch.nn.functional.cross_entropy(logits, t.long(), reduction="sum")
+    # reference semantics (src/core/tensor/math_kernel.cu ComputeCrossEntropy):
+    # batch mean of -log(max(p, FLT_MIN)), so a zero probability costs 87.3
+    probs = torch.softmax(logits, 1)[torch.arange(3), t.long()]
+    ref_v = float((-torch.log(torch.clamp(
+        probs, min=float(np.finfo(np.float32).tiny)))).mean())
     got = float(loss.cpu()[0])
     assert np.isfinite(got)
-    ref_v = float(ref)
-    assert got == pytest.approx(ref_v, rel=1e-5) or \
-        got == pytest.approx(ref_v / 3, rel=1e-5)
+    assert got == pytest.approx(ref_v, rel=1e-4)
     assert torch.isfinite(p.cpu()).all()
     # constant input: variance exactly zero
     xc = torch.full((4, 3, 5, 5), 2.5)

@@ -427,6 +427,22 @@ class _GraphStamps(object):
         g.AddTimeElapsed(vals[self.n])
 
 
+def _drain_collective_watchdog(dev):
+    """Let the process group's watchdog thread retire every collective issued
+    so far before a capture starts.
+
+    The watchdog polls the completion event of each outstanding collective.
+    On ROCm an event query fails with "operation not permitted on an event
+    last recorded in a capturing stream" as soon as the stream the event was
+    recorded on is capturing -- also for events recorded *before* the capture
+    began -- and the watchdog then aborts the process.  Collectives issued
+    inside the capture are never handed to the watchdog; the ones from the
+    eager warm-up iteration are: wait until they have finished on the GPU and
+    give the watchdog (which wakes every 100 ms) time to drop them."""
+    torch.cuda.synchronize(dev.torch_device)
+    time.sleep(float(os.environ.get("SINGA_CAPTURE_DRAIN_MS", "350")) / 1e3)
+
+
 class _HipGraphReplay(object):
     """Captured form of one device graph.  With stream-ordered collectives
     (RCCL) the whole plan is ONE hipGraph: the communication nodes fork the
@@ -473,6 +489,8 @@ class _HipGraphReplay(object):
                 not any(r[0] == "eager" for r in ranges):
             stamps = _GraphStamps(dev, len(names), self.verbosity, names)
         dev._stamps = stamps
+        if dev.collectives_capturable:
+            _drain_collective_watchdog(dev)
         pool = torch.cuda.graph_pool_handle()
         cap_stream = torch.cuda.Stream(device=dev.torch_device)
         dev.phase = "capture"

@@ -2244,7 +2244,8 @@ class _Pooling2d(Operator):
     def forward(self, x):
         assert x.nDim() == 4, "The dimensions of input should be 4D."
         if self.odd_padding != (0, 0, 0, 0):
-            x = utils.handle_odd_pad_fwd(x, self.odd_padding, True)
+            x = utils.handle_odd_pad_fwd(x, self.odd_padding, True,
+                                         bool(self.handle.is_max_pooling))
         y = singa.PoolingForward(self.handle, x)
         if training:
             self.cache = (x, y)
@@ -2254,7 +2255,8 @@ class _Pooling2d(Operator):
         dx = singa.PoolingBackward(self.handle, dy, self.cache[0],
                                    self.cache[1])
         if self.odd_padding != (0, 0, 0, 0):
-            dx = utils.handle_odd_pad_bwd(dx, self.odd_padding, True)
+            dx = utils.handle_odd_pad_bwd(dx, self.odd_padding, True,
+                                          bool(self.handle.is_max_pooling))
         return dx
 
 

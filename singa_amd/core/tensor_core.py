@@ -810,6 +810,19 @@ def SoftmaxCrossEntropyFusedBwd(p, t):
 def MultWithScale(alpha, A, B, beta, C):
     alpha, beta = float(alpha), float(beta)
     reads = [A, B] + ([C] if beta else [])
+    # the kernels trust these extents: check them here, on the host
+    inner = B._shape[0] if B.nDim() == 1 else B._shape[-2]
+    if A._shape[-1] != inner:
+        raise ValueError("matmul: inner extents differ, %s x %s" %
+                         (A._shape, B._shape))
+    want = list(A._shape[:-1]) + ([] if B.nDim() == 1 else [B._shape[-1]])
+    if Product(C._shape) != Product(want) or (
+            B.nDim() > 1 and C._shape[-1] != B._shape[-1]):
+        raise ValueError("matmul: result %s does not fit %s x %s" %
+                         (C._shape, A._shape, B._shape))
+    if B.nDim() > 2 and list(A._shape[:-2]) != list(B._shape[:-2]):
+        raise ValueError("matmul: batch extents differ, %s x %s" %
+                         (A._shape, B._shape))
     if B.nDim() == 1:
         assert A.nDim() == 2
 

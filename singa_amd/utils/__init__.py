@@ -38,17 +38,18 @@ def _replicate_border(x, axis, count, at_start):
     return singa.ConcatOn(singa.VecTensor(parts), axis)
 
 
-def handle_odd_pad_fwd(x, odd_padding, is_pool=False):
+def handle_odd_pad_fwd(x, odd_padding, is_pool=False, is_max=False):
     """Apply the asymmetric part of a padding: (top, bottom, left, right)
-    extra rows / columns.  Convolution pads with zeros (one embed kernel);
-    pooling replicates the border so the extra cells never win a max or bias
-    an average."""
+    extra rows / columns.  Convolution pads with zeros (one embed kernel); max
+    pooling with the most negative number, so a padded cell never wins and
+    never receives gradient; average pooling replicates the border so the
+    extra cells do not bias the mean."""
     top, bottom, left, right = (int(p) for p in odd_padding)
-    if not is_pool:
+    if not is_pool or is_max:
         n, c, h, w = x.shape()
         return singa.EmbedND(x, [n, c, h + top + bottom, w + left + right],
                              [0, 0, top, left], [n, c, top + h, left + w],
-                             None, 0.0)
+                             None, -3.0e38 if is_pool else 0.0)
     for axis, at_start, count in ((2, True, top), (2, False, bottom),
                                   (3, True, left), (3, False, right)):
         if count:
@@ -76,12 +77,12 @@ def _fold_border(dx, axis, count, at_start):
                                              0.0))
 
 
-def handle_odd_pad_bwd(dx, odd_padding, is_pool=False):
-    """Drop the rows / columns that handle_odd_pad_fwd added.  For pooling the
-    added cells were copies of border cells, so their gradient belongs to
-    those cells (a maximum found in the copy must not lose its gradient)."""
+def handle_odd_pad_bwd(dx, odd_padding, is_pool=False, is_max=False):
+    """Drop the rows / columns that handle_odd_pad_fwd added.  For average
+    pooling the added cells were copies of border cells, so their gradient
+    belongs to those cells."""
     top, bottom, left, right = (int(p) for p in odd_padding)
-    if is_pool:
+    if is_pool and not is_max:
         for axis, at_start, count in ((3, False, right), (3, True, left),
                                       (2, False, bottom), (2, True, top)):
             if count:

@@ -12,7 +12,7 @@ conformance is "parity unpinned" against the official suite.
 import numpy as np
 import pytest
 
-from singa_amd import sonnx, tensor
+from singa_amd import autograd, sonnx, tensor
 from singa_amd.onnx_proto import TensorProto, helper
 
 RS = np.random.RandomState(77)
@@ -453,10 +453,11 @@ for _op, _is_max in (("MaxPool", True), ("AveragePool", False)):
     case("test_%s_2d_pads" % _n, _op, [_px],
          [_pool_ref(_px, 3, 1, [1, 1, 1, 1], _is_max)], kernel_shape=[3, 3],
          pads=[1, 1, 1, 1])
-    # SAME_* with an odd total padding: the extra cell is a replicated border
-    # cell here (as in the reference, python/singa/utils.py handle_odd_pad_fwd),
-    # which equals the specification's "excluded from the average" for the
-    # 2 x 2 / stride 1 window of the official case; wider windows deviate
+    # SAME_* with an odd total padding: max pooling pads with the lowest
+    # value (the specification); average pooling replicates the border cell
+    # (as the reference does, python/singa/utils.py handle_odd_pad_fwd), which
+    # equals the specification's "excluded from the average" for the 2 x 2 /
+    # stride 1 window of the official case; wider windows deviate
     case("test_%s_2d_same_upper" % _n, _op, [_px],
          [_pool_ref(_px, 2, 1, _same_pads((8, 8), (2, 2), (1, 1), True),
                     _is_max)], kernel_shape=[2, 2], auto_pad="SAME_UPPER")
@@ -564,7 +565,12 @@ def test_node(dev, op, inputs, attrs, expected, rtol, atol):
         expected = _expected_default(op, inputs, attrs)
     outs = ["out%d" % i for i in range(len(expected))]
     node = helper.make_node(op, names, outs, **attrs)
-    got = sonnx.run_node(node, [np.asarray(a) for a in inputs], dev)
+    was_training = autograd.training
+    autograd.training = False     # node tests have inference semantics
+    try:
+        got = sonnx.run_node(node, [np.asarray(a) for a in inputs], dev)
+    finally:
+        autograd.training = was_training
     assert list(got.keys()) == outs
     for name, want in zip(outs, expected):
         have = tensor.to_numpy(got[name])

@@ -1050,6 +1050,12 @@ def ConcatOn(tensors, axis):
     tensors = list(tensors)
     axis = int(axis)
     shape = list(tensors[0]._shape)
+    for t in tensors[1:]:
+        other = list(t._shape)
+        if len(other) != len(shape) or \
+                other[:axis] + other[axis + 1:] != shape[:axis] + shape[axis + 1:]:
+            raise ValueError("concatenation along axis %d of shapes %s and %s"
+                             % (axis, tensors[0]._shape, t._shape))
     shape[axis] = sum(t._shape[axis] for t in tensors)
     out = Tensor(shape, tensors[0]._dev, tensors[0]._dtype)
     sizes = [t._shape[axis] for t in tensors]

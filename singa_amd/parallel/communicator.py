@@ -70,6 +70,70 @@ _STRICT = int(os.environ.get("SINGA_DIST_STRICT", "0"))
 _CAPTURE = os.environ.get("SINGA_DIST_CAPTURE", "1") != "0"
 
 
+# SINGA_RCCL_DIRECT=0 routes device collectives through torch.distributed's
+# work objects instead of calling RCCL on the communicator's stream directly
+_DIRECT = os.environ.get("SINGA_RCCL_DIRECT", "1") != "0"
+
+
+class _Rccl(object):
+    """RCCL entry points called directly on the process group's communicator.
+
+    ``torch.distributed`` wraps every collective in a work object whose
+    completion event a watchdog thread polls.  A collective issued while a
+    hipGraph is being captured must never reach that thread (querying an event
+    recorded in a capturing stream aborts the process), and each wrapped call
+    also hops through the group's internal stream with two event syncs.  Here
+    the collective is enqueued on the caller's current stream with the
+    communicator the process group has already built (rendezvous, topology
+    and xGMI ring set-up stay torch's job): nothing to poll, one kernel per
+    collective, capturable like any other kernel launch."""
+
+    _DTYPES = {torch.int8: 0, torch.uint8: 1, torch.int32: 2, torch.int64: 4,
+               torch.float16: 6, torch.float32: 7, torch.float64: 8,
+               torch.bfloat16: 9}
+    _SUM = 0
+
+    def __init__(self, device):
+        import ctypes
+        path = os.path.join(os.path.dirname(torch.__file__), "lib",
+                            "librccl.so")
+        self.lib = ctypes.CDLL(path)
+        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        self.lib.ncclAllReduce.argtypes = [vp, vp, sz, ci, ci, vp, vp]
+        self.lib.ncclAllReduce.restype = ci
+        self.lib.ncclAllGather.argtypes = [vp, vp, sz, ci, vp, vp]
+        self.lib.ncclAllGather.restype = ci
+        self.lib.ncclGetErrorString.argtypes = [ci]
+        self.lib.ncclGetErrorString.restype = ctypes.c_char_p
+        group = dist.distributed_c10d._get_default_group()
+        backend = group._get_backend(device)
+        # the communicator exists once the group has run a collective
+        warm = torch.zeros(1, dtype=torch.float32, device=device)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize(device)
+        self.comm = int(backend._comm_ptr())
+        if not self.comm:
+            raise RuntimeError("the process group has no RCCL communicator")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s failed: %s" % (
+                what, self.lib.ncclGetErrorString(rc).decode()))
+
+    def all_reduce(self, flat):
+        stream = torch.cuda.current_stream(flat.device).cuda_stream
+        self._check(self.lib.ncclAllReduce(
+            flat.data_ptr(), flat.data_ptr(), flat.numel(),
+            self._DTYPES[flat.dtype], self._SUM, self.comm, stream),
+            "ncclAllReduce")
+
+    def all_gather(self, out, flat):
+        stream = torch.cuda.current_stream(flat.device).cuda_stream
+        self._check(self.lib.ncclAllGather(
+            flat.data_ptr(), out.data_ptr(), flat.numel(),
+            self._DTYPES[flat.dtype], self.comm, stream), "ncclAllGather")
+
+
 def _env_int(names, default):
     for n in names:
         v = os.environ.get(n)
@@ -135,6 +199,10 @@ class Communicator(object):
         # beyond the capacity stay in the accumulator and go out later);
         # without accumulation the capacity is the whole bucket
         self.spars_cap = float(os.environ.get("SINGA_SPARS_CAP", "1.0"))
+        self._rccl = None         # direct RCCL calls
+        if _DIRECT and self._active and not self._host_backend and self._gpu:
+            self._rccl = _Rccl(torch.device("cuda",
+                                            torch.cuda.current_device()))
         self._dev = None          # device of the last synchronised tensors
         self._blocks = []         # their blocks: what wait() orders against
         self._buffers = {}        # (slot, kind, dtype) -> persistent buffer
@@ -186,6 +254,19 @@ class Communicator(object):
         GPU.)  RCCL collectives are stream ordered and take the tensor as is."""
         return t.is_cuda and self._host_backend
 
+    def _direct(self, t):
+        """True when the collective on ``t`` is a direct RCCL call."""
+        if not (_DIRECT and t.is_cuda and self._active and
+                not self._host_backend and t.is_contiguous() and
+                t.dtype in _Rccl._DTYPES):
+            return False
+        if self._rccl is None:
+            # first use is in the eager iteration that precedes any capture
+            assert not torch.cuda.is_current_stream_capturing(), \
+                "the first collective of a process must not be captured"
+            self._rccl = _Rccl(t.device)
+        return True
+
     @staticmethod
     def _to_host(t):
         torch.cuda.synchronize(t.device)
@@ -205,6 +286,8 @@ class Communicator(object):
             host = self._to_host(flat)
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             flat.copy_(host)
+        elif self._direct(flat):
+            self._rccl.all_reduce(flat)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if _DEBUG:
@@ -222,6 +305,10 @@ class Communicator(object):
             gathered = torch.empty(out.numel(), dtype=host.dtype)
             dist.all_gather_into_tensor(gathered, host)
             out.copy_(gathered)
+        elif self._direct(flat):
+            assert out.is_contiguous() and out.dtype == flat.dtype and \
+                out.numel() == self.world_size * flat.numel()
+            self._rccl.all_gather(out, flat)
         elif flat.is_cuda:
             dist.all_gather_into_tensor(out, flat)
         else:

@@ -79,7 +79,15 @@ def _rank():
 
 _CONV1X1_GEMM = os.environ.get("SINGA_CONV1X1_GEMM", "1") != "0"
 _CONV3X3_GEMM = os.environ.get("SINGA_CONV3X3_GEMM", "1") != "0"
-_CONV3X3_GEMM_MIN_HW = int(os.environ.get("SINGA_CONV3X3_GEMM_MIN_HW", "400"))
+_CONV_FLAT = os.environ.get("SINGA_CONV_FLAT", "1") != "0"
+# 1x1 layers with at most this many positions per image take the kernel over
+# flattened positions instead of one GEMM per image
+_CONV_FLAT_MAX_HW = int(os.environ.get("SINGA_CONV_FLAT_MAX_HW", "399"))
+# 3x3 layers need at least this many positions per image for that kernel (the
+# 7 x 7 layers have too few columns to fill the chip with its tiles)
+_CONV_FLAT_MIN_HW_3X3 = int(os.environ.get("SINGA_CONV_FLAT_MIN_HW_3X3", "64"))
+_CONV_WGRAD_GEMM = os.environ.get("SINGA_CONV_WGRAD_GEMM", "1") != "0"
+_CONV3X3_GEMM_MIN_HW = int(os.environ.get("SINGA_CONV3X3_GEMM_MIN_HW", "2000"))
 
 class HipMath(object):
     name = "hip"
@@ -634,8 +642,38 @@ class HipMath(object):
             wt.data_ptr(), addend.data_ptr() if addend is not None else 0,
             out.data_ptr(), self._s())
 
+    def _flat16(self, mode, act, w, addend, out, stride, pad, groups):
+        """16-bit 1x1 or 3x3 / pad 1 stride-1 convolution (forward or
+        backward-data) on the tap GEMM over the flattened positions of all
+        images; any image size.  False when the geometry does not fit."""
+        if not (_CONV_FLAT and groups == 1 and tuple(stride) == (1, 1) and
+                act.dtype in (torch.float16, torch.bfloat16) and
+                act.is_contiguous() and out.is_contiguous()):
+            return False
+        window = (w.shape[2], w.shape[3]) + tuple(pad)
+        if window not in ((1, 1, 0, 0), (3, 3, 1, 1)):
+            return False
+        N, _, H, W = act.shape
+        K, C = w.shape[0], w.shape[1]
+        taps = w.shape[2] * w.shape[3]
+        if taps == 9 and H * W < _CONV_FLAT_MIN_HW_3X3:
+            return False
+        wt = torch.empty(taps * K * C, dtype=w.dtype, device=w.device)
+        return self.k.conv_flat_h16(
+            _code(act), mode, N, C, K, H, W, taps, act.data_ptr(),
+            w.data_ptr(), wt.data_ptr(),
+            addend.data_ptr() if addend is not None else 0, out.data_ptr(),
+            self._s())
+
+    @staticmethod
+    def _small_image(t):
+        return t.shape[2] * t.shape[3] <= _CONV_FLAT_MAX_HW
+
     def conv_fwd(self, x, w, b, y, stride, pad, groups):
         w = self._contig(w)
+        if b is None and self._small_image(x) and \
+                self._flat16(0, x, w, None, y, stride, pad, groups):
+            return
         if b is None and self._pointwise16(x, w, stride, pad, groups):
             N, C, H, W = x.shape
             if self.k.conv1x1_h16(_code(x), 0, N, C, w.shape[0], H * W,
@@ -644,6 +682,8 @@ class HipMath(object):
                 return
         if b is None and self._window16(x, w, stride, pad, groups) and \
                 self._conv3x3_h16(0, x, w, None, y):
+            return
+        if b is None and self._flat16(0, x, w, None, y, stride, pad, groups):
             return
         g = self._geom(x.shape, w.shape, y.shape, stride, pad, groups)
         scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)
@@ -663,6 +703,9 @@ class HipMath(object):
         reached the same input along another path happens in the kernel's
         epilogue instead of in a separate pass over dx."""
         w = self._contig(w)
+        if addend is not None:
+            assert addend.shape == dx.shape and addend.dtype == dx.dtype \
+                and addend.data_ptr() != dx.data_ptr()
         if self._pointwise16(dx, w, stride, pad, groups):
             N, C, H, W = dx.shape
             ad = None
@@ -682,6 +725,10 @@ class HipMath(object):
                 ad = self._contig(addend)
             if self._conv3x3_h16(1, dy, w, ad, dx):
                 return
+        if self._flat16(1, dy, w,
+                        None if addend is None else self._contig(addend), dx,
+                        stride, pad, groups):
+            return
         g = self._geom(dx.shape, w.shape, dy.shape, stride, pad, groups)
         scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)
             g, dx, dx.shape[1] // groups,
@@ -702,7 +749,34 @@ class HipMath(object):
             self.k.conv_bwd_data_acc(code, g, args[0], args[1],
                                      addend.data_ptr(), args[2], self._s())
 
+    def _wgrad16(self, dy, x, dw, stride, pad, groups):
+        """16-bit weight gradient of a 1x1 or 3x3 / pad 1 stride-1 convolution
+        on the tiled 16-bit GEMM kernel (split reduction over positions,
+        float partial products); False when the geometry does not fit."""
+        if not (_CONV_WGRAD_GEMM and groups == 1 and
+                x.dtype in (torch.float16, torch.bfloat16) and
+                dw.dtype == x.dtype and tuple(stride) == (1, 1)):
+            return False
+        window = (dw.shape[2], dw.shape[3]) + tuple(pad)
+        if window not in ((1, 1, 0, 0), (3, 3, 1, 1)) or not (
+                dy.is_contiguous() and x.is_contiguous() and
+                dw.is_contiguous()):
+            return False
+        N, C, H, W = x.shape
+        K, taps = dw.shape[0], dw.shape[2] * dw.shape[3]
+        assert tuple(dy.shape) == (N, K, H, W) and dw.shape[1] == C
+        splits = self.k.conv_wgrad_h16_splits(N, C, K, H, W, taps)
+        if not splits:
+            return False
+        part = torch.empty(splits * taps * K * C, dtype=torch.float32,
+                           device=x.device)
+        return self.k.conv_wgrad_h16(
+            _code(x), N, C, K, H, W, taps, dy.data_ptr(), x.data_ptr(),
+            part.data_ptr(), splits, dw.data_ptr(), self._s())
+
     def conv_bwd_weight(self, dy, x, dw, stride, pad, groups):
+        if self._wgrad16(dy, x, dw, stride, pad, groups):
+            return
         g = self._geom(x.shape, dw.shape, dy.shape, stride, pad, groups)
         key = (tuple(x.shape), tuple(dw.shape), tuple(stride), tuple(pad),
                groups, _code(x))

@@ -265,6 +265,28 @@ PYBIND11_MODULE(_hip, m) {
     check(rc, "conv3x3_h16");
     return true;
   });
+  m.def("conv_flat_h16", [](int dt, int mode, int n_img, int C, int K, int H,
+                            int W, int taps, uintptr_t act, uintptr_t w,
+                            uintptr_t wt, uintptr_t addend, uintptr_t out,
+                            uintptr_t s) {
+    const int rc = sa_conv_flat_h16(dt, mode, n_img, C, K, H, W, taps, CP(act),
+                                    CP(w), P(wt), CP(addend), P(out), S(s));
+    if (rc == -3) return false;
+    check(rc, "conv_flat_h16");
+    return true;
+  });
+  m.def("conv_wgrad_h16_splits", &sa_conv_wgrad_h16_splits);
+  m.def("conv_wgrad_h16", [](int dt, int n_img, int C, int K, int H, int W,
+                             int taps, uintptr_t dy, uintptr_t x,
+                             uintptr_t part, int splits, uintptr_t dw,
+                             uintptr_t s) {
+    const int rc = sa_conv_wgrad_h16(dt, n_img, C, K, H, W, taps, CP(dy), CP(x),
+                                     reinterpret_cast<float *>(part), splits,
+                                     P(dw), S(s));
+    if (rc == -3) return false;
+    check(rc, "conv_wgrad_h16");
+    return true;
+  });
   m.def("conv_bwd_data", [](int dt, const ConvGeom &g, uintptr_t dy,
                             uintptr_t w, uintptr_t dx, uintptr_t s) {
     check(sa_conv_bwd_data(dt, &g, CP(dy), CP(w), P(dx), S(s)),

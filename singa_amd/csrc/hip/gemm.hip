@@ -927,6 +927,574 @@ static void launch_conv3x3_h16(const ConvTapArgs &a, int n_img, hipStream_t s) {
                      dim3(64 * WVM * WVN), 0, s, a, ntm, ntn);
 }
 
+// ---------------------------------------------------------------------------
+// 16-bit 1x1 / 3x3 stride-1 same-size convolution over flattened positions
+// ---------------------------------------------------------------------------
+// The same tap GEMM as above for images of any size, small ones included:
+// the GEMM's column index runs over the 8-position pieces of ALL images
+// (`ppi` pieces per image, the last one of an image possibly partial), so a
+// 14 x 14 or 7 x 7 layer fills whole tiles instead of one ragged tile per
+// image.  A piece's elements start at any 2-byte offset (odd image sizes, odd
+// tap shifts): it is fetched as five aligned dwords and funnel-shifted when
+// its first element sits in the upper half of a dword (VARPAR: decided per
+// thread and tile; otherwise the parity is the tap's).  All loads are
+// select-based, `DEPTH` reduction tiles are in flight in registers, and only
+// the few tiles that can reach past an end of the tensors (first / last image,
+// first / last channel block) take the dword-by-dword EDGE variant.
+struct ConvFlatArgs {
+  const void *wt;      // [taps][M][Kc]
+  const void *act;     // [n][Kc][HW]
+  const void *addend;  // [n][M][HW] or null
+  void *out;           // [n][M][HW]
+  int M, Kc, H, W, n_img, taps;
+  int ppi;             // pieces of 8 positions per image
+  unsigned ppi_magic;  // ceil(2^32 / ppi)
+};
+
+template <typename T, int WVM, int WVN, int TM, int TN, int DEPTH, bool VARPAR>
+__global__ void __launch_bounds__(64 * WVM * WVN)
+conv_flat_h16_kernel(ConvFlatArgs a, int ntm, int ntn) {
+  using namespace h16;
+  using frag = typename Half16<T>::frag;
+  constexpr int NT = 64 * WVM * WVN;
+  constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
+  using OpA = Operand<true, BM, NT>;
+  using OpB = Operand<false, BN, NT>;
+  constexpr int kImgA = BM * BK * 2, kImgB = BN * BK * 2;
+  constexpr int CPR = OpB::CPR, PERB = OpB::PER, PERA = OpA::PER;
+  __shared__ __attribute__((aligned(16))) char smem[2][kImgA + kImgB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WVN, wn = wid % WVN;
+  int pid_m, pid_n;
+  {
+    const int w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (w >= ntm * ntn) return;
+    pid_m = w % ntm;
+    pid_n = w / ntm;
+  }
+  const int m0 = pid_m * BM, n0 = pid_n * BN;
+  const int H = a.H, W = a.W, HW = H * W, Kc = a.Kc, M = a.M;
+  const int n_pieces = a.n_img * a.ppi;
+
+  OpA opa{__builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(a.wt), 0,
+                                            a.taps * M * Kc * 2, 0x00020000),
+          Kc, 1, m0, Kc};
+  const int limit_b = a.n_img * Kc * HW * 2;
+  const rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(a.act), 0, limit_b, 0x00020000);
+
+  // the eight positions all of this thread's activation pieces cover
+  const int chb = tid % CPR, krb = tid / CPR;
+  const int gb = n0 / 8 + chb;
+  const int nb = (int)__umulhi((unsigned)gb, a.ppi_magic);
+  const int pb = (gb - nb * a.ppi) * 8;
+  const bool live = nb < a.n_img;
+  const int eb = nb * Kc * HW + pb;  // element offset of the piece in row 0
+  unsigned top = 0, bottom = 0, left = 0, right = 0, beyond = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int p = pb + i;
+    if (p >= HW || !live) {
+      beyond |= 1u << i;
+    } else {
+      const int h = p / W, w = p - h * W;
+      if (h == 0) top |= 1u << i;
+      if (h == H - 1) bottom |= 1u << i;
+      if (w == 0) left |= 1u << i;
+      if (w == W - 1) right |= 1u << i;
+    }
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[DEPTH][PERA], rb[DEPTH][PERB];
+  const int ntc = Kc / BK;
+  const int steps = a.taps * ntc;
+
+  auto dw = [](const rsrc_t &rs, int o, int limit) {
+    const int at = (o >= 0 && o + 4 <= limit) ? o : kOobOff;
+    return __builtin_bit_cast(
+        unsigned, __builtin_amdgcn_raw_buffer_load_b32(rs, at, 0, 0));
+  };
+
+  auto fetch = [&](int t, u32x4 *ra, u32x4 *rb, auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    const int tap = t / ntc, kc = (t - tap * ntc) * BK;
+    const int r = a.taps == 9 ? tap / 3 : 1;
+    const int sft = a.taps == 9 ? tap - 3 * r : 1;
+    int oa[PERA];
+    opa.plan(tid, kc, oa);
+#pragma unroll
+    for (int j = 0; j < PERA; ++j)
+      oa[j] = oa[j] != kOobOff ? oa[j] + tap * M * Kc * 2 : kOobOff;
+    opa.load(oa, ra);
+    const unsigned inv = beyond | (r == 0 ? top : 0u) | (r == 2 ? bottom : 0u) |
+                         (sft == 0 ? left : 0u) | (sft == 2 ? right : 0u);
+    unsigned keep[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      keep[d] = (((inv >> (2 * d)) & 1u) ? 0u : 0x0000ffffu) |
+                (((inv >> (2 * d + 1)) & 1u) ? 0u : 0xffff0000u);
+    const int shift = (r - 1) * W + (sft - 1);
+    const bool want = inv != 0xffu;
+    // without VARPAR every element offset has the parity of the tap's shift
+    const bool tap_odd = sft != 1;
+#pragma unroll
+    for (int j = 0; j < PERB; ++j) {
+      const int kr = krb + (NT / CPR) * j;
+      const int e0 = eb + (kc + kr) * HW + shift;
+      const bool odd = VARPAR ? (e0 & 1) != 0 : tap_odd;
+      const int b0 = (e0 & ~1) * 2;
+      const bool five = VARPAR || tap_odd;
+      u32x4 lo;
+      unsigned hi = 0;
+      if (EDGE) {
+        lo.x = dw(rsrc_b, want ? b0 : kOobOff, limit_b);
+        lo.y = dw(rsrc_b, want ? b0 + 4 : kOobOff, limit_b);
+        lo.z = dw(rsrc_b, want ? b0 + 8 : kOobOff, limit_b);
+        lo.w = dw(rsrc_b, want ? b0 + 12 : kOobOff, limit_b);
+        if (five) hi = dw(rsrc_b, want ? b0 + 16 : kOobOff, limit_b);
+      } else {
+        lo = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                       rsrc_b, want ? b0 : kOobOff, 0, 0));
+        if (five)
+          hi = __builtin_bit_cast(
+              unsigned, __builtin_amdgcn_raw_buffer_load_b32(
+                            rsrc_b, want ? b0 + 16 : kOobOff, 0, 0));
+      }
+      u32x4 v = lo;
+      if (five) {
+        u32x4 sh;
+        sh.x = __builtin_amdgcn_alignbit(lo.y, lo.x, 16);
+        sh.y = __builtin_amdgcn_alignbit(lo.z, lo.y, 16);
+        sh.z = __builtin_amdgcn_alignbit(lo.w, lo.z, 16);
+        sh.w = __builtin_amdgcn_alignbit(hi, lo.w, 16);
+        v.x = odd ? sh.x : lo.x; v.y = odd ? sh.y : lo.y;
+        v.z = odd ? sh.z : lo.z; v.w = odd ? sh.w : lo.w;
+      }
+      v.x &= keep[0]; v.y &= keep[1]; v.z &= keep[2]; v.w &= keep[3];
+      rb[j] = v;
+    }
+  };
+  // tiles that can reach past an end of the activations: workgroups holding
+  // pieces of the first / last image, in the first / last channel block
+  const bool wg_lo = n0 / 8 < a.ppi;
+  const bool wg_hi = n0 / 8 + BN / 8 > n_pieces - a.ppi;
+  auto fetch_tile = [&](int t, u32x4 *ra, u32x4 *rb) {
+    const int kc = (t % ntc) * BK;
+    if ((wg_lo && kc == 0) || (wg_hi && kc + BK >= Kc))
+      fetch(t, ra, rb, std::true_type{});
+    else
+      fetch(t, ra, rb, std::false_type{});
+  };
+
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u)
+    if (u < steps) fetch_tile(u, ra[u], rb[u]);
+  OpA::store(tid, smem[0], ra[0]);
+  OpB::store(tid, smem[0] + kImgA, rb[0]);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < steps; t += DEPTH) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      const int tt = t + u;
+      if (tt >= steps) break;
+      const char *as = smem[cur], *bs = smem[cur] + kImgA;
+      if (tt + DEPTH < steps) fetch_tile(tt + DEPTH, ra[u], rb[u]);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        frag fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[i] = __builtin_bit_cast(
+              frag, OpA::frag(as, (wm * TM + i) * 32, ks, lane));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[j] = __builtin_bit_cast(
+              frag, OpB::frag(bs, (wn * TN + j) * 32, ks, lane));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = Half16<T>::mma(fa[i], fb[j], acc[i][j]);
+      }
+      if (tt + 1 < steps) {
+        OpA::store(tid, smem[cur ^ 1], ra[(u + 1) % DEPTH]);
+        OpB::store(tid, smem[cur ^ 1] + kImgA, rb[(u + 1) % DEPTH]);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  T *out = (T *)a.out;
+  const T *addend = (const T *)a.addend;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+    const int g = col >> 3;
+    const int n = (int)__umulhi((unsigned)g, a.ppi_magic);
+    const int p = (g - n * a.ppi) * 8 + (col & 7);
+    if (n >= a.n_img || p >= HW) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) +
+                        4 * (lane >> 5);
+        if (row >= M) continue;
+        const int64_t at = ((int64_t)n * M + row) * HW + p;
+        float v = acc[i][j][r];
+        if (addend) v += to_f<T>(addend[at]);
+        out[at] = from_f<T>(v);
+      }
+  }
+}
+
+// Filter re-layout for conv_flat_h16_kernel with `taps` taps (1 or 9).
+// mode 0 (forward): w is [M][Kc][taps], wt[tap][m][k] = w[m][k][tap].  mode 1
+// (backward-data): w is the forward filter [Kc][M][taps] seen from dY's side,
+// wt[tap][m][k] = w[k][m][taps - 1 - tap].
+template <typename T>
+__global__ void conv_flat_prep_kernel(const T *__restrict__ w,
+                                      T *__restrict__ wt, int M, int Kc,
+                                      int taps, int mode) {
+  const int64_t total = (int64_t)taps * M * Kc;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += step) {
+    const int k = (int)(e % Kc);
+    const int m = (int)((e / Kc) % M);
+    const int tap = (int)(e / ((int64_t)Kc * M));
+    wt[e] = mode == 0 ? w[((int64_t)m * Kc + k) * taps + tap]
+                      : w[((int64_t)k * M + m) * taps + (taps - 1 - tap)];
+  }
+}
+
+template <typename T, int WVM, int WVN, int TM, int TN, int DEPTH>
+static void launch_conv_flat(const ConvFlatArgs &a, bool varpar,
+                             hipStream_t s) {
+  constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
+  const int ntm = (a.M + BM - 1) / BM;
+  const int ntn = (a.n_img * a.ppi * 8 + BN - 1) / BN;
+  const dim3 grid((unsigned)(((int64_t)ntm * ntn + 7) / 8 * 8));
+  if (varpar)
+    hipLaunchKernelGGL(
+        (conv_flat_h16_kernel<T, WVM, WVN, TM, TN, DEPTH, true>), grid,
+        dim3(64 * WVM * WVN), 0, s, a, ntm, ntn);
+  else
+    hipLaunchKernelGGL(
+        (conv_flat_h16_kernel<T, WVM, WVN, TM, TN, DEPTH, false>), grid,
+        dim3(64 * WVM * WVN), 0, s, a, ntm, ntn);
+}
+
+// ---------------------------------------------------------------------------
+// 16-bit weight gradient of 1x1 and 3x3 / stride 1 / same-size convolutions
+// ---------------------------------------------------------------------------
+// dW[m][c][tap] = sum over images n and positions p of
+//                 dy[n][m][p] * x[n][c][p shifted by the tap]
+// Per tap this is a GEMM whose reduction index (the position) is contiguous in
+// BOTH operands, the layout the tiled 16-bit kernel reads fastest (16-byte
+// pieces into a row-major LDS image, ds_read_b128 fragments).  The reduction
+// runs over the flattened list of 8-position pieces of all images (`ppi`
+// pieces per image, so images whose size is not a multiple of 64 positions
+// waste no matrix work); a reduction tile is 8 consecutive pieces.  The x
+// pieces of a shifted tap are fetched at the shifted byte offset (odd shifts
+// as five aligned dwords funnel-shifted into four) and cleared where the tap
+// leaves the image.  The reduction is cut into `splits` ranges; a workgroup
+// (tile, tap, split) writes its float partial product to
+// part[split][tap][M][Nc], summed and cast by wgrad_reduce_kernel.
+struct WgradArgs {
+  const void *dy;  // [n][M][HW]
+  const void *x;   // [n][Nc][HW]
+  float *part;     // [splits][taps][M][Nc]
+  int M, Nc, H, W, n_img;
+  int ppi;         // pieces of 8 positions per image
+  int tiles;       // reduction tiles in total
+  int per_split;   // reduction tiles per split
+  int taps;        // 1 or 9
+  int splits;
+  unsigned ppi_magic, w_magic;  // ceil(2^32 / d): umulhi(v, magic) == v / d
+};
+
+template <typename T, int WVM, int WVN, int TM, int TN, int DEPTH>
+__global__ void __launch_bounds__(64 * WVM * WVN)
+conv_wgrad_h16_kernel(WgradArgs a, int ntm, int ntn) {
+  using namespace h16;
+  using frag = typename Half16<T>::frag;
+  constexpr int NT = 64 * WVM * WVN;
+  constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
+  using OpA = Operand<true, BM, NT>;
+  using OpB = Operand<true, BN, NT>;
+  constexpr int PERA = OpA::PER, PERB = OpB::PER;
+  constexpr int kImgA = BM * BK * 2, kImgB = BN * BK * 2;
+  __shared__ __attribute__((aligned(16))) char smem[2][kImgA + kImgB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WVN, wn = wid % WVN;
+  // Workgroup ids go round-robin over the 8 XCDs: XCD x takes the x-th eighth
+  // of the work list, which is ordered split-major, so the workgroups that
+  // read the same positions (all tiles and taps of one split) share an L2.
+  int pid_m, pid_n, tap, split;
+  {
+    const int per_split = ntm * ntn * a.taps;
+    const int w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (w >= per_split * a.splits) return;
+    split = w / per_split;
+    const int in = w - split * per_split;
+    tap = in / (ntm * ntn);
+    const int tile = in - tap * (ntm * ntn);
+    pid_m = tile % ntm;
+    pid_n = tile / ntm;
+  }
+  const int m0 = pid_m * BM, n0 = pid_n * BN;
+  const int H = a.H, W = a.W, HW = H * W, M = a.M, Nc = a.Nc;
+  const int dr = a.taps == 9 ? tap / 3 - 1 : 0;
+  const int ds = a.taps == 9 ? tap % 3 - 1 : 0;
+  const int shift = dr * W + ds;
+
+  const int limit_a = a.n_img * M * HW * 2, limit_b = a.n_img * Nc * HW * 2;
+  const rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(a.dy), 0, limit_a, 0x00020000);
+  const rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void *>(a.x), 0, limit_b, 0x00020000);
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // DEPTH reduction tiles are in flight in registers: the loads of tile
+  // t + DEPTH are issued while tile t is multiplied, so a workgroup keeps
+  // streaming although one load takes about a microsecond
+  u32x4 ra[DEPTH][PERA], rb[DEPTH][PERB];
+  const int ch = tid & 7, r_first = tid >> 3;
+
+  auto expand = [](unsigned bits, unsigned *keep) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+      keep[d] = (((bits >> (2 * d)) & 1u) ? 0x0000ffffu : 0u) |
+                (((bits >> (2 * d + 1)) & 1u) ? 0xffff0000u : 0u);
+  };
+  // One dword, range-checked on its own; offsets are redirected one by one so
+  // that the loads cannot be fused back into a wide load, which is
+  // range-checked as a whole.
+  auto dw = [](const rsrc_t &rs, int o, int limit) {
+    const int at = (o >= 0 && o + 4 <= limit) ? o : kOobOff;
+    return __builtin_bit_cast(
+        unsigned, __builtin_amdgcn_raw_buffer_load_b32(rs, at, 0, 0));
+  };
+
+  // Loads of reduction tile t into one register stage.  Everything is
+  // select-based (an unwanted piece is fetched at the out-of-range offset and
+  // reads zero): divergent branches around the loads would make the wave
+  // wait for each piece in turn.  EDGE is the variant for the few tiles at
+  // the two ends of the tensors, where a shifted or overhanging piece may
+  // start before the buffer or end behind it: it fetches dword by dword.
+  auto fetch = [&](int t, u32x4 *ra, u32x4 *rb, auto edge_tag) {
+    constexpr bool EDGE = decltype(edge_tag)::value;
+    // this thread's piece of the reduction tile: image n, positions p .. p + 7
+    const int g = t * 8 + ch;
+    const int n = (int)__umulhi((unsigned)g, a.ppi_magic);
+    const int p = (g - n * a.ppi) * 8;
+    const bool live = n < a.n_img;
+    const int tail = HW - p;  // valid positions in the piece when < 8
+    unsigned keep_a[4], keep_b[4];
+    const unsigned tailbits = tail >= 8 ? 0xffu : ((1u << tail) - 1u);
+    unsigned bbits = tailbits;
+    if (a.taps == 9) {
+      const int h = (int)__umulhi((unsigned)p, a.w_magic);
+      const int w0 = p - h * W;
+      const int e_wrap = W - w0;  // first element on row h + 1
+      const unsigned first = e_wrap >= 8 ? 0xffu : ((1u << e_wrap) - 1u);
+      const unsigned second = 0xffu & ~first;
+      const bool v1 = h < H && (unsigned)(h + dr) < (unsigned)H;
+      const bool v2 = h + 1 < H && (unsigned)(h + 1 + dr) < (unsigned)H;
+      bbits = (v1 ? first : 0u) | (v2 ? second : 0u);
+      if (ds < 0)
+        bbits &= ~((w0 == 0 ? 1u : 0u) | (e_wrap < 8 ? (1u << e_wrap) : 0u));
+      if (ds > 0) bbits &= ~(e_wrap <= 8 ? (1u << (e_wrap - 1)) : 0u);
+    }
+    if (!live) bbits = 0u;
+    expand(tailbits, keep_a);
+    expand(bbits, keep_b);
+#pragma unroll
+    for (int j = 0; j < PERA; ++j) {
+      const int r = m0 + r_first + (NT / 8) * j;
+      const bool want = live && r < M;
+      const int b0 = ((n * M + r) * HW + p) * 2;
+      u32x4 v;
+      if (EDGE) {
+        v.x = dw(rsrc_a, want ? b0 : kOobOff, limit_a);
+        v.y = dw(rsrc_a, want ? b0 + 4 : kOobOff, limit_a);
+        v.z = dw(rsrc_a, want ? b0 + 8 : kOobOff, limit_a);
+        v.w = dw(rsrc_a, want ? b0 + 12 : kOobOff, limit_a);
+      } else {
+        v = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                       rsrc_a, want ? b0 : kOobOff, 0, 0));
+      }
+      v.x &= keep_a[0]; v.y &= keep_a[1]; v.z &= keep_a[2]; v.w &= keep_a[3];
+      ra[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < PERB; ++j) {
+      const int r = n0 + r_first + (NT / 8) * j;
+      const bool want = bbits != 0u && r < Nc;
+      const int byte = ((n * Nc + r) * HW + p + shift) * 2;
+      // first aligned dword touched; an odd shift needs five dwords
+      const int b0 = ds == 0 ? byte : byte - 2;
+      u32x4 lo;
+      unsigned hi = 0;
+      if (EDGE) {
+        lo.x = dw(rsrc_b, want ? b0 : kOobOff, limit_b);
+        lo.y = dw(rsrc_b, want ? b0 + 4 : kOobOff, limit_b);
+        lo.z = dw(rsrc_b, want ? b0 + 8 : kOobOff, limit_b);
+        lo.w = dw(rsrc_b, want ? b0 + 12 : kOobOff, limit_b);
+        if (ds != 0) hi = dw(rsrc_b, want ? b0 + 16 : kOobOff, limit_b);
+      } else {
+        lo = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                       rsrc_b, want ? b0 : kOobOff, 0, 0));
+        if (ds != 0)
+          hi = __builtin_bit_cast(
+              unsigned, __builtin_amdgcn_raw_buffer_load_b32(
+                            rsrc_b, want ? b0 + 16 : kOobOff, 0, 0));
+      }
+      u32x4 v = lo;
+      if (ds != 0) {
+        v.x = __builtin_amdgcn_alignbit(lo.y, lo.x, 16);
+        v.y = __builtin_amdgcn_alignbit(lo.z, lo.y, 16);
+        v.z = __builtin_amdgcn_alignbit(lo.w, lo.z, 16);
+        v.w = __builtin_amdgcn_alignbit(hi, lo.w, 16);
+      }
+      v.x &= keep_b[0]; v.y &= keep_b[1]; v.z &= keep_b[2]; v.w &= keep_b[3];
+      rb[j] = v;
+    }
+  };
+  // tiles whose pieces may reach W + 1 positions past an end of the tensors
+  const int edge_lo = ((W + 23) / 8 + 7) / 8;                  // tiles [0, lo)
+  const int edge_hi = (a.n_img * a.ppi - (W + 24) / 8 - 1) / 8;  // [hi, ...)
+  auto fetch_tile = [&](int t, u32x4 *ra, u32x4 *rb) {
+    if (t < edge_lo || t >= edge_hi) fetch(t, ra, rb, std::true_type{});
+    else fetch(t, ra, rb, std::false_type{});
+  };
+
+  const int t0 = split * a.per_split;
+  const int t1 = min(a.tiles, t0 + a.per_split);
+#pragma unroll
+  for (int u = 0; u < DEPTH; ++u)
+    if (t0 + u < t1) fetch_tile(t0 + u, ra[u], rb[u]);
+  if (t0 < t1) {
+    OpA::store(tid, smem[0], ra[0]);
+    OpB::store(tid, smem[0] + kImgA, rb[0]);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int t = t0; t < t1; t += DEPTH) {
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+      const int tt = t + u;
+      if (tt >= t1) break;
+      // tile tt sits in LDS; its registers (slot u) take tile tt + DEPTH
+      const char *as = smem[cur], *bs = smem[cur] + kImgA;
+      if (tt + DEPTH < t1) fetch_tile(tt + DEPTH, ra[u], rb[u]);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        frag fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          fa[i] = __builtin_bit_cast(
+              frag, OpA::frag(as, (wm * TM + i) * 32, ks, lane));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fb[j] = __builtin_bit_cast(
+              frag, OpB::frag(bs, (wn * TN + j) * 32, ks, lane));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = Half16<T>::mma(fa[i], fb[j], acc[i][j]);
+      }
+      if (tt + 1 < t1) {
+        // the other buffer was last read before the previous barrier
+        OpA::store(tid, smem[cur ^ 1], ra[(u + 1) % DEPTH]);
+        OpB::store(tid, smem[cur ^ 1] + kImgA, rb[(u + 1) % DEPTH]);
+      }
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  float *part = a.part + ((int64_t)split * a.taps + tap) * M * Nc;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+      if (col >= Nc) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) +
+                        4 * (lane >> 5);
+        if (row >= M) continue;
+        part[(int64_t)row * Nc + col] = acc[i][j][r];
+      }
+    }
+}
+
+// dw[m][c][tap] = sum over splits of part[split][tap][m][c], in dw's type.
+// A block sums 32 consecutive elements; its 8 groups of 32 threads each take
+// every eighth split (coalesced 128-byte reads) and meet in LDS.
+template <typename T>
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float *__restrict__ part, int splits, int taps,
+                    int64_t mn, T *__restrict__ dw) {
+  __shared__ float sums[8][33];
+  const int64_t total = mn * taps;
+  const int ii = threadIdx.x & 31, si = threadIdx.x >> 5;
+  const int64_t i = (int64_t)blockIdx.x * 32 + ii;
+  float v = 0.f;
+  if (i < total)
+    for (int sp = si; sp < splits; sp += 8) v += part[sp * total + i];
+  sums[si][ii] = v;
+  __syncthreads();
+  if (si == 0 && i < total) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v += sums[k][ii];
+    const int64_t tap = i / mn, e = i - tap * mn;
+    dw[e * taps + tap] = from_f<T>(v);
+  }
+}
+
+template <typename T, int WVM, int WVN, int TM, int TN, int DEPTH>
+static void launch_wgrad_h16(const WgradArgs &a, hipStream_t s) {
+  constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
+  const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nc + BN - 1) / BN;
+  const int64_t wgs = (int64_t)ntm * ntn * a.taps * a.splits;
+  hipLaunchKernelGGL((conv_wgrad_h16_kernel<T, WVM, WVN, TM, TN, DEPTH>),
+                     dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(64 * WVM * WVN),
+                     0, s, a, ntm, ntn);
+}
+
+// Tile of the weight-gradient kernel for an M x Nc filter matrix: rows, columns
+static void wgrad_tile(int M, int Nc, int *bm, int *bn) {
+  *bm = M <= 64 ? 64 : 128;
+  *bn = Nc <= 64 ? 64 : 128;
+}
+
 template <int BM, int BN>
 void launch_f32(const GemmArgs &g, int amode, int bmode, dim3 grid,
                 hipStream_t s) {
@@ -1173,6 +1741,131 @@ int sa_conv3x3_h16(int dtype, int mode, int n_img, int C, int K, int H, int W,
                          (const T *)w, (T *)wt, M, Kc, mode);
       if (M <= 64) launch_conv3x3_h16<T, 1, 4, 2, 1>(a, n_img, s);
       else launch_conv3x3_h16<T, 2, 2, 2, 2>(a, n_img, s);
+    }
+  });
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// Split count of the 16-bit weight-gradient kernel for a K x C filter with
+// `taps` taps over n_img images of H x W positions; `part` must hold
+// splits * taps * K * C floats.  0 when the geometry does not fit the kernel
+// (the caller then uses the implicit-GEMM convolution kernel).
+int sa_conv_wgrad_h16_splits(int n_img, int C, int K, int H, int W, int taps) {
+  const int64_t HW = (int64_t)H * W;
+  if ((taps != 1 && taps != 9) || n_img <= 0 || C < 8 || K < 8 || W < 8 ||
+      W % 2 != 0 || HW < 64 ||
+      (int64_t)n_img * std::max(C, K) * HW >= ((int64_t)1 << 29))
+    return 0;
+  static const int forced = [] {
+    const char *v = getenv("SA_WGRAD_SPLITS");
+    return v && *v ? atoi(v) : 0;
+  }();
+  int bm, bn;
+  wgrad_tile(K, C, &bm, &bn);
+  const int64_t base =
+      (int64_t)((K + bm - 1) / bm) * ((C + bn - 1) / bn) * taps;
+  const int64_t ppi = (HW + 7) / 8;
+  const int64_t tiles = (n_img * ppi + 7) / 8;
+  // Measured on ResNet-50's layers: about 576 workgroups in all is the best
+  // trade between filling the CUs and the traffic of the partial products
+  // (each split writes and re-reads a whole filter gradient); at least four
+  // reduction tiles per workgroup, at most 24 MB of partial products.
+  int64_t splits = std::max<int64_t>(1, 576 / base);
+  splits = std::min(splits, std::max<int64_t>(1, tiles / 4));
+  splits = std::min(
+      splits, std::max<int64_t>(1, ((int64_t)6 << 20) / ((int64_t)taps * K * C)));
+  if (forced > 0) splits = std::min<int64_t>(forced, tiles);
+  const int64_t per = (tiles + splits - 1) / splits;
+  return (int)((tiles + per - 1) / per);
+}
+
+// dw (K x C x taps, 16-bit) = weight gradient of a 1x1 (taps 1) or 3x3 / pad 1
+// (taps 9) stride-1 convolution from dy [n][K][H][W] and x [n][C][H][W].
+int sa_conv_wgrad_h16(int dtype, int n_img, int C, int K, int H, int W,
+                      int taps, const void *dy, const void *x, float *part,
+                      int splits, void *dw, hipStream_t s) {
+  if (dtype != kF16 && dtype != kBF16) return -1;
+  if (splits <= 0 ||
+      splits != sa_conv_wgrad_h16_splits(n_img, C, K, H, W, taps))
+    return -3;
+  auto al16 = [](const void *p) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  };
+  if (!al16(dy) || !al16(x) || !al16(part)) return -3;
+  const int HW = H * W;
+  WgradArgs a{};
+  a.dy = dy; a.x = x; a.part = part;
+  a.M = K; a.Nc = C; a.H = H; a.W = W; a.n_img = n_img;
+  a.ppi = (HW + 7) / 8;
+  a.tiles = (n_img * a.ppi + 7) / 8;
+  a.per_split = (a.tiles + splits - 1) / splits;
+  a.taps = taps;
+  a.splits = splits;
+  a.ppi_magic = (unsigned)((((uint64_t)1 << 32) + a.ppi - 1) / a.ppi);
+  a.w_magic = (unsigned)((((uint64_t)1 << 32) + W - 1) / W);
+  int bm, bn;
+  wgrad_tile(K, C, &bm, &bn);
+  SA_DISPATCH_FLOAT(dtype, T, {
+    if constexpr (!std::is_same<T, float>::value) {
+      if (bm == 64 && bn == 64) launch_wgrad_h16<T, 2, 2, 1, 1, 4>(a, s);
+      else if (bm == 64) launch_wgrad_h16<T, 1, 4, 2, 1, 3>(a, s);
+      else if (bn == 64) launch_wgrad_h16<T, 4, 1, 1, 2, 3>(a, s);
+      else launch_wgrad_h16<T, 2, 2, 2, 2, 3>(a, s);
+      hipLaunchKernelGGL((wgrad_reduce_kernel<T>),
+                         dim3((unsigned)(((int64_t)taps * K * C + 31) / 32)),
+                         dim3(256), 0, s, part, splits, taps, (int64_t)K * C,
+                         (T *)dw);
+    }
+  });
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// 16-bit 1x1 (taps 1) or 3x3 / pad 1 (taps 9) stride-1 convolution over the
+// flattened positions of all images, forward (mode 0) and backward-data
+// (mode 1); any image size.  `wt` is workspace of taps * C * K elements for
+// the re-laid-out filter (unused for a forward 1x1).  Returns -3 when the
+// geometry does not fit (caller uses the implicit-GEMM convolution kernel).
+int sa_conv_flat_h16(int dtype, int mode, int n_img, int C, int K, int H,
+                     int W, int taps, const void *act, const void *w, void *wt,
+                     const void *addend, void *out, hipStream_t s) {
+  if (dtype != kF16 && dtype != kBF16) return -1;
+  if (n_img <= 0) return 0;
+  const int M = mode == 0 ? K : C, Kc = mode == 0 ? C : K;
+  auto al16 = [](const void *p) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  };
+  const int64_t HW = (int64_t)H * W;
+  if ((taps != 1 && taps != 9) || Kc % 64 != 0 || M < 8 || H < 1 || W < 1 ||
+      (taps == 9 && (H < 2 || W < 2)) || !al16(act) || !al16(out) ||
+      !al16(wt) || !al16(w) ||
+      (int64_t)n_img * std::max(M, Kc) * HW >= ((int64_t)1 << 29) ||
+      (int64_t)taps * M * Kc >= ((int64_t)1 << 29))
+    return -3;
+  const bool direct = taps == 1 && mode == 0;  // w already is [M][Kc]
+  ConvFlatArgs a{direct ? w : wt, act, addend, out, M, Kc, H, W, n_img, taps};
+  a.ppi = (int)((HW + 7) / 8);
+  a.ppi_magic = (unsigned)((((uint64_t)1 << 32) + a.ppi - 1) / a.ppi);
+  const bool varpar = (HW % 2 != 0) || (W % 2 != 0);
+  const int64_t cols = (int64_t)n_img * a.ppi * 8;
+  auto wgs = [&](int bm, int bn) {
+    return (int64_t)((M + bm - 1) / bm) * ((cols + bn - 1) / bn);
+  };
+  const int64_t total = (int64_t)taps * M * Kc;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    if constexpr (!std::is_same<T, float>::value) {
+      if (!direct)
+        hipLaunchKernelGGL((conv_flat_prep_kernel<T>),
+                           dim3(grid_for(total, 256)), dim3(256), 0, s,
+                           (const T *)w, (T *)wt, M, Kc, taps, mode);
+      // the largest tile that still gives every CU a workgroup and a bit
+      if (M > 64 && wgs(128, 128) >= 320)
+        launch_conv_flat<T, 2, 2, 2, 2, 3>(a, varpar, s);
+      else if (M <= 64 && wgs(64, 128) >= 320)
+        launch_conv_flat<T, 1, 4, 2, 1, 3>(a, varpar, s);
+      else if (M > 64 && wgs(128, 64) >= 320)
+        launch_conv_flat<T, 4, 1, 1, 2, 3>(a, varpar, s);
+      else
+        launch_conv_flat<T, 2, 2, 1, 1, 4>(a, varpar, s);
     }
   });
   return hipGetLastError() == hipSuccess ? 0 : -1;

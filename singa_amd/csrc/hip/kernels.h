@@ -126,6 +126,21 @@ int sa_conv1x1_h16(int dtype, int mode, int64_t n_img, int64_t C, int64_t K,
 int sa_conv3x3_h16(int dtype, int mode, int n_img, int C, int K, int H, int W,
                    const void *act, const void *w, void *wt,
                    const void *addend, void *out, hipStream_t s);
+// 16-bit 1x1 (taps 1) or 3x3 / pad 1 (taps 9) stride-1 convolution over the
+// flattened positions of all images (any image size), forward (mode 0) and
+// backward-data (mode 1, optional addend of dx's shape).  wt: workspace of
+// taps * C * K elements.  Returns -3 when the geometry does not fit.
+int sa_conv_flat_h16(int dtype, int mode, int n_img, int C, int K, int H,
+                     int W, int taps, const void *act, const void *w, void *wt,
+                     const void *addend, void *out, hipStream_t s);
+// 16-bit weight gradient of a 1x1 (taps 1) or 3x3 / pad 1 (taps 9) stride-1
+// convolution on the tiled 16-bit kernel with a split reduction.  _splits
+// returns the split count (0 = geometry not supported); part is workspace of
+// splits * taps * K * C floats; dw is [K][C][taps] in the operands' type.
+int sa_conv_wgrad_h16_splits(int n_img, int C, int K, int H, int W, int taps);
+int sa_conv_wgrad_h16(int dtype, int n_img, int C, int K, int H, int W,
+                      int taps, const void *dy, const void *x, float *part,
+                      int splits, void *dw, hipStream_t s);
 
 // device-to-device copy / zero-fill as kernels (4-byte aligned pointers)
 int sa_copy_bytes(void *dst, const void *src, int64_t bytes, hipStream_t s);

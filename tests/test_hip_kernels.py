@@ -533,6 +533,94 @@ def test_conv3x3_16bit_tap_gemm_path(maths, dt, N, C, K, H, W):
     close(dx, rdx + add.float())
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,C,K,H,W,R", [
+    (5, 64, 96, 14, 14, 3),     # 196 positions: half-filled last piece
+    (6, 128, 64, 7, 7, 3),      # odd image size: per-piece parity
+    (3, 64, 200, 7, 7, 1),      # 1x1 on an odd image size
+    (2, 192, 72, 5, 9, 3),      # odd row length with an even-sized... image
+    (40, 64, 64, 14, 14, 1),    # 1x1 over many small images, 64-row tiles
+    (33, 128, 256, 14, 14, 3),  # enough columns for the 128 x 128 tile
+    (2, 64, 40, 28, 28, 3),     # larger image through the same kernel
+])
+def test_conv_16bit_flattened_positions_path(maths, dt, N, C, K, H, W, R,
+                                             monkeypatch):
+    """16-bit 1x1 and 3x3 / pad 1 stride-1 convolutions over the flattened
+    positions of all images (forward, backward-data with and without the fused
+    addend), including odd image sizes; reference: fp32 convolution on the
+    same rounded inputs."""
+    from singa_amd.core import math_hip
+    # the routing threshold keeps tiny 3x3 images off this kernel for speed
+    monkeypatch.setattr(math_hip, "_CONV_FLAT_MIN_HW_3X3", 0)
+    hm, cm, dev = maths
+    pad = (R // 2, R // 2)
+    x = rnd(N, C, H, W, seed=80).to(dt)
+    w = rnd(K, C, R, R, seed=81, lo=-0.3, hi=0.3).to(dt)
+    eps = 2 ** -10 if dt == torch.float16 else 2 ** -7
+
+    def close(got, ref):
+        ref = ref.numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got.float().cpu().numpy(), ref,
+                                   atol=eps * scale, rtol=2 * eps)
+
+    ry = torch.empty(N, K, H, W)
+    cm.conv_fwd(x.float(), w.float(), None, ry, (1, 1), pad, 1)
+    y = torch.zeros(N, K, H, W, device=dev.torch_device, dtype=dt)
+    assert hm._flat16(0, g(x, dev), g(w, dev), None, y, (1, 1), pad, 1)
+    close(y, ry)
+    dy = rnd(N, K, H, W, seed=82).to(dt)
+    add = rnd(N, C, H, W, seed=83).to(dt)
+    rdx = torch.empty(N, C, H, W)
+    cm.conv_bwd_data(dy.float(), w.float(), rdx, (1, 1), pad, 1)
+    dx = torch.zeros(N, C, H, W, device=dev.torch_device, dtype=dt)
+    if K % 64 == 0:
+        assert hm._flat16(1, g(dy, dev), g(w, dev), None, dx, (1, 1), pad, 1)
+        close(dx, rdx)
+        assert hm._flat16(1, g(dy, dev), g(w, dev), g(add, dev), dx, (1, 1),
+                          pad, 1)
+        close(dx, rdx + add.float())
+    else:
+        assert not hm._flat16(1, g(dy, dev), g(w, dev), None, dx, (1, 1), pad,
+                              1)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (1, 1), pad, 1, g(add, dev))
+    close(dx, rdx + add.float())
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,C,K,H,W,R", [
+    (2, 64, 64, 56, 56, 3),     # 64 x 64 tiles, whole pieces
+    (3, 128, 96, 28, 28, 3),    # 128 x 128 tiles with a ragged row tile
+    (5, 72, 256, 14, 14, 3),    # 196 positions: half-filled last piece
+    (2, 40, 64, 10, 12, 3),     # pieces spanning two image rows, odd counts
+    (3, 64, 256, 14, 14, 1),    # 1x1: 128 x 64 tiles
+    (2, 256, 64, 28, 28, 1),    # 1x1: 64 x 128 tiles
+    (4, 136, 200, 9, 8, 1),     # 1x1: ragged tiles in both directions
+])
+def test_conv_weight_gradient_16bit_gemm_path(maths, dt, N, C, K, H, W, R):
+    """16-bit weight gradients of 1x1 and 3x3 / pad 1 stride-1 convolutions
+    run on the tiled 16-bit kernel with the reduction over positions split
+    across workgroups; reference: fp32 weight gradient on the same rounded
+    inputs."""
+    hm, cm, dev = maths
+    pad = (R // 2, R // 2)
+    x = rnd(N, C, H, W, seed=70).to(dt)
+    dy = rnd(N, K, H, W, seed=71).to(dt)
+    rdw = torch.empty(K, C, R, R)
+    cm.conv_bwd_weight(dy.float(), x.float(), rdw, (1, 1), pad, 1)
+    dw = torch.zeros(K, C, R, R, device=dev.torch_device, dtype=dt)
+    assert hm._wgrad16(g(dy, dev), g(x, dev), dw, (1, 1), pad, 1)
+    eps = 2 ** -10 if dt == torch.float16 else 2 ** -7
+    ref = rdw.numpy()
+    scale = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(dw.float().cpu().numpy(), ref,
+                               atol=eps * scale, rtol=2 * eps)
+    dw.zero_()
+    hm.conv_bwd_weight(g(dy, dev), g(x, dev), dw, (1, 1), pad, 1)
+    np.testing.assert_allclose(dw.float().cpu().numpy(), ref,
+                               atol=eps * scale, rtol=2 * eps)
+
+
 @pytest.mark.parametrize("N,C,K,HW", [(2, 16, 64, 56), (3, 24, 96, 28),
                                       (2, 64, 40, 14), (1, 8, 128, 56),
                                       (2, 72, 64, 28)])

@@ -2118,7 +2118,7 @@ class _Conv2d(Operator):
         if training:
             self.inputs = (x, W, b) if self.handle.bias_term else (x, W)
         return singa.ConvForward(x, W, b if self.handle.bias_term else None,
-                                 self.handle)
+                                 self.handle, emit_stats=bool(training))
 
     def backward(self, dy):
         assert training is True and hasattr(

@@ -206,8 +206,19 @@ class CpuMath(object):
         dx.div_(p.shape[0])
 
     # ---- convolution ------------------------------------------------------------------
-    def conv_fwd(self, x, w, b, y, stride, pad, groups):
+    STAT_COPIES = 1
+
+    def conv_fwd(self, x, w, b, y, stride, pad, groups, stats=None,
+                 shift=None):
+        """``stats`` (float[STAT_COPIES * 2 * K + K]) receives the output's
+        per-channel sums of y - shift and (y - shift)^2, for a following batch
+        normalisation that then skips its own statistics pass."""
         y.copy_(F.conv2d(x, w, b, stride=stride, padding=pad, groups=groups))
+        if stats is not None:
+            K = y.shape[1]
+            d = y.float() - shift.float().reshape(1, K, 1, 1)
+            stats[:K] += d.sum(dim=(0, 2, 3))
+            stats[K:2 * K] += (d * d).sum(dim=(0, 2, 3))
 
     def conv_bwd_data(self, dy, w, dx, stride, pad, groups, addend=None):
         r = torch.nn.grad.conv2d_input(dx.shape, w, dy, stride=stride,
@@ -232,15 +243,24 @@ class CpuMath(object):
         return z
 
     def bn_fwd_train(self, x, scale, bias, rmean, rvar, factor, eps, y, mean,
-                     invstd, act=0, residual=None):
+                     invstd, act=0, residual=None, stats=None):
         """Channel statistics over (N, H, W) (or N for 2-d input).  Running
         stats follow running = (1 - factor) * running + factor * batch with the
-        unbiased batch variance."""
+        unbiased batch variance.  With ``stats`` (filled by the producer of x,
+        see conv_fwd) the statistics are taken from there and the buffer is
+        cleared for the next step."""
         dims = [0] + list(range(2, x.dim()))
         m = x.numel() // x.shape[1]
         xf = x.float()
-        mu = xf.mean(dim=dims)
-        var = xf.var(dim=dims, unbiased=False)
+        if stats is not None:
+            C = x.shape[1]
+            dm = stats[:C] / m
+            mu = rmean.float() + dm
+            var = (stats[C:2 * C] / m - dm * dm).clamp_(min=0)
+            stats.zero_()
+        else:
+            mu = xf.mean(dim=dims)
+            var = xf.var(dim=dims, unbiased=False)
         istd = torch.rsqrt(var + eps)
         shp = [1, -1] + [1] * (x.dim() - 2)
         y.copy_(self._bn_act(

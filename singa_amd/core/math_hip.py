@@ -669,21 +669,25 @@ class HipMath(object):
     def _small_image(t):
         return t.shape[2] * t.shape[3] <= _CONV_FLAT_MAX_HW
 
-    def conv_fwd(self, x, w, b, y, stride, pad, groups):
+    @property
+    def STAT_COPIES(self):
+        return self.k.stat_copies
+
+    def conv_fwd(self, x, w, b, y, stride, pad, groups, stats=None,
+                 shift=None):
+        """``stats`` (float[STAT_COPIES * 2 * K + K], zero on entry) receives
+        the output's per-channel sums of y - shift and (y - shift)^2 for a
+        following batch normalisation: from the convolution kernel's epilogue
+        where it has one, else from one pass over y."""
         w = self._contig(w)
-        if b is None and self._small_image(x) and \
-                self._flat16(0, x, w, None, y, stride, pad, groups):
-            return
-        if b is None and self._pointwise16(x, w, stride, pad, groups):
-            N, C, H, W = x.shape
-            if self.k.conv1x1_h16(_code(x), 0, N, C, w.shape[0], H * W,
-                                  x.data_ptr(), w.data_ptr(), 0, y.data_ptr(),
-                                  self._s()):
-                return
-        if b is None and self._window16(x, w, stride, pad, groups) and \
-                self._conv3x3_h16(0, x, w, None, y):
-            return
-        if b is None and self._flat16(0, x, w, None, y, stride, pad, groups):
+        if stats is not None:
+            assert stats.dtype == torch.float32 and \
+                shift.dtype == torch.float32 and shift.is_contiguous()
+        if self._conv_fwd_16bit(x, w, b, y, stride, pad, groups):
+            if stats is not None:
+                self.k.chan_sums(_code(y), y.data_ptr(), stats.data_ptr(),
+                                 shift.data_ptr(), y.shape[0], y.shape[1],
+                                 y.shape[2] * y.shape[3], self._s())
             return
         g = self._geom(x.shape, w.shape, y.shape, stride, pad, groups)
         scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)
@@ -696,7 +700,28 @@ class HipMath(object):
                groups, code)
         self._tuned(0, g, key,
                     lambda gg: self.k.conv_fwd(code, gg, *args, self._s()))
+        if stats is not None:
+            # only now: the timing launches above must not add to the sums
+            g.set_stats(stats.data_ptr(), shift.data_ptr())
         self.k.conv_fwd(code, g, *args, self._s())
+
+    def _conv_fwd_16bit(self, x, w, b, y, stride, pad, groups):
+        """The 16-bit GEMM-shaped forward kernels; False when none applies."""
+        if b is not None:
+            return False
+        if self._small_image(x) and \
+                self._flat16(0, x, w, None, y, stride, pad, groups):
+            return True
+        if self._pointwise16(x, w, stride, pad, groups):
+            N, C, H, W = x.shape
+            if self.k.conv1x1_h16(_code(x), 0, N, C, w.shape[0], H * W,
+                                  x.data_ptr(), w.data_ptr(), 0, y.data_ptr(),
+                                  self._s()):
+                return True
+        if self._window16(x, w, stride, pad, groups) and \
+                self._conv3x3_h16(0, x, w, None, y):
+            return True
+        return self._flat16(0, x, w, None, y, stride, pad, groups)
 
     def conv_bwd_data(self, dy, w, dx, stride, pad, groups, addend=None):
         """dx = backward-data(dy, w) [+ addend]: the sum with a gradient that
@@ -812,10 +837,23 @@ class HipMath(object):
         return t if t.dtype == torch.float32 else self._cast(t, torch.float32)
 
     def bn_fwd_train(self, x, scale, bias, rmean, rvar, factor, eps, y, mean,
-                     invstd, act=0, residual=None):
+                     invstd, act=0, residual=None, stats=None):
         """act: 0 none, 1 ReLU, 2 add ``residual`` then ReLU (fused into the
-        normalisation pass)."""
+        normalisation pass).  With ``stats`` (filled by the producer of x, see
+        conv_fwd) the statistics pass is skipped: one pass over x, which also
+        clears the buffer for the next step."""
         N, C, HW = self._nchw(x)
+        if stats is not None:
+            assert rmean.dtype == torch.float32 and \
+                rvar.dtype == torch.float32 and stats.dtype == torch.float32
+            sc, bi = self._f32(scale), self._f32(bias)
+            self.k.bn_fwd_train_sums(
+                _code(x), x.data_ptr(), sc.data_ptr(), bi.data_ptr(),
+                rmean.data_ptr(), rvar.data_ptr(), float(factor), float(eps),
+                y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), N, C, HW,
+                stats.data_ptr(), int(act),
+                residual.data_ptr() if residual is not None else 0, self._s())
+            return
         work = self._tmp(self.k.bn_workspace(N, C, HW))
         sc, bi = self._f32(scale), self._f32(bias)
         rm, rv = self._f32(rmean), self._f32(rvar)

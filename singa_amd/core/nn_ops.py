@@ -6,8 +6,16 @@ on the GPU), so ``Cpu*`` and ``Gpu*`` names are aliases of the same function.
 Behaviour parity: reference src/model/operation/{convolution,batchnorm,
 pooling}.{h,cc}; binding names from src/api/model_operation.i:37-191.
 """
+import os
+
 from . import dtypes
 from .tensor_core import Tensor, _submit, Contiguous
+
+# SINGA_CONV_BN_STATS=1: a convolution takes the statistics of the batch
+# normalisation that reads its output (ChannelStatLink).  Off by default: on
+# MI355X the per-tile atomics of the epilogue cost more than the statistics
+# pass they replace (measured per layer in profiles/bn_stats_in_conv_epilogue.md).
+CONV_BN_STATS = os.environ.get("SINGA_CONV_BN_STATS", "0") == "1"
 
 
 def _pair(v):
@@ -47,6 +55,9 @@ class ConvHandle(object):
         self.imagesize = x.Size() // self.batchsize
         self.workspace_byte_limit = workspace_byte_limit
         self.prefer = prefer
+        # set by the batch normalisation that reads this convolution's output
+        self.stat_link = None
+        self.stat_link_refused = False
 
     def out_shape(self, batch):
         return [batch, self.num_filters, self.conv_height, self.conv_width]
@@ -55,26 +66,108 @@ class ConvHandle(object):
 CudnnConvHandle = ConvHandle
 
 
+class ChannelStatLink(object):
+    """Hand-over of batch-norm statistics from a convolution to the batch
+    normalisation that reads its output: the convolution kernel's epilogue
+    adds the per-channel sums of (y - shift) and (y - shift)^2 into ``stats``
+    while y is still in registers, and the normalisation takes them from there
+    instead of reading y once more for a statistics pass.  ``shift`` is the
+    normalisation's running mean as it is before the step (any value works;
+    one near the batch mean keeps E[d^2] - E[d]^2 free of cancellation).  The
+    normalisation clears the buffer once it has read it.
+
+    ``token`` counts emissions and ``pending`` says that the last one has not
+    been consumed: a normalisation only trusts the sums of the very tensor it
+    was handed, and a convolution whose previous sums nobody took clears them
+    before adding new ones."""
+
+    def __init__(self, dev, channels, shift):
+        math = dev.math
+        self.stats = Tensor([(2 * math.STAT_COPIES + 1) * channels], dev,
+                            dtypes.kFloat32)
+        self.shift = shift
+        self.token = 0
+        self.pending = False
+        self.clear()
+
+    def clear(self):
+        dev = self.stats.device()
+        was = dev.graph_enabled()
+        dev.EnableGraph(False)      # parameters-like state: set right now
+        try:
+            self.stats.SetValue(0.0)
+        finally:
+            dev.EnableGraph(was)
+
+
+def stat_link_for(x, running_mean, channels):
+    """The link through which the producer of ``x`` handed statistics to the
+    batch normalisation owning ``running_mean``, or None.  A convolution seen
+    for the first time is asked to emit them from its next run on."""
+    source = getattr(x, "_stat_source", None)
+    if source is None or not CONV_BN_STATS:
+        return None
+    handle, token = source
+    link = handle.stat_link
+    if link is None:
+        if not handle.stat_link_refused and \
+                running_mean.data_type() == dtypes.kFloat32 and \
+                handle.num_filters == channels:
+            handle.stat_link = ChannelStatLink(x.device(), channels,
+                                               running_mean)
+        return None
+    if link.shift is not running_mean:
+        # two normalisations read this convolution: keep both on their own pass
+        handle.stat_link, handle.stat_link_refused = None, True
+        return None
+    if token != link.token or not link.pending:
+        return None
+    link.pending = False
+    return link
+
+
 def _check_conv_input(x, ch):
     assert x.nDim() == 4 and x.shape(1) == ch.channels and \
         x.shape(2) == ch.height and x.shape(3) == ch.width, "input sample not match"
 
 
-def ConvForward(x, W, b, ch):
+def ConvForward(x, W, b, ch, emit_stats=False):
+    """``emit_stats``: this is a training step; when a batch normalisation
+    linked itself to the handle (``ChannelStatLink``) the launch also produces
+    its statistics, and the output remembers where it came from so that the
+    normalisation can find them."""
     _check_conv_input(x, ch)
     xs = x if x.is_contiguous() else Contiguous(x)
     y = Tensor(ch.out_shape(x.shape(0)), x.device(), x.data_type())
     st, pd, g = (ch.stride_h, ch.stride_w), (ch.pad_h, ch.pad_w), ch.group
-    if ch.bias_term and b is not None and b.Size() > 0:
-        _submit(x.device(), "ConvForward",
-                lambda a, w, bb, o: a._dev.math.conv_fwd(
-                    a.view(), w.view(), bb.view(), o.view(), st, pd, g),
-                [xs, W, b], [y])
+    bias = b if ch.bias_term and b is not None and b.Size() > 0 else None
+    link = ch.stat_link if emit_stats else None
+    if link is not None and link.stats.device() is not x.device():
+        link = None
+    if link is not None:
+        if link.pending:
+            link.stats.SetValue(0.0)       # sums nobody consumed
+        link.token += 1
+        link.pending = True
+    y._stat_source = (ch, link.token if link is not None else -1)
+    reads = [xs, W] + ([bias] if bias is not None else [])
+    nb = bias is not None
+    if link is None:
+        def body(a, w, *rest):
+            bb, o = (rest[0], rest[1]) if nb else (None, rest[0])
+            a._dev.math.conv_fwd(a.view(), w.view(),
+                                 bb.view() if nb else None, o.view(), st, pd,
+                                 g)
+        _submit(x.device(), "ConvForward", body, reads, [y])
     else:
-        _submit(x.device(), "ConvForward",
-                lambda a, w, o: a._dev.math.conv_fwd(
-                    a.view(), w.view(), None, o.view(), st, pd, g),
-                [xs, W], [y])
+        def body(a, w, *rest):
+            bb = rest[0] if nb else None
+            sh, _, o, sums = rest[-4:]
+            a._dev.math.conv_fwd(a.view(), w.view(),
+                                 bb.view() if nb else None, o.view(), st, pd,
+                                 g, sums.view(), sh.view())
+        _submit(x.device(), "ConvForward", body,
+                reads + [link.shift, link.stats], [y, link.stats])
     return y
 
 
@@ -160,32 +253,49 @@ def BatchNormForwardTraining(bnh, x, scale, bias, running_mean, running_var,
                              act=BN_ACT_NONE, residual=None):
     """Returns [y, batch_mean, batch_inv_std]; updates the running statistics
     in place.  ``act`` fuses an activation into the normalisation pass:
-    BN_ACT_RELU gives relu(bn(x)), BN_ACT_ADD_RELU relu(bn(x) + residual)."""
+    BN_ACT_RELU gives relu(bn(x)), BN_ACT_ADD_RELU relu(bn(x) + residual).
+    When x comes from a convolution that already took the statistics
+    (``ChannelStatLink``) the statistics pass over x is skipped."""
+    link = stat_link_for(x, running_mean, bnh.channels)
     xs, res = _contig(x), _contig(residual)
+    if xs is not x:
+        link = None
     dev = x.device()
     y = Tensor(x.shape(), dev, x.data_type())
     mean = Tensor([bnh.channels], dev, dtypes.kFloat32)
     invstd = Tensor([bnh.channels], dev, dtypes.kFloat32)
     f, eps = bnh.factor, bnh.eps
-    if act == BN_ACT_ADD_RELU:
-        def body(a, s, b, rm_in, rv_in, r, o, m, iv, rm, rv):
-            a._dev.math.bn_fwd_train(a.view(), s.view(), b.view(), rm.view(),
-                                     rv.view(), f, eps, o.view(), m.view(),
-                                     iv.view(), act, r.view())
-        reads = [xs, scale, bias, running_mean, running_var, res]
-    else:
-        def body(a, s, b, rm_in, rv_in, o, m, iv, rm, rv):
-            a._dev.math.bn_fwd_train(a.view(), s.view(), b.view(), rm.view(),
-                                     rv.view(), f, eps, o.view(), m.view(),
-                                     iv.view(), act)
-        reads = [xs, scale, bias, running_mean, running_var]
-    _submit(dev, "BatchNormForwardTraining", body, reads,
-            [y, mean, invstd, running_mean, running_var])
+    with_res = act == BN_ACT_ADD_RELU
+    reads = [xs, scale, bias, running_mean, running_var]
+    if with_res:
+        reads.append(res)
+    if link is not None:
+        reads.append(link.stats)
+    n_in = len(reads)
+
+    def body(*t):
+        a, s, b = t[0], t[1], t[2]
+        r = t[5] if with_res else None
+        sums = t[n_in - 1] if link is not None else None
+        o, m, iv, rm, rv = t[n_in:n_in + 5]
+        a._dev.math.bn_fwd_train(
+            a.view(), s.view(), b.view(), rm.view(), rv.view(), f, eps,
+            o.view(), m.view(), iv.view(), act,
+            r.view() if r is not None else None,
+            **({"stats": sums.view()} if sums is not None else {}))
+
+    writes = [y, mean, invstd, running_mean, running_var]
+    if link is not None:
+        writes.append(link.stats)
+    _submit(dev, "BatchNormForwardTraining", body, reads, writes)
     return [y, mean, invstd]
 
 
 def BatchNormForwardInference(bnh, x, scale, bias, running_mean, running_var,
                               act=BN_ACT_NONE, residual=None):
+    # a first (dry or evaluation) pass already tells the convolution in front
+    # that a normalisation follows
+    stat_link_for(x, running_mean, bnh.channels)
     xs, res = _contig(x), _contig(residual)
     dev = x.device()
     y = Tensor(x.shape(), dev, x.data_type())

@@ -43,7 +43,9 @@ def _contig_strides(shape):
 class Tensor(object):
     """Core tensor.  ``Tensor(other)`` is a shallow copy sharing the block."""
 
-    __slots__ = ("_shape", "_stride", "_dtype", "_dev", "_block", "__weakref__")
+    # _stat_source: set on a convolution's output, see nn_ops.ChannelStatLink
+    __slots__ = ("_shape", "_stride", "_dtype", "_dev", "_block",
+                 "_stat_source", "__weakref__")
 
     def __init__(self, shape=None, device=None, dtype=kFloat32):
         if isinstance(shape, Tensor):  # copy constructor

@@ -239,6 +239,10 @@ PYBIND11_MODULE(_hip, m) {
         g.scratch = reinterpret_cast<float *>(p);
         g.scratch_elems = elems;
       })
+      .def("set_stats", [](ConvGeom &g, uintptr_t stats, uintptr_t shift) {
+        g.stats = reinterpret_cast<float *>(stats);
+        g.stats_shift = reinterpret_cast<const float *>(shift);
+      })
       .def("set_prof", [](ConvGeom &g, uintptr_t p) {
         g.prof = reinterpret_cast<unsigned long long *>(p);
       });
@@ -353,6 +357,26 @@ PYBIND11_MODULE(_hip, m) {
                               (float *)P(mean), (float *)P(invstd), N, C, HW,
                               (float *)P(work), act, CP(res), S(s)),
           "bn_fwd_train_act");
+  });
+  m.def("bn_fwd_train_sums", [](int dt, uintptr_t x, uintptr_t scale,
+                                uintptr_t bias, uintptr_t rmean,
+                                uintptr_t rvar, float factor, float eps,
+                                uintptr_t y, uintptr_t mean, uintptr_t invstd,
+                                int N, int C, int HW, uintptr_t stats, int act,
+                                uintptr_t res, uintptr_t s) {
+    check(sa_bn_fwd_train_sums(dt, CP(x), (const float *)CP(scale),
+                               (const float *)CP(bias), (float *)P(rmean),
+                               (float *)P(rvar), factor, eps, P(y),
+                               (float *)P(mean), (float *)P(invstd), N, C, HW,
+                               (float *)P(stats), act, CP(res), S(s)),
+          "bn_fwd_train_sums");
+  });
+  m.attr("stat_copies") = kStatCopies;
+  m.def("chan_sums", [](int dt, uintptr_t y, uintptr_t stats, uintptr_t shift,
+                        int N, int K, int PQ, uintptr_t s) {
+    check(sa_chan_sums(dt, CP(y), (float *)P(stats), (const float *)CP(shift),
+                       N, K, PQ, S(s)),
+          "chan_sums");
   });
   m.def("bn_fwd_infer_act", [](int dt, uintptr_t x, uintptr_t scale,
                                uintptr_t bias, uintptr_t rmean, uintptr_t rvar,

@@ -118,28 +118,72 @@ __device__ __forceinline__ float bn_act(float z, float r) {
   return z;
 }
 
-template <typename T, int VEC, int ACT>
+// SUMS: the statistics were taken by the producer of x (a convolution's
+// epilogue, ConvGeom::stats): `work` is float[kStatCopies][2][C] holding
+// sums of x - rmean[c] (the running mean as it is BEFORE this step's update),
+// followed by one unsigned counter per channel.  Every block reads the sums
+// and the shift, then counts itself in; the last block of a channel to do so
+// writes the saved and running statistics and clears the channel's sums and
+// counter for the next step (nobody reads them any more at that point).
+template <typename T, int VEC, int ACT, bool SUMS = false>
 __global__ void bn_apply_train_kernel(
     const T *__restrict__ x, const float *__restrict__ scale,
     const float *__restrict__ bias, float *__restrict__ rmean,
     float *__restrict__ rvar, float factor, float eps, T *__restrict__ y,
     float *__restrict__ mean_out, float *__restrict__ invstd_out,
-    const float *__restrict__ work, const T *__restrict__ res, int N, int C,
+    float *__restrict__ work, const T *__restrict__ res, int N, int C,
     int HW, int S) {
   const int c = blockIdx.x, s = blockIdx.y;
-  float sum = 0.f, sq = 0.f;
-  for (int i = 0; i < S; ++i) {
-    sum += work[((size_t)c * S + i) * 2 + 0];
-    sq += work[((size_t)c * S + i) * 2 + 1];
+  float sum = 0.f, sq = 0.f, shift;
+  if constexpr (SUMS) {
+    __shared__ float got[3];
+    if (threadIdx.x == 0) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int k = 0; k < kStatCopies; ++k) {
+        a += work[((size_t)k * 2 + 0) * C + c];
+        b += work[((size_t)k * 2 + 1) * C + c];
+      }
+      got[0] = a;
+      got[1] = b;
+      got[2] = rmean[c];
+    }
+    __syncthreads();
+    sum = got[0];
+    sq = got[1];
+    shift = got[2];
+  } else {
+    for (int i = 0; i < S; ++i) {
+      sum += work[((size_t)c * S + i) * 2 + 0];
+      sq += work[((size_t)c * S + i) * 2 + 1];
+    }
+    shift = to_f<T>(x[(size_t)c * HW]);
   }
   const float cnt = (float)N * (float)HW;
-  const float shift = to_f<T>(x[(size_t)c * HW]);
   const float dm = sum / cnt;
   const float mean = shift + dm;
   float var = sq / cnt - dm * dm;
   var = fmaxf(var, 0.f);
   const float invstd = rsqrtf(var + eps);
-  if (s == 0 && threadIdx.x == 0) {
+  bool writer = s == 0 && threadIdx.x == 0;
+  if constexpr (SUMS) {
+    writer = false;
+    if (threadIdx.x == 0) {
+      unsigned *counter =
+          reinterpret_cast<unsigned *>(work + (size_t)kStatCopies * 2 * C);
+      __threadfence();
+      writer = atomicAdd(counter + c, 1u) == gridDim.y - 1;
+      if (writer) {
+#pragma unroll
+        for (int k = 0; k < kStatCopies; ++k) {
+          work[((size_t)k * 2 + 0) * C + c] = 0.f;
+          work[((size_t)k * 2 + 1) * C + c] = 0.f;
+        }
+        counter[c] = 0u;
+      }
+    }
+  }
+  if (writer) {
     mean_out[c] = mean;
     invstd_out[c] = invstd;
     const float unbiased = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
@@ -371,6 +415,41 @@ int sa_bn_fwd_train_act(int dtype, const void *x, const float *scale,
       hipLaunchKernelGGL((bn_apply_train_kernel<T, 1, ACT>), grid, block, 0,
                          s, (const T *)x, scale, bias, rmean, rvar, factor,
                          eps, (T *)y, mean, invstd, work, (const T *)residual,
+                         N, C, HW, S);
+    });
+  });
+  return 0;
+}
+
+// Training forward from statistics taken by the producer of x: one pass.
+// stats: float[kStatCopies][2][C] + unsigned[C], see bn_apply_train_kernel.
+int sa_bn_fwd_train_sums(int dtype, const void *x, const float *scale,
+                         const float *bias, float *rmean, float *rvar,
+                         float factor, float eps, void *y, float *mean,
+                         float *invstd, int N, int C, int HW, float *stats,
+                         int act, const void *residual, hipStream_t s) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  if (act == 2 && residual == nullptr) return -5;
+  if (stats == nullptr) return -5;
+  const int S = bn_splits(N, C);
+  if (bn_vec4(dtype, HW, x, y, residual, nullptr)) {
+    const dim3 grid(C, S), block(bn_block(HW / 4));
+    SA_DISPATCH_FLOAT(dtype, T, {
+      BN_ACT_SWITCH(act, {
+        hipLaunchKernelGGL((bn_apply_train_kernel<T, 4, ACT, true>), grid,
+                           block, 0, s, (const T *)x, scale, bias, rmean, rvar,
+                           factor, eps, (T *)y, mean, invstd, stats,
+                           (const T *)residual, N, C, HW, S);
+      });
+    });
+    return 0;
+  }
+  const dim3 grid(C, S), block(bn_block(HW));
+  SA_DISPATCH_FLOAT(dtype, T, {
+    BN_ACT_SWITCH(act, {
+      hipLaunchKernelGGL((bn_apply_train_kernel<T, 1, ACT, true>), grid, block,
+                         0, s, (const T *)x, scale, bias, rmean, rvar, factor,
+                         eps, (T *)y, mean, invstd, stats, (const T *)residual,
                          N, C, HW, S);
     });
   });

@@ -42,6 +42,26 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
+// Sums each of 16 per-lane values over the 32 lanes of the lane's half of the
+// wave (the layout of a 32 x 32 MFMA accumulator block: 32 columns across the
+// lanes of a half, 16 rows in registers).  The halves exchange registers while
+// they add, so the whole reduction costs 16 shuffles instead of 80: on return
+// a[0] of lane l holds the total of value number (l >> 1) & 15.
+__device__ __forceinline__ void half_wave_sums16(float (&a)[16], int lane) {
+#pragma unroll
+  for (int width = 8; width >= 1; width >>= 1) {
+    const int mask = 2 * width;  // 16, 8, 4, 2
+    const bool upper = (lane & mask) != 0;
+#pragma unroll
+    for (int k = 0; k < width; ++k) {
+      const float send = upper ? a[k] : a[k + width];
+      const float keep = upper ? a[k + width] : a[k];
+      a[k] = keep + __shfl_xor(send, mask, 64);
+    }
+  }
+  a[0] += __shfl_xor(a[0], 1, 64);
+}
+
 // Block-wide sum for blockDim.x <= 1024 (16 waves); result valid in all lanes.
 __device__ __forceinline__ float block_sum(float v, float *smem /*>=17 floats*/) {
   v = wave_sum(v);

@@ -804,6 +804,48 @@ conv_igemm_kernel(ConvArgs a) {
         }
       }
   }
+  // ---- batch-norm statistics of the tile just written -----------------------
+  if (MODE == CONV_FWD) {
+    if (a.g.stats != nullptr && a.splits == 1) {
+      const int Ktot = g.K;
+      float *stats = a.g.stats + (size_t)(blockIdx.x & (kStatCopies - 1)) * 2 * Ktot;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        float sm[16], sq[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row =
+              m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int ch = grp * a.Kg + min(row, a.M - 1);
+          const float bv = a.bias ? to_f<T>(((const T *)a.bias)[ch]) : 0.f;
+          const float sh = a.g.stats_shift[ch];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * WN + 32 * j + (lane & 31);
+            // the value as the output tensor holds it
+            const float y = to_f<T>(from_f<T>(acc[i][j][r] + bv)) - sh;
+            if (col < Ngemm) {
+              s1 += y;
+              s2 += y * y;
+            }
+          }
+          sm[r] = s1;
+          sq[r] = s2;
+        }
+        half_wave_sums16(sm, lane);
+        half_wave_sums16(sq, lane);
+        const int idx = (lane >> 1) & 15;
+        const int row =
+            m0 + wm * WM + 32 * i + (idx & 3) + 8 * (idx >> 2) + 4 * (lane >> 5);
+        if ((lane & 1) == 0 && row < a.M) {
+          const int ch = grp * a.Kg + row;
+          atomicAdd(stats + ch, sm[0]);
+          atomicAdd(stats + Ktot + ch, sq[0]);
+        }
+      }
+    }
+  }
 #ifdef SA_CONV_PROF
   {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1027,10 +1069,55 @@ static bool window_ok(int64_t image_elems, int64_t span, int64_t filter_elems,
          filter_elems * (int64_t)sz < lim;
 }
 
+// Per-channel sums of a finished tensor y [N][K][PQ], added to copy 0 of the
+// statistics rows: grid (K, S), block (k, s) walks the images s, s + S, ...
+template <typename T>
+__global__ void __launch_bounds__(256)
+chan_sums_kernel(const T *__restrict__ y, float *__restrict__ stats,
+                 const float *__restrict__ shift, int N, int K, int PQ) {
+  __shared__ float smem[32];
+  const int k = blockIdx.x;
+  const float sh = shift[k];
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = blockIdx.y; n < N; n += gridDim.y) {
+    const T *p = y + ((size_t)n * K + k) * PQ;
+    for (int i = threadIdx.x; i < PQ; i += blockDim.x) {
+      const float v = to_f<T>(p[i]) - sh;
+      s1 += v;
+      s2 += v * v;
+    }
+  }
+  s1 = block_sum(s1, smem);
+  s2 = block_sum(s2, smem);
+  if (threadIdx.x == 0) {
+    atomicAdd(stats + k, s1);
+    atomicAdd(stats + K + k, s2);
+  }
+}
+
+int sa_chan_sums(int dtype, const void *y, float *stats, const float *shift,
+                 int N, int K, int PQ, hipStream_t s) {
+  if (N <= 0 || K <= 0 || PQ <= 0) return 0;
+  int split = 8192 / K;
+  split = std::max(1, std::min(split, N));
+  const int threads = PQ >= 256 ? 256 : 64;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((chan_sums_kernel<T>), dim3(K, split), dim3(threads), 0,
+                       s, (const T *)y, stats, shift, N, K, PQ);
+  });
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                 const void *bias, void *y, hipStream_t s) {
   if (!geom_ok(g)) return -2;
-  if (sa_dwconv_applies(g)) return sa_dwconv_fwd(dtype, g, x, w, bias, y, s);
+  if (g->stats != nullptr && g->stats_shift == nullptr) return -2;
+  if (sa_dwconv_applies(g)) {
+    const int rc = sa_dwconv_fwd(dtype, g, x, w, bias, y, s);
+    if (rc != 0 || g->stats == nullptr) return rc;
+    return sa_chan_sums(dtype, y, g->stats, g->stats_shift, g->N, g->K,
+                        g->P * g->Q, s);
+  }
   if (sa_conv3x3_applies(dtype, g, g->C))
     return sa_conv3x3_fwd(g, x, w, bias, y, s);
   ConvArgs a = make_args(*g, CONV_FWD);
@@ -1042,6 +1129,10 @@ int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
     return -2;
   const int64_t elems = (int64_t)g->N * g->K * g->P * g->Q;
   SA_DISPATCH_FLOAT(dtype, T, { launch_conv<T, CONV_FWD>(a, elems, true, s); });
+  // a split reduction has no workgroup that sees a finished value
+  if (g->stats != nullptr && a.splits > 1)
+    return sa_chan_sums(dtype, y, g->stats, g->stats_shift, g->N, g->K,
+                        g->P * g->Q, s);
   return 0;
 }
 

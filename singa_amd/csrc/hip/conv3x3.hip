@@ -36,6 +36,9 @@ struct Halo3Args {
   const float *in, *w, *bias, *addend;
   float *out;
   int N, Cin, Cout, H, tiles_h;
+  // forward: batch-norm statistics of the output (see ConvGeom::stats)
+  float *stats;
+  const float *shift;
 };
 
 constexpr int kH3Chunk = 8;     // input channels per LDS stage
@@ -234,6 +237,64 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(Halo3Args a) {
         }
       }
   }
+
+  // ---- batch-norm statistics of the tile just written -----------------------
+  // Per wave: 16 rows x 32 positions per block, summed over the lanes of a
+  // half with the register-exchanging butterfly; the four waves (same
+  // channels, other positions) meet in LDS and one lane per channel adds the
+  // workgroup's total to the statistics rows.
+  if (MODE == 0) {
+    if (a.stats != nullptr) {
+      float *red = &Ws[0][0];  // [4 waves][2 sums][64 channels]
+      __syncthreads();         // every wave is done with the weight images
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float sm[16], sq[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const int mc = min(m, a.Cout - 1);
+          const float off = (a.bias ? a.bias[mc] : 0.f) - a.shift[mc];
+          float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            const int q = (wave * NTW + j) * 32 + n31;
+            const int ro = q / Wp, co = q - ro * Wp;
+            const bool ok = co < W && ro < TH && h0 + ro < H;
+            const float y = acc[i][j][r] + off;
+            if (ok) {
+              s1 += y;
+              s2 += y * y;
+            }
+          }
+          sm[r] = s1;
+          sq[r] = s2;
+        }
+        half_wave_sums16(sm, lane);
+        half_wave_sums16(sq, lane);
+        if ((lane & 1) == 0) {
+          const int idx = (lane >> 1) & 15;
+          const int ml = i * 32 + (idx & 3) + 8 * (idx >> 2) + 4 * kh;
+          red[(wave * 2 + 0) * 64 + ml] = sm[0];
+          red[(wave * 2 + 1) * 64 + ml] = sq[0];
+        }
+      }
+      __syncthreads();
+      if (tid < 128) {
+        const int which = tid >> 6, ml = tid & 63;
+        const float t = red[(0 * 2 + which) * 64 + ml] +
+                        red[(1 * 2 + which) * 64 + ml] +
+                        red[(2 * 2 + which) * 64 + ml] +
+                        red[(3 * 2 + which) * 64 + ml];
+        if (m0 + ml < a.Cout)
+          atomicAdd(a.stats +
+                        ((size_t)(blockIdx.x & (kStatCopies - 1)) * 2 + which) *
+                            a.Cout +
+                        m0 + ml,
+                    t);
+      }
+    }
+  }
 }
 
 static int env_flag(const char *name, int dflt) {
@@ -291,6 +352,7 @@ int sa_conv3x3_fwd(const ConvGeom *g, const void *x, const void *w,
   a.in = (const float *)x; a.w = (const float *)w;
   a.bias = (const float *)bias; a.addend = nullptr; a.out = (float *)y;
   a.N = g->N; a.Cin = g->C; a.Cout = g->K; a.H = g->H;
+  a.stats = g->stats; a.shift = g->stats_shift;
   return run_halo3(g, a, 0, s);
 }
 

@@ -177,7 +177,15 @@ struct ConvGeom {
   int64_t scratch_elems = 0;
   // diagnostic builds only: eight 64-bit phase counters (see conv.hip)
   unsigned long long *prof = nullptr;
+  // forward only: per-channel batch-norm statistics of the output, taken while
+  // it is produced.  stats is float[kStatCopies][2][K], the launch ADDS
+  // sum(y - shift[k]) and sum((y - shift[k])^2) over (n, p) to one of the
+  // copies of [0][k] and [1][k]; shift is float[K].
+  float *stats = nullptr;
+  const float *stats_shift = nullptr;
 };
+// copies of the statistics rows (spreads same-address atomics; one per XCD)
+constexpr int kStatCopies = 8;
 int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,
                 const void *bias, void *y, hipStream_t s);
 int sa_conv_bwd_data(int dtype, const ConvGeom *g, const void *dy,
@@ -193,6 +201,10 @@ int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
                        const void *x, void *dw, hipStream_t s);
 int sa_conv_bwd_bias(int dtype, const void *dy, void *db, int N, int K,
                      int PQ, hipStream_t s);
+// The same statistics as ConvGeom::stats from a finished tensor y [N][K][PQ]
+// (for convolution kernels without the fused epilogue).
+int sa_chan_sums(int dtype, const void *y, float *stats, const float *shift,
+                 int N, int K, int PQ, hipStream_t s);
 
 // ---- conv3x3.hip ------------------------------------------------------------------------------
 // Direct halo-tile kernel for float32 3x3 / stride 1 / pad 1 convolutions
@@ -232,6 +244,14 @@ int sa_bn_bwd(int dtype, const void *dy, const void *x, const float *scale,
 // Fused variants.  act: 0 none, 1 ReLU, 2 add `residual` then ReLU.  The
 // backward masks dy by (output > 0) first; for act 2 it needs the saved output
 // y and also writes the masked gradient to `dres` (gradient of the residual).
+// one-pass training forward from statistics taken by the producer of x
+// (ConvGeom::stats); stats: float[kStatCopies][2][C] followed by unsigned[C],
+// all zero before the producer ran, cleared again by this launch
+int sa_bn_fwd_train_sums(int dtype, const void *x, const float *scale,
+                         const float *bias, float *rmean, float *rvar,
+                         float factor, float eps, void *y, float *mean,
+                         float *invstd, int N, int C, int HW, float *stats,
+                         int act, const void *residual, hipStream_t s);
 int sa_bn_fwd_train_act(int dtype, const void *x, const float *scale,
                         const float *bias, float *rmean, float *rvar,
                         float factor, float eps, void *y, float *mean,

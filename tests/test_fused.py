@@ -269,3 +269,69 @@ def test_sgd_16bit_hyper_parameters_gpu(master):
 def test_sgd_16bit_hyper_parameters_cpu(master):
     from singa_amd import device
     assert _sgd16_vs_fp32(device.get_default_device(), master) < 2e-3
+
+
+def _conv_bn_net(seed):
+    """conv -> bn -> relu -> conv(+bias) -> bn, trained for a few steps;
+    returns the loss trajectory, the running statistics and the handles."""
+    from singa_amd import layer, model, opt, tensor, device
+    from singa_amd.core import nn_ops
+
+    class Net(model.Model):
+
+        def __init__(self):
+            super(Net, self).__init__()
+            self.c1 = layer.Conv2d(8, 3, padding=1, bias=False)
+            self.b1 = layer.BatchNorm2d()
+            self.r1 = layer.ReLU()
+            self.c2 = layer.Conv2d(6, 1, bias=True)
+            self.b2 = layer.BatchNorm2d()
+            self.flat = layer.Flatten()
+            self.fc = layer.Linear(5)
+            self.loss = layer.SoftMaxCrossEntropy()
+
+        def forward(self, x):
+            y = self.b2(self.c2(self.r1(self.b1(self.c1(x)))))
+            return self.fc(self.flat(y))
+
+        def train_one_batch(self, x, t):
+            out = self.forward(x)
+            l = self.loss(out, t)
+            self.optimizer(l)
+            return out, l
+
+    dev = device.get_default_device()
+    dev.SetRandSeed(seed)
+    rs = np.random.RandomState(seed)
+    x = tensor.from_numpy(rs.randn(4, 3, 6, 6).astype(np.float32) + 3.0)
+    t = tensor.from_numpy(rs.randint(0, 5, 4).astype(np.int32))
+    m = Net()
+    m.set_optimizer(opt.SGD(lr=0.05, momentum=0.9))
+    m.compile([x], is_train=True, use_graph=False, sequential=False)
+    losses = []
+    for _ in range(4):
+        _, l = m(x, t)
+        losses.append(float(tensor.to_numpy(l).reshape(-1)[0]))
+    stats = [tensor.to_numpy(v) for v in (m.b1.running_mean, m.b1.running_var,
+                                          m.b2.running_mean, m.b2.running_var)]
+    return losses, stats, (m.c1.handle, m.c2.handle), nn_ops
+
+
+def test_conv_hands_batchnorm_statistics_cpu(monkeypatch):
+    """A batch normalisation that reads a convolution's output takes its
+    statistics from the sums the convolution produced; trajectory and running
+    statistics equal those of the two-pass normalisation."""
+    from singa_amd.core import nn_ops as ops
+    monkeypatch.setattr(ops, "CONV_BN_STATS", True)
+    losses, stats, handles, nn_ops = _conv_bn_net(3)
+    for h in handles:
+        link = h.stat_link
+        assert link is not None and link.token == 4 and not link.pending
+        # consumed and cleared
+        assert float(link.stats.view().abs().max()) == 0.0
+    monkeypatch.setattr(nn_ops, "CONV_BN_STATS", False)
+    ref_losses, ref_stats, ref_handles, _ = _conv_bn_net(3)
+    assert all(h.stat_link is None for h in ref_handles)
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    for a, b in zip(stats, ref_stats):
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-6)

@@ -1016,3 +1016,87 @@ def test_extreme_and_nonfinite_inputs(maths):
     hm.clamp(v.to(d), -1.5, 1.5, o)
     np.testing.assert_array_equal(o.cpu().numpy(),
                                   np.array([-1.5, -1, 0, 1.5, 1.5], np.float32))
+
+
+@pytest.mark.parametrize("dt,N,C,K,H,W,R,st,pd,bias", [
+    (torch.float32, 3, 16, 72, 28, 28, 3, 1, 1, True),    # halo kernel
+    (torch.float32, 2, 24, 40, 14, 14, 3, 1, 1, False),   # halo, partial tile
+    (torch.float32, 4, 32, 96, 12, 12, 1, 1, 0, True),    # implicit GEMM
+    (torch.float32, 5, 20, 130, 9, 9, 3, 2, 1, False),    # strided, ragged
+    (torch.float32, 2, 512, 64, 4, 4, 3, 1, 1, False),    # split reduction
+    (torch.float32, 3, 12, 12, 10, 10, 3, 1, 1, False),   # depthwise (groups)
+    (torch.float16, 3, 64, 96, 14, 14, 3, 1, 1, False),   # 16-bit tap GEMM
+    (torch.bfloat16, 2, 64, 128, 28, 28, 1, 1, 0, False),  # 16-bit 1x1 GEMM
+    (torch.float16, 2, 24, 40, 10, 10, 3, 1, 1, True),    # 16-bit implicit GEMM
+])
+def test_conv_forward_emits_batchnorm_statistics(maths, dt, N, C, K, H, W, R,
+                                                 st, pd, bias):
+    """Forward convolutions add the per-channel sums of (y - shift) and
+    (y - shift)^2 to the statistics rows (fused epilogue where the kernel has
+    one, a pass over y otherwise); reference: the sums of the stored output."""
+    hm, cm, dev = maths
+    grp = C if (C == K == 12) else 1
+    x = rnd(N, C, H, W, seed=90).to(dt)
+    w = rnd(K, C // grp, R, R, seed=91, lo=-0.4, hi=0.4).to(dt)
+    b = (rnd(K, seed=92) + 1.5).to(dt) if bias else None
+    P = (H + 2 * pd - R) // st + 1
+    shift = rnd(K, seed=93, lo=-0.5, hi=0.5)
+    copies = hm.STAT_COPIES
+    y = torch.empty(N, K, P, P, device=dev.torch_device, dtype=dt)
+    stats = torch.zeros((2 * copies + 1) * K, device=dev.torch_device)
+    for _ in range(2):      # sums accumulate over launches
+        hm.conv_fwd(g(x, dev), g(w, dev), g(b, dev) if bias else None, y,
+                    (st, st), (pd, pd), grp, stats, g(shift, dev))
+    got = stats[:2 * copies * K].cpu().reshape(copies, 2, K).sum(0).numpy()
+    assert float(stats[2 * copies * K:].abs().max()) == 0.0
+    d = y.float().cpu() - shift.reshape(1, K, 1, 1)
+    ref1 = 2 * d.sum(dim=(0, 2, 3)).numpy()
+    ref2 = 2 * (d * d).sum(dim=(0, 2, 3)).numpy()
+    n = N * P * P
+    np.testing.assert_allclose(got[0], ref1, rtol=1e-4,
+                               atol=2e-5 * n * float(d.abs().max()))
+    np.testing.assert_allclose(got[1], ref2, rtol=1e-4, atol=1e-4 * n)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16])
+@pytest.mark.parametrize("N,C,HW,act", [(6, 40, 49, 0), (4, 64, 196, 1),
+                                        (3, 24, 784, 2), (33, 8, 16, 1)])
+def test_batchnorm_forward_from_producer_sums(maths, dt, N, C, HW, act):
+    """Training forward from statistics handed over by the producer equals
+    the two-pass kernel (output, saved and running statistics), and leaves the
+    statistics rows and block counters cleared."""
+    hm, cm, dev = maths
+    side = int(round(HW ** 0.5))
+    x = (rnd(N, C, side, side, seed=95) * 2.0 + 1.0).to(dt)
+    res = rnd(N, C, side, side, seed=96).to(dt) if act == 2 else None
+    scale, bias = rnd(C, seed=97, lo=0.5, hi=1.5), rnd(C, seed=98)
+    rm0, rv0 = rnd(C, seed=99, lo=0.5, hi=1.5), rnd(C, seed=100, lo=0.5, hi=2.0)
+    copies = hm.STAT_COPIES
+
+    def run(fused):
+        rm, rv = g(rm0.clone(), dev), g(rv0.clone(), dev)
+        y = torch.empty_like(x, device=dev.torch_device)
+        mean = torch.empty(C, device=dev.torch_device)
+        inv = torch.empty(C, device=dev.torch_device)
+        kw = {}
+        if fused:
+            stats = torch.zeros((2 * copies + 1) * C, device=dev.torch_device)
+            xd = g(x, dev)
+            d = xd.float() - rm.reshape(1, C, 1, 1)
+            # spread over the copies as kernels on several XCDs would
+            s1, s2 = d.sum(dim=(0, 2, 3)), (d * d).sum(dim=(0, 2, 3))
+            view = stats[:2 * copies * C].reshape(copies, 2, C)
+            view[0, 0], view[0, 1] = 0.25 * s1, 0.25 * s2
+            view[copies - 1, 0], view[copies - 1, 1] = 0.75 * s1, 0.75 * s2
+            kw["stats"] = stats
+        hm.bn_fwd_train(g(x, dev), g(scale, dev), g(bias, dev), rm, rv, 0.1,
+                        1e-5, y, mean, inv, act,
+                        g(res, dev) if res is not None else None, **kw)
+        if fused:
+            assert float(kw["stats"].abs().max()) == 0.0
+        return [t.float().cpu().numpy() for t in (y, mean, inv, rm, rv)]
+
+    for a, b in zip(run(True), run(False)):
+        np.testing.assert_allclose(a, b, rtol=2e-3 if dt != torch.float32
+                                   else 1e-4, atol=2e-3 if dt != torch.float32
+                                   else 1e-5)

@@ -148,6 +148,16 @@ def main():
         fl = 2.0 * N * K * P * P * C * R * R
         t_f = timeit(lambda: m.conv_fwd(x, w, None, y, (st, st), (pd, pd), 1),
                      args.iters)
+        if os.environ.get("BENCH_CONV_STATS"):
+            # forward with batch-norm statistics taken in the same launch
+            sums = torch.zeros((2 * m.STAT_COPIES + 1) * K, device=dev)
+            shift = torch.zeros(K, device=dev)
+            t_d = timeit(lambda: m.conv_fwd(x, w, None, y, (st, st), (pd, pd),
+                                            1, sums, shift), args.iters)
+            print("%-34s %10.3f plain  %10.3f with statistics" %
+                  ("%d,%d,%d,%d,%d,%d x%d" % (C, K, R, st, pd, H, cnt), t_f,
+                   t_d), flush=True)
+            continue
         t_d = 0.0
         if li > 0:
             t_d = timeit(

@@ -522,6 +522,149 @@ struct Operand {
   }
 };
 
+// ---- output tile through LDS ---------------------------------------------
+// Elements per store of an output row: 8 (16 bytes) or 4 (8 bytes) when every
+// row of C (and of the addend, which shares its layout) starts on such a
+// boundary, 0 when only single elements can be stored.
+__device__ __forceinline__ int store_width(const GemmArgs &g, const void *c) {
+  const uintptr_t bits = reinterpret_cast<uintptr_t>(c) |
+                         reinterpret_cast<uintptr_t>(g.addend) |
+                         reinterpret_cast<uintptr_t>(g.bias);
+  if (((g.ldc | g.c_bs | g.N) & 3) != 0 || (bits & 7) != 0) return 0;
+  if (((g.ldc | g.c_bs | g.N) & 7) == 0 && (bits & 15) == 0) return 8;
+  return 4;
+}
+
+// One pass of the output tile through LDS: the float accumulators of row
+// blocks [i0, i0 + TI) of every wave go to a [rows][BN] float image (a wave's
+// 32 lanes write 32 consecutive floats: conflict free), then each thread
+// takes VEC consecutive columns of a row and stores
+// C = act(alpha * tile + bias + beta * C + addend) in one access per operand,
+// rounding once.
+// the float accumulators of row blocks [i0, i0 + TI) of every wave -> img
+template <int TM, int TN, int WVN, int TI>
+__device__ __forceinline__ void stage_rows(float *img, f32x16 (&acc)[TM][TN],
+                                           int i0, int wm, int wn, int lane) {
+  constexpr int BN = 32 * TN * WVN;
+#pragma unroll
+  for (int ii = 0; ii < TI; ++ii)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row =
+            (wm * TI + ii) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        img[row * BN + col] = acc[i0 + ii][j][r];
+      }
+    }
+}
+
+template <typename T, int TM, int TN, int WVM, int WVN, int TI, int VEC>
+__device__ __forceinline__ void tile_pass(float *img, f32x16 (&acc)[TM][TN],
+                                          int i0, T *C, const T *add,
+                                          const T *bias, const GemmArgs &g,
+                                          int m0, int n0, int wm, int wn,
+                                          int tid) {
+  constexpr int NT = 64 * WVM * WVN;
+  constexpr int BN = 32 * TN * WVN;
+  constexpr int ROWS = 32 * TI * WVM;  // rows staged per pass
+  constexpr int PPR = BN / VEC;        // pieces per row
+  using vec_t = typename std::conditional<VEC == 8, u32x4, uint2>::type;
+  stage_rows<TM, TN, WVN, TI>(img, acc, i0, wm, wn, tid & 63);
+  __syncthreads();
+  for (int e = tid; e < ROWS * PPR; e += NT) {
+    const int row = e / PPR, pc = e - row * PPR;
+    // staged row -> tile row: wave row wm holds row blocks wm * TM + i
+    const int w = row / (32 * TI), in = row - w * (32 * TI);
+    const int64_t grow = m0 + (w * TM + i0) * 32 + in;
+    const int64_t gcol = n0 + pc * VEC;
+    if (grow >= g.M || gcol >= g.N) continue;
+    float f[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k += 4) {
+      const float4 q =
+          *reinterpret_cast<const float4 *>(img + row * BN + pc * VEC + k);
+      f[k] = g.alpha * q.x; f[k + 1] = g.alpha * q.y;
+      f[k + 2] = g.alpha * q.z; f[k + 3] = g.alpha * q.w;
+    }
+    const int64_t at = grow * g.ldc + gcol;
+    T t[VEC];
+    if (bias) {
+      const vec_t bw = *reinterpret_cast<const vec_t *>(bias + gcol);
+      __builtin_memcpy(t, &bw, sizeof(bw));
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f[k] += to_f<T>(t[k]);
+    }
+    if (g.beta != 0.f) {
+      const vec_t cw = *reinterpret_cast<const vec_t *>(C + at);
+      __builtin_memcpy(t, &cw, sizeof(cw));
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f[k] += g.beta * to_f<T>(t[k]);
+    }
+    if (add) {
+      const vec_t aw = *reinterpret_cast<const vec_t *>(add + at);
+      __builtin_memcpy(t, &aw, sizeof(aw));
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f[k] += to_f<T>(t[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+      t[k] = from_f<T>(g.act == 1 ? fmaxf(f[k], 0.f) : f[k]);
+    vec_t o;
+    __builtin_memcpy(&o, t, sizeof(o));
+    *reinterpret_cast<vec_t *>(C + at) = o;
+  }
+  __syncthreads();
+}
+
+// The same pass for the convolution over flattened positions: a piece of VEC
+// columns is VEC consecutive positions of one image.
+template <typename T, int TM, int TN, int WVM, int WVN, int TI, int VEC>
+__device__ __forceinline__ void flat_tile_pass(
+    float *img, f32x16 (&acc)[TM][TN], int i0, T *out, const T *add, int M,
+    int HW, int n_img, int ppi, unsigned ppi_magic, int m0, int n0, int wm,
+    int wn, int tid) {
+  constexpr int NT = 64 * WVM * WVN;
+  constexpr int BN = 32 * TN * WVN;
+  constexpr int ROWS = 32 * TI * WVM;
+  constexpr int PPR = BN / VEC;
+  using vec_t = typename std::conditional<VEC == 8, u32x4, uint2>::type;
+  stage_rows<TM, TN, WVN, TI>(img, acc, i0, wm, wn, tid & 63);
+  __syncthreads();
+  for (int e = tid; e < ROWS * PPR; e += NT) {
+    const int row = e / PPR, pc = e - row * PPR;
+    const int w = row / (32 * TI), in = row - w * (32 * TI);
+    const int grow = m0 + (w * TM + i0) * 32 + in;
+    const int col = n0 + pc * VEC;
+    const int gp = col >> 3;
+    const int n = (int)__umulhi((unsigned)gp, ppi_magic);
+    const int p = (gp - n * ppi) * 8 + (col & 7);
+    if (grow >= M || n >= n_img || p >= HW) continue;
+    float f[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; k += 4) {
+      const float4 q =
+          *reinterpret_cast<const float4 *>(img + row * BN + pc * VEC + k);
+      f[k] = q.x; f[k + 1] = q.y; f[k + 2] = q.z; f[k + 3] = q.w;
+    }
+    const int64_t at = ((int64_t)n * M + grow) * HW + p;
+    T t[VEC];
+    if (add) {
+      const vec_t aw = *reinterpret_cast<const vec_t *>(add + at);
+      __builtin_memcpy(t, &aw, sizeof(aw));
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) f[k] += to_f<T>(t[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) t[k] = from_f<T>(f[k]);
+    vec_t o;
+    __builtin_memcpy(&o, t, sizeof(o));
+    *reinterpret_cast<vec_t *>(out + at) = o;
+  }
+  __syncthreads();
+}
+
 }  // namespace h16
 
 // WVM x WVN waves, each computing TM x TN blocks of 32 x 32:
@@ -624,6 +767,30 @@ gemm_h16_fast_kernel(GemmArgs g, int ntm, int ntn) {
   }
 
   const T *bias = (const T *)g.bias;
+  // 16-bit output whose rows can be written in 8- or 16-byte pieces: the
+  // tile goes through LDS so that a lane stores (and reads the addend /
+  // previous C in) whole pieces instead of single 2-byte elements.
+  const int vec = g.c_float ? 0 : h16::store_width(g, C);
+  if (vec) {
+    // the operand images hold half of the tile as floats: two passes
+    constexpr int TI = (TM + 1) / 2;
+    static_assert(32 * TI * WVM * BN * 4 <= (int)sizeof(smem),
+                  "half of the output tile must fit the operand images");
+    const T *add = g.addend ? (const T *)g.addend + (int64_t)blockIdx.z * g.c_bs
+                            : nullptr;
+    float *img = reinterpret_cast<float *>(&smem[0][0]);
+    __syncthreads();  // every wave is done reading the operand images
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += TI) {
+      if (vec == 8)
+        h16::tile_pass<T, TM, TN, WVM, WVN, TI, 8>(img, acc, i0, C, add, bias,
+                                                   g, m0, n0, wm, wn, tid);
+      else
+        h16::tile_pass<T, TM, TN, WVM, WVN, TI, 4>(img, acc, i0, C, add, bias,
+                                                   g, m0, n0, wm, wn, tid);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -880,6 +1047,22 @@ conv3x3_h16_kernel(ConvTapArgs a, int ntm, int ntn) {
     __syncthreads();
   }
 
+  if ((HW & 7) == 0 && (((int64_t)M * HW) & 7) == 0) {
+    // rows of whole 16-byte pieces: the tile goes out through LDS
+    constexpr int TI = (TM + 1) / 2;
+    static_assert(32 * TI * WVM * BN * 4 <= (int)sizeof(smem),
+                  "half of the output tile must fit the operand images");
+    GemmArgs gg{};
+    gg.M = M; gg.N = HW; gg.ldc = HW;
+    gg.alpha = 1.f; gg.beta = 0.f; gg.act = 0;
+    float *img = reinterpret_cast<float *>(&smem[0][0]);
+    __syncthreads();  // every wave is done reading the operand images
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += TI)
+      tile_pass<T, TM, TN, WVM, WVN, TI, 8>(img, acc, i0, out, addend, nullptr,
+                                            gg, m0, n0, wm, wn, tid);
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1138,6 +1321,27 @@ conv_flat_h16_kernel(ConvFlatArgs a, int ntm, int ntn) {
 
   T *out = (T *)a.out;
   const T *addend = (const T *)a.addend;
+  // whole 16- or 8-byte pieces per lane when the image rows allow it
+  const int vec = (HW & 7) == 0 ? 8 : ((HW & 3) == 0 ? 4 : 0);
+  if (vec) {
+    constexpr int TI = (TM + 1) / 2;
+    static_assert(32 * TI * WVM * BN * 4 <= (int)sizeof(smem),
+                  "half of the output tile must fit the operand images");
+    float *img = reinterpret_cast<float *>(&smem[0][0]);
+    __syncthreads();  // every wave is done reading the operand images
+#pragma unroll
+    for (int i0 = 0; i0 < TM; i0 += TI) {
+      if (vec == 8)
+        flat_tile_pass<T, TM, TN, WVM, WVN, TI, 8>(
+            img, acc, i0, out, addend, M, HW, a.n_img, a.ppi, a.ppi_magic, m0,
+            n0, wm, wn, tid);
+      else
+        flat_tile_pass<T, TM, TN, WVM, WVN, TI, 4>(
+            img, acc, i0, out, addend, M, HW, a.n_img, a.ppi, a.ppi_magic, m0,
+            n0, wm, wn, tid);
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -1728,7 +1932,7 @@ int sa_conv3x3_h16(int dtype, int mode, int n_img, int C, int K, int H, int W,
   };
   const int64_t HW = (int64_t)H * W;
   if (Kc % 64 != 0 || M < 8 || W % 2 != 0 || H < 2 || W < 4 ||
-      !al16(act) || !al16(out) || !al16(wt) ||
+      !al16(act) || !al16(out) || !al16(wt) || !al16(addend) ||
       (int64_t)std::max(M, Kc) * HW >= ((int64_t)1 << 29) ||
       (int64_t)9 * M * Kc >= ((int64_t)1 << 29))
     return -3;
@@ -1837,7 +2041,7 @@ int sa_conv_flat_h16(int dtype, int mode, int n_img, int C, int K, int H,
   const int64_t HW = (int64_t)H * W;
   if ((taps != 1 && taps != 9) || Kc % 64 != 0 || M < 8 || H < 1 || W < 1 ||
       (taps == 9 && (H < 2 || W < 2)) || !al16(act) || !al16(out) ||
-      !al16(wt) || !al16(w) ||
+      !al16(wt) || !al16(w) || !al16(addend) ||
       (int64_t)n_img * std::max(M, Kc) * HW >= ((int64_t)1 << 29) ||
       (int64_t)taps * M * Kc >= ((int64_t)1 << 29))
     return -3;

@@ -357,6 +357,167 @@ __global__ void bn_bwd_apply_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// One workgroup per channel: the channel lives in registers
+// ---------------------------------------------------------------------------
+// When a channel of the batch (N * HW values) fits the registers of one
+// workgroup -- the 28 x 28, 14 x 14 and 7 x 7 layers of a ResNet at batch 32 --
+// the two passes above become one kernel that reads every tensor ONCE: each
+// thread keeps up to UNITS pieces (VEC values each) of the channel, the block
+// reduces the statistics, and the normalisation (or its gradient) is applied
+// to the values still held in registers.  Half the launches and one pass over
+// the tensor less than the split-channel kernels, which remain for channels
+// too large for one workgroup.
+constexpr int kBnUnits = 7;
+
+template <typename T, int VEC> struct BnPiece {
+  float v[VEC];
+  __device__ __forceinline__ void ld(const T *p, size_t off, int i) {
+    if constexpr (VEC == 4) {
+      const float4 q = V4<T>::ld(p + off, i);
+      v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+      v[0] = to_f<T>(p[off + i]);
+    }
+  }
+  __device__ __forceinline__ void st(T *p, size_t off, int i) const {
+    if constexpr (VEC == 4)
+      V4<T>::st(p + off, i, make_float4(v[0], v[1], v[2], v[3]));
+    else
+      p[off + i] = from_f<T>(v[0]);
+  }
+};
+
+// unit u of the channel: image u / per_img, piece u % per_img of that image
+struct BnUnit {
+  size_t off;
+  int i;
+};
+__device__ __forceinline__ BnUnit bn_unit(int u, int c, int C, int HW,
+                                          Div32 div_per) {
+  uint32_t n, i;
+  div_per.divmod((uint32_t)u, n, i);
+  return BnUnit{((size_t)n * C + c) * HW, (int)i};
+}
+
+template <typename T, int VEC, int ACT>
+__global__ void __launch_bounds__(1024)
+bn_fwd_channel_kernel(const T *__restrict__ x, const float *__restrict__ scale,
+                      const float *__restrict__ bias, float *__restrict__ rmean,
+                      float *__restrict__ rvar, float factor, float eps,
+                      T *__restrict__ y, float *__restrict__ mean_out,
+                      float *__restrict__ invstd_out, const T *__restrict__ res,
+                      int N, int C, int HW, int units, Div32 div_per) {
+  __shared__ float smem[32];
+  const int c = blockIdx.x;
+  const float shift = to_f<T>(x[(size_t)c * HW]);
+  BnPiece<T, VEC> xv[kBnUnits];
+  float sum = 0.f, sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < kBnUnits; ++k) {
+    const int u = threadIdx.x + k * blockDim.x;
+    if (u < units) {
+      const BnUnit at = bn_unit(u, c, C, HW, div_per);
+      xv[k].ld(x, at.off, at.i);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float d = xv[k].v[e] - shift;
+        sum += d;
+        sq += d * d;
+      }
+    }
+  }
+  sum = block_sum(sum, smem);
+  sq = block_sum(sq, smem);
+  const float cnt = (float)N * (float)HW;
+  const float dm = sum / cnt;
+  const float mean = shift + dm;
+  const float var = fmaxf(sq / cnt - dm * dm, 0.f);
+  const float invstd = rsqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    const float unbiased = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
+    rmean[c] = (1.f - factor) * rmean[c] + factor * mean;
+    rvar[c] = (1.f - factor) * rvar[c] + factor * unbiased;
+  }
+  const float g = scale[c] * invstd;
+  const float b = bias[c] - mean * g;
+#pragma unroll
+  for (int k = 0; k < kBnUnits; ++k) {
+    const int u = threadIdx.x + k * blockDim.x;
+    if (u < units) {
+      const BnUnit at = bn_unit(u, c, C, HW, div_per);
+      BnPiece<T, VEC> r, o;
+      if (ACT == 2) r.ld(res, at.off, at.i);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        o.v[e] = bn_act<ACT>(fmaf(xv[k].v[e], g, b), ACT == 2 ? r.v[e] : 0.f);
+      o.st(y, at.off, at.i);
+    }
+  }
+}
+
+template <typename T, int VEC, int ACT>
+__global__ void __launch_bounds__(1024)
+bn_bwd_channel_kernel(const T *__restrict__ dy, const T *__restrict__ x,
+                      const T *__restrict__ y, const float *__restrict__ scale,
+                      const float *__restrict__ bias,
+                      const float *__restrict__ mean,
+                      const float *__restrict__ invstd, T *__restrict__ dx,
+                      T *__restrict__ dres, float *__restrict__ dscale,
+                      float *__restrict__ dbias, int N, int C, int HW,
+                      int units, Div32 div_per) {
+  __shared__ float smem[32];
+  const int c = blockIdx.x;
+  const float m = mean[c], iv = invstd[c];
+  const float g = scale[c] * iv;
+  const float b = ACT == 1 ? bias[c] - m * g : 0.f;
+  BnPiece<T, VEC> dv[kBnUnits], xv[kBnUnits];
+  float sdy = 0.f, sdyx = 0.f;
+#pragma unroll
+  for (int k = 0; k < kBnUnits; ++k) {
+    const int u = threadIdx.x + k * blockDim.x;
+    if (u < units) {
+      const BnUnit at = bn_unit(u, c, C, HW, div_per);
+      dv[k].ld(dy, at.off, at.i);
+      xv[k].ld(x, at.off, at.i);
+      BnPiece<T, VEC> yv;
+      if (ACT == 2) yv.ld(y, at.off, at.i);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        // the masked gradient replaces dy in the registers
+        const float d = bn_mask<ACT>(dv[k].v[e], xv[k].v[e], g, b,
+                                     ACT == 2 ? yv.v[e] : 0.f);
+        dv[k].v[e] = d;
+        sdy += d;
+        sdyx += d * (xv[k].v[e] - m);
+      }
+    }
+  }
+  sdy = block_sum(sdy, smem);
+  sdyx = block_sum(sdyx, smem) * iv;
+  if (threadIdx.x == 0) {
+    dscale[c] = sdyx;
+    dbias[c] = sdy;
+  }
+  const float cnt = (float)N * (float)HW;
+  const float k1 = sdy / cnt, k2 = sdyx / cnt * iv;
+#pragma unroll
+  for (int k = 0; k < kBnUnits; ++k) {
+    const int u = threadIdx.x + k * blockDim.x;
+    if (u < units) {
+      const BnUnit at = bn_unit(u, c, C, HW, div_per);
+      BnPiece<T, VEC> o;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        o.v[e] = g * (dv[k].v[e] - k1 - (xv[k].v[e] - m) * k2);
+      o.st(dx, at.off, at.i);
+      if (ACT == 2) dv[k].st(dres, at.off, at.i);
+    }
+  }
+}
+
 }  // namespace sa
 
 using namespace sa;
@@ -377,6 +538,21 @@ static inline bool bn_vec4(int dtype, int HW, const void *a, const void *b,
   return HW % 4 == 0 && (bits & (dtype == kF32 ? 15 : 7)) == 0;
 }
 
+
+// Threads of the one-workgroup-per-channel kernels for `units` pieces per
+// channel, 0 when a channel does not fit (or the switch SA_BN_CHANNEL=0 is
+// set).
+static int bn_channel_threads(int64_t units) {
+  static const int enabled = [] {
+    const char *v = getenv("SA_BN_CHANNEL");
+    return v && *v ? atoi(v) : 1;
+  }();
+  if (!enabled || units > (int64_t)1024 * kBnUnits) return 0;
+  int t = (int)((units + kBnUnits - 1) / kBnUnits);
+  t = (t + 63) / 64 * 64;
+  return t < 64 ? 64 : t;
+}
+
 #define BN_ACT_SWITCH(act, ...)                         \
   switch (act) {                                        \
     case 0: { constexpr int ACT = 0; __VA_ARGS__; break; } \
@@ -393,6 +569,31 @@ int sa_bn_fwd_train_act(int dtype, const void *x, const float *scale,
   if (N <= 0 || C <= 0 || HW <= 0) return 0;
   if (act == 2 && residual == nullptr) return -5;
   const int S = bn_splits(N, C);
+  {
+    const bool v4 = bn_vec4(dtype, HW, x, y, residual, nullptr);
+    const int per = v4 ? HW / 4 : HW;
+    const int64_t units = (int64_t)N * per;
+    const int threads = bn_channel_threads(units);
+    if (threads) {
+      SA_DISPATCH_FLOAT(dtype, T, {
+        BN_ACT_SWITCH(act, {
+          if (v4)
+            hipLaunchKernelGGL((bn_fwd_channel_kernel<T, 4, ACT>), dim3(C),
+                               dim3(threads), 0, s, (const T *)x, scale, bias,
+                               rmean, rvar, factor, eps, (T *)y, mean, invstd,
+                               (const T *)residual, N, C, HW, (int)units,
+                               Div32(per));
+          else
+            hipLaunchKernelGGL((bn_fwd_channel_kernel<T, 1, ACT>), dim3(C),
+                               dim3(threads), 0, s, (const T *)x, scale, bias,
+                               rmean, rvar, factor, eps, (T *)y, mean, invstd,
+                               (const T *)residual, N, C, HW, (int)units,
+                               Div32(per));
+        });
+      });
+      return 0;
+    }
+  }
   if (bn_vec4(dtype, HW, x, y, residual, nullptr)) {
     const dim3 grid(C, S), block(bn_block(HW / 4));
     SA_DISPATCH_FLOAT(dtype, T, {
@@ -497,6 +698,32 @@ int sa_bn_bwd_act(int dtype, const void *dy, const void *x, const void *y,
   if (act == 2 && (y == nullptr || dres == nullptr)) return -5;
   if (act == 1 && bias == nullptr) return -5;
   const int S = bn_splits(N, C);
+  {
+    const bool v4 = bn_vec4(dtype, HW, dy, x, dx, act == 2 ? y : nullptr) &&
+                    (reinterpret_cast<uintptr_t>(dres) & 15) == 0;
+    const int per = v4 ? HW / 4 : HW;
+    const int64_t units = (int64_t)N * per;
+    const int threads = bn_channel_threads(units);
+    if (threads) {
+      SA_DISPATCH_FLOAT(dtype, T, {
+        BN_ACT_SWITCH(act, {
+          if (v4)
+            hipLaunchKernelGGL((bn_bwd_channel_kernel<T, 4, ACT>), dim3(C),
+                               dim3(threads), 0, s, (const T *)dy,
+                               (const T *)x, (const T *)y, scale, bias, mean,
+                               invstd, (T *)dx, (T *)dres, dscale, dbias, N, C,
+                               HW, (int)units, Div32(per));
+          else
+            hipLaunchKernelGGL((bn_bwd_channel_kernel<T, 1, ACT>), dim3(C),
+                               dim3(threads), 0, s, (const T *)dy,
+                               (const T *)x, (const T *)y, scale, bias, mean,
+                               invstd, (T *)dx, (T *)dres, dscale, dbias, N, C,
+                               HW, (int)units, Div32(per));
+        });
+      });
+      return 0;
+    }
+  }
   if (bn_vec4(dtype, HW, dy, x, dx, act == 2 ? y : nullptr) &&
       (reinterpret_cast<uintptr_t>(dres) & 15) == 0) {
     const dim3 grid(C, S), block(bn_block(HW / 4));

@@ -14,7 +14,8 @@ def _grads(loss_fn, params):
     return [got[id(p)] for p in params]
 
 
-@pytest.mark.parametrize("shape", [(4, 6, 5, 8), (3, 5, 7, 7), (8, 16)])
+@pytest.mark.parametrize("shape", [(4, 6, 5, 8), (3, 5, 7, 7), (8, 16),
+                                   (8, 3, 64, 64)])
 @pytest.mark.parametrize("with_residual", [False, True])
 def test_bn_act_matches_unfused(dev, shape, with_residual):
     if len(shape) == 2 and with_residual:

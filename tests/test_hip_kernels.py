@@ -657,8 +657,12 @@ def test_conv3x3_float32_halo_path(maths, N, C, K, HW):
 
 
 @pytest.mark.parametrize("shape", [(8, 16, 14, 14), (32, 64, 7, 7), (16, 10),
-                                   (4, 3, 33, 17)])
+                                   (4, 3, 33, 17), (32, 8, 28, 28),
+                                   (40, 6, 56, 56), (9, 5, 61, 67)])
 def test_batchnorm(maths, shape):
+    """Channels that fit one workgroup's registers run the one-kernel path
+    (up to 7168 pieces: the first five shapes), larger ones the two split
+    passes ((40, 6, 56, 56) four values per access, (9, 5, 61, 67) scalar)."""
     hm, cm, dev = maths
     C = shape[1]
     x = rnd(*shape, seed=40, lo=-2, hi=5)
@@ -700,7 +704,8 @@ def test_batchnorm(maths, shape):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(8, 16, 14, 14), (4, 3, 33, 17)])
+@pytest.mark.parametrize("shape", [(8, 16, 14, 14), (4, 3, 33, 17),
+                                   (40, 6, 56, 56), (9, 5, 61, 67)])
 def test_batchnorm_16bit(maths, shape, dt):
     """16-bit activations, float parameters and statistics; (8, 16, 14, 14)
     takes the four-elements-per-access path, (4, 3, 33, 17) the scalar one."""

@@ -86,6 +86,7 @@ _CONV_FLAT_MAX_HW = int(os.environ.get("SINGA_CONV_FLAT_MAX_HW", "399"))
 # 3x3 layers need at least this many positions per image for that kernel (the
 # 7 x 7 layers have too few columns to fill the chip with its tiles)
 _CONV_FLAT_MIN_HW_3X3 = int(os.environ.get("SINGA_CONV_FLAT_MIN_HW_3X3", "64"))
+_CONV_S2_GATHER = os.environ.get("SINGA_CONV_S2_GATHER", "1") != "0"
 _CONV_WGRAD_GEMM = os.environ.get("SINGA_CONV_WGRAD_GEMM", "1") != "0"
 _CONV3X3_GEMM_MIN_HW = int(os.environ.get("SINGA_CONV3X3_GEMM_MIN_HW", "2000"))
 
@@ -705,10 +706,32 @@ class HipMath(object):
             g.set_stats(stats.data_ptr(), shift.data_ptr())
         self.k.conv_fwd(code, g, *args, self._s())
 
+    @staticmethod
+    def _strided_pointwise16(x, w, stride, pad, groups):
+        """16-bit 1x1 / stride 2 / unpadded convolution on even-sized images:
+        a stride-1 problem on the gathered even positions."""
+        return (_CONV_S2_GATHER and groups == 1 and
+                x.dtype in (torch.float16, torch.bfloat16) and
+                w.shape[2] == 1 and w.shape[3] == 1 and
+                tuple(stride) == (2, 2) and tuple(pad) == (0, 0) and
+                x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and
+                x.is_contiguous())
+
+    def _even_positions(self, x):
+        N, C, H, W = x.shape
+        xs = torch.empty((N, C, H // 2, W // 2), dtype=x.dtype,
+                         device=x.device)
+        self.k.subsample2(_code(x), x.data_ptr(), xs.data_ptr(), N * C, H, W,
+                          self._s())
+        return xs
+
     def _conv_fwd_16bit(self, x, w, b, y, stride, pad, groups):
         """The 16-bit GEMM-shaped forward kernels; False when none applies."""
         if b is not None:
             return False
+        if self._strided_pointwise16(x, w, stride, pad, groups):
+            return self._conv_fwd_16bit(self._even_positions(x), w, None, y,
+                                        (1, 1), (0, 0), 1)
         if self._small_image(x) and \
                 self._flat16(0, x, w, None, y, stride, pad, groups):
             return True
@@ -731,6 +754,17 @@ class HipMath(object):
         if addend is not None:
             assert addend.shape == dx.shape and addend.dtype == dx.dtype \
                 and addend.data_ptr() != dx.data_ptr()
+        if self._strided_pointwise16(dx, w, stride, pad, groups) and \
+                dy.is_contiguous():
+            N, C, H, W = dx.shape
+            dxs = torch.empty((N, C, H // 2, W // 2), dtype=dx.dtype,
+                              device=dx.device)
+            self.conv_bwd_data(dy, w, dxs, (1, 1), (0, 0), 1)
+            ad = None if addend is None else self._contig(addend)
+            self.k.upsample2_add(_code(dx), dxs.data_ptr(),
+                                 ad.data_ptr() if ad is not None else 0,
+                                 dx.data_ptr(), N * C, H, W, self._s())
+            return
         if self._pointwise16(dx, w, stride, pad, groups):
             N, C, H, W = dx.shape
             ad = None
@@ -800,6 +834,14 @@ class HipMath(object):
             part.data_ptr(), splits, dw.data_ptr(), self._s())
 
     def conv_bwd_weight(self, dy, x, dw, stride, pad, groups):
+        if self._strided_pointwise16(x, dw, stride, pad, groups) and \
+                _CONV_WGRAD_GEMM and dw.dtype == x.dtype and \
+                self.k.conv_wgrad_h16_splits(
+                    x.shape[0], x.shape[1], dw.shape[0], x.shape[2] // 2,
+                    x.shape[3] // 2, 1) and \
+                self._wgrad16(dy, self._even_positions(x), dw, (1, 1), (0, 0),
+                              1):
+            return
         if self._wgrad16(dy, x, dw, stride, pad, groups):
             return
         g = self._geom(x.shape, dw.shape, dy.shape, stride, pad, groups)

@@ -279,6 +279,16 @@ PYBIND11_MODULE(_hip, m) {
     check(rc, "conv_flat_h16");
     return true;
   });
+  m.def("subsample2", [](int dt, uintptr_t x, uintptr_t xs, int64_t planes,
+                         int H, int W, uintptr_t s) {
+    check(sa_subsample2(dt, CP(x), P(xs), planes, H, W, S(s)), "subsample2");
+  });
+  m.def("upsample2_add", [](int dt, uintptr_t dxs, uintptr_t addend,
+                            uintptr_t dx, int64_t planes, int H, int W,
+                            uintptr_t s) {
+    check(sa_upsample2_add(dt, CP(dxs), CP(addend), P(dx), planes, H, W, S(s)),
+          "upsample2_add");
+  });
   m.def("conv_wgrad_h16_splits", &sa_conv_wgrad_h16_splits);
   m.def("conv_wgrad_h16", [](int dt, int n_img, int C, int K, int H, int W,
                              int taps, uintptr_t dy, uintptr_t x,

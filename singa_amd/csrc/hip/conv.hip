@@ -1253,3 +1253,85 @@ int sa_conv_bwd_bias(int dtype, const void *dy, void *db, int N, int K, int PQ,
   });
   return 0;
 }
+
+// ---------------------------------------------------------------------------
+// Stride-2 sampling for 1x1 / stride 2 convolutions
+// ---------------------------------------------------------------------------
+// A 1x1 convolution with stride 2 only ever sees x[.., 2h, 2w]: gathering
+// those into a dense quarter-size tensor turns forward, data gradient and
+// weight gradient into stride-1 problems for the GEMM-shaped kernels.  The
+// data gradient goes back through the inverse (values at even positions,
+// zero elsewhere), fused with the gradient that reached x along another path.
+namespace sa {
+
+template <typename T>
+__global__ void subsample2_kernel(const T *__restrict__ x, T *__restrict__ xs,
+                                  int64_t planes, int H, int W, int P, int Q) {
+  const int64_t total = planes * P * Q;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += step) {
+    const int q = (int)(i % Q);
+    const int64_t t = i / Q;
+    const int p = (int)(t % P);
+    const int64_t plane = t / P;
+    xs[i] = x[(plane * H + 2 * p) * W + 2 * q];
+  }
+}
+
+// dx[.., h, w] = addend[.., h, w] + (h, w both even ? dxs[.., h/2, w/2] : 0);
+// one thread per pair of columns (W even)
+template <typename T>
+__global__ void upsample2_add_kernel(const T *__restrict__ dxs,
+                                     const T *__restrict__ addend,
+                                     T *__restrict__ dx, int64_t planes, int H,
+                                     int W, int P, int Q) {
+  const int W2 = W / 2;
+  const int64_t total = planes * H * W2;
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += step) {
+    const int w2 = (int)(i % W2);
+    const int64_t t = i / W2;
+    const int h = (int)(t % H);
+    const int64_t plane = t / H;
+    const int64_t at = (plane * H + h) * W + 2 * w2;
+    float a = 0.f, b = 0.f;
+    if (addend) {
+      a = to_f<T>(addend[at]);
+      b = to_f<T>(addend[at + 1]);
+    }
+    if ((h & 1) == 0) a += to_f<T>(dxs[(plane * P + (h >> 1)) * Q + w2]);
+    dx[at] = from_f<T>(a);
+    dx[at + 1] = from_f<T>(b);
+  }
+}
+
+}  // namespace sa
+
+int sa_subsample2(int dtype, const void *x, void *xs, int64_t planes, int H,
+                  int W, hipStream_t s) {
+  const int P = (H + 1) / 2, Q = (W + 1) / 2;
+  const int64_t total = planes * P * Q;
+  if (total <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((subsample2_kernel<T>), dim3(grid_for(total, 256)),
+                       dim3(256), 0, s, (const T *)x, (T *)xs, planes, H, W, P,
+                       Q);
+  });
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+int sa_upsample2_add(int dtype, const void *dxs, const void *addend, void *dx,
+                     int64_t planes, int H, int W, hipStream_t s) {
+  if (W % 2 != 0) return -3;
+  const int P = (H + 1) / 2, Q = (W + 1) / 2;
+  const int64_t total = planes * H * (W / 2);
+  if (total <= 0) return 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((upsample2_add_kernel<T>), dim3(grid_for(total, 256)),
+                       dim3(256), 0, s, (const T *)dxs, (const T *)addend,
+                       (T *)dx, planes, H, W, P, Q);
+  });
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}

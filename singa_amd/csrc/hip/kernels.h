@@ -201,6 +201,14 @@ int sa_conv_bwd_weight(int dtype, const ConvGeom *g, const void *dy,
                        const void *x, void *dw, hipStream_t s);
 int sa_conv_bwd_bias(int dtype, const void *dy, void *db, int N, int K,
                      int PQ, hipStream_t s);
+// xs[.., p, q] = x[.., 2p, 2q] over `planes` H x W images (xs is
+// ceil(H/2) x ceil(W/2)), and its transpose fused with an addend (may be
+// null): dx = addend + (values of dxs at even positions, zero elsewhere);
+// W even, -3 otherwise.
+int sa_subsample2(int dtype, const void *x, void *xs, int64_t planes, int H,
+                  int W, hipStream_t s);
+int sa_upsample2_add(int dtype, const void *dxs, const void *addend, void *dx,
+                     int64_t planes, int H, int W, hipStream_t s);
 // The same statistics as ConvGeom::stats from a finished tensor y [N][K][PQ]
 // (for convolution kernels without the fused epilogue).
 int sa_chan_sums(int dtype, const void *y, float *stats, const float *shift,

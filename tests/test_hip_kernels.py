@@ -588,6 +588,48 @@ def test_conv_16bit_flattened_positions_path(maths, dt, N, C, K, H, W, R,
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,C,K,H,W", [(3, 64, 128, 28, 28), (2, 128, 64, 56, 56),
+                                       (4, 64, 72, 14, 14), (2, 64, 64, 12, 20)])
+def test_conv1x1_stride2_16bit_gathered(maths, dt, N, C, K, H, W):
+    """16-bit 1x1 / stride 2 convolutions run as stride-1 problems on the
+    gathered even positions (forward, weight gradient) and scatter the data
+    gradient back, fused with the addend; reference: fp32 convolution."""
+    hm, cm, dev = maths
+    x = rnd(N, C, H, W, seed=110).to(dt)
+    w = rnd(K, C, 1, 1, seed=111, lo=-0.3, hi=0.3).to(dt)
+    assert hm._strided_pointwise16(g(x, dev), g(w, dev), (2, 2), (0, 0), 1)
+    eps = 2 ** -10 if dt == torch.float16 else 2 ** -7
+
+    def close(got, ref):
+        ref = ref.numpy()
+        scale = max(1.0, float(np.abs(ref).max()))
+        np.testing.assert_allclose(got.float().cpu().numpy(), ref,
+                                   atol=eps * scale, rtol=2 * eps)
+
+    P, Q = H // 2, W // 2
+    ry = torch.empty(N, K, P, Q)
+    cm.conv_fwd(x.float(), w.float(), None, ry, (2, 2), (0, 0), 1)
+    y = torch.zeros(N, K, P, Q, device=dev.torch_device, dtype=dt)
+    hm.conv_fwd(g(x, dev), g(w, dev), None, y, (2, 2), (0, 0), 1)
+    close(y, ry)
+    dy = rnd(N, K, P, Q, seed=112).to(dt)
+    add = rnd(N, C, H, W, seed=113).to(dt)
+    rdx = torch.empty(N, C, H, W)
+    cm.conv_bwd_data(dy.float(), w.float(), rdx, (2, 2), (0, 0), 1)
+    dx = torch.full((N, C, H, W), 7.0, device=dev.torch_device, dtype=dt)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (2, 2), (0, 0), 1)
+    close(dx, rdx)
+    hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (2, 2), (0, 0), 1,
+                     g(add, dev))
+    close(dx, rdx + add.float())
+    rdw = torch.empty(K, C, 1, 1)
+    cm.conv_bwd_weight(dy.float(), x.float(), rdw, (2, 2), (0, 0), 1)
+    dw = torch.zeros(K, C, 1, 1, device=dev.torch_device, dtype=dt)
+    hm.conv_bwd_weight(g(dy, dev), g(x, dev), dw, (2, 2), (0, 0), 1)
+    close(dw, rdw)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("N,C,K,H,W,R", [
     (2, 64, 64, 56, 56, 3),     # 64 x 64 tiles, whole pieces
     (3, 128, 96, 28, 28, 3),    # 128 x 128 tiles with a ragged row tile

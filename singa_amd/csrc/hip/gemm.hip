@@ -1430,7 +1430,7 @@ struct WgradArgs {
   unsigned ppi_magic, w_magic;  // ceil(2^32 / d): umulhi(v, magic) == v / d
 };
 
-template <typename T, int WVM, int WVN, int TM, int TN, int DEPTH>
+template <typename T, int WVM, int WVN, int TM, int TN, int DEPTH, bool VARPAR>
 __global__ void __launch_bounds__(64 * WVM * WVN)
 conv_wgrad_h16_kernel(WgradArgs a, int ntm, int ntn) {
   using namespace h16;
@@ -1529,61 +1529,64 @@ conv_wgrad_h16_kernel(WgradArgs a, int ntm, int ntn) {
       bbits = (v1 ? first : 0u) | (v2 ? second : 0u);
       if (ds < 0)
         bbits &= ~((w0 == 0 ? 1u : 0u) | (e_wrap < 8 ? (1u << e_wrap) : 0u));
-      if (ds > 0) bbits &= ~(e_wrap <= 8 ? (1u << (e_wrap - 1)) : 0u);
+      if (ds > 0)
+        bbits &= ~((e_wrap <= 8 ? (1u << (e_wrap - 1)) : 0u) |
+                   (e_wrap + W - 1 < 8 ? (1u << (e_wrap + W - 1)) : 0u));
     }
     if (!live) bbits = 0u;
     expand(tailbits, keep_a);
     expand(bbits, keep_b);
+    // one 8-element piece starting at element offset e0 (any parity: odd
+    // starts are fetched as five aligned dwords and funnel-shifted; `odd` is
+    // per thread with VARPAR, else the same for the whole tile)
+    auto piece = [&](const rsrc_t &rs, int limit, int e0, bool want, bool odd,
+                     bool five) {
+      const int b0 = (e0 & ~1) * 2;
+      u32x4 lo;
+      unsigned hi = 0;
+      if (EDGE) {
+        lo.x = dw(rs, want ? b0 : kOobOff, limit);
+        lo.y = dw(rs, want ? b0 + 4 : kOobOff, limit);
+        lo.z = dw(rs, want ? b0 + 8 : kOobOff, limit);
+        lo.w = dw(rs, want ? b0 + 12 : kOobOff, limit);
+        if (five) hi = dw(rs, want ? b0 + 16 : kOobOff, limit);
+      } else {
+        lo = __builtin_bit_cast(
+            u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                       rs, want ? b0 : kOobOff, 0, 0));
+        if (five)
+          hi = __builtin_bit_cast(
+              unsigned, __builtin_amdgcn_raw_buffer_load_b32(
+                            rs, want ? b0 + 16 : kOobOff, 0, 0));
+      }
+      u32x4 v = lo;
+      if (five) {
+        u32x4 sh;
+        sh.x = __builtin_amdgcn_alignbit(lo.y, lo.x, 16);
+        sh.y = __builtin_amdgcn_alignbit(lo.z, lo.y, 16);
+        sh.z = __builtin_amdgcn_alignbit(lo.w, lo.z, 16);
+        sh.w = __builtin_amdgcn_alignbit(hi, lo.w, 16);
+        v.x = odd ? sh.x : lo.x; v.y = odd ? sh.y : lo.y;
+        v.z = odd ? sh.z : lo.z; v.w = odd ? sh.w : lo.w;
+      }
+      return v;
+    };
+    const bool tap_odd = (shift & 1) != 0;
 #pragma unroll
     for (int j = 0; j < PERA; ++j) {
       const int r = m0 + r_first + (NT / 8) * j;
-      const bool want = live && r < M;
-      const int b0 = ((n * M + r) * HW + p) * 2;
-      u32x4 v;
-      if (EDGE) {
-        v.x = dw(rsrc_a, want ? b0 : kOobOff, limit_a);
-        v.y = dw(rsrc_a, want ? b0 + 4 : kOobOff, limit_a);
-        v.z = dw(rsrc_a, want ? b0 + 8 : kOobOff, limit_a);
-        v.w = dw(rsrc_a, want ? b0 + 12 : kOobOff, limit_a);
-      } else {
-        v = __builtin_bit_cast(
-            u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                       rsrc_a, want ? b0 : kOobOff, 0, 0));
-      }
+      const int e0 = (n * M + r) * HW + p;
+      u32x4 v = piece(rsrc_a, limit_a, e0, live && r < M,
+                      VARPAR && (e0 & 1) != 0, VARPAR);
       v.x &= keep_a[0]; v.y &= keep_a[1]; v.z &= keep_a[2]; v.w &= keep_a[3];
       ra[j] = v;
     }
 #pragma unroll
     for (int j = 0; j < PERB; ++j) {
       const int r = n0 + r_first + (NT / 8) * j;
-      const bool want = bbits != 0u && r < Nc;
-      const int byte = ((n * Nc + r) * HW + p + shift) * 2;
-      // first aligned dword touched; an odd shift needs five dwords
-      const int b0 = ds == 0 ? byte : byte - 2;
-      u32x4 lo;
-      unsigned hi = 0;
-      if (EDGE) {
-        lo.x = dw(rsrc_b, want ? b0 : kOobOff, limit_b);
-        lo.y = dw(rsrc_b, want ? b0 + 4 : kOobOff, limit_b);
-        lo.z = dw(rsrc_b, want ? b0 + 8 : kOobOff, limit_b);
-        lo.w = dw(rsrc_b, want ? b0 + 12 : kOobOff, limit_b);
-        if (ds != 0) hi = dw(rsrc_b, want ? b0 + 16 : kOobOff, limit_b);
-      } else {
-        lo = __builtin_bit_cast(
-            u32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                       rsrc_b, want ? b0 : kOobOff, 0, 0));
-        if (ds != 0)
-          hi = __builtin_bit_cast(
-              unsigned, __builtin_amdgcn_raw_buffer_load_b32(
-                            rsrc_b, want ? b0 + 16 : kOobOff, 0, 0));
-      }
-      u32x4 v = lo;
-      if (ds != 0) {
-        v.x = __builtin_amdgcn_alignbit(lo.y, lo.x, 16);
-        v.y = __builtin_amdgcn_alignbit(lo.z, lo.y, 16);
-        v.z = __builtin_amdgcn_alignbit(lo.w, lo.z, 16);
-        v.w = __builtin_amdgcn_alignbit(hi, lo.w, 16);
-      }
+      const int e0 = (n * Nc + r) * HW + p + shift;
+      u32x4 v = piece(rsrc_b, limit_b, e0, bbits != 0u && r < Nc,
+                      VARPAR ? (e0 & 1) != 0 : tap_odd, VARPAR || tap_odd);
       v.x &= keep_b[0]; v.y &= keep_b[1]; v.z &= keep_b[2]; v.w &= keep_b[3];
       rb[j] = v;
     }
@@ -1688,9 +1691,16 @@ static void launch_wgrad_h16(const WgradArgs &a, hipStream_t s) {
   constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
   const int ntm = (a.M + BM - 1) / BM, ntn = (a.Nc + BN - 1) / BN;
   const int64_t wgs = (int64_t)ntm * ntn * a.taps * a.splits;
-  hipLaunchKernelGGL((conv_wgrad_h16_kernel<T, WVM, WVN, TM, TN, DEPTH>),
-                     dim3((unsigned)((wgs + 7) / 8 * 8)), dim3(64 * WVM * WVN),
-                     0, s, a, ntm, ntn);
+  const dim3 grid((unsigned)((wgs + 7) / 8 * 8)), block(64 * WVM * WVN);
+  // an odd image size puts the rows of both operands at either parity
+  if ((a.H * a.W) % 2 != 0)
+    hipLaunchKernelGGL(
+        (conv_wgrad_h16_kernel<T, WVM, WVN, TM, TN, DEPTH, true>), grid, block,
+        0, s, a, ntm, ntn);
+  else
+    hipLaunchKernelGGL(
+        (conv_wgrad_h16_kernel<T, WVM, WVN, TM, TN, DEPTH, false>), grid,
+        block, 0, s, a, ntm, ntn);
 }
 
 // Tile of the weight-gradient kernel for an M x Nc filter matrix: rows, columns
@@ -1956,8 +1966,9 @@ int sa_conv3x3_h16(int dtype, int mode, int n_img, int C, int K, int H, int W,
 // (the caller then uses the implicit-GEMM convolution kernel).
 int sa_conv_wgrad_h16_splits(int n_img, int C, int K, int H, int W, int taps) {
   const int64_t HW = (int64_t)H * W;
-  if ((taps != 1 && taps != 9) || n_img <= 0 || C < 8 || K < 8 || W < 8 ||
-      W % 2 != 0 || HW < 64 ||
+  // a piece of 8 positions may span two image rows, not three
+  if ((taps != 1 && taps != 9) || n_img <= 0 || C < 8 || K < 8 || W < 7 ||
+      HW < 49 ||
       (int64_t)n_img * std::max(C, K) * HW >= ((int64_t)1 << 29))
     return 0;
   static const int forced = [] {

@@ -638,6 +638,10 @@ def test_conv1x1_stride2_16bit_gathered(maths, dt, N, C, K, H, W):
     (3, 64, 256, 14, 14, 1),    # 1x1: 128 x 64 tiles
     (2, 256, 64, 28, 28, 1),    # 1x1: 64 x 128 tiles
     (4, 136, 200, 9, 8, 1),     # 1x1: ragged tiles in both directions
+    (6, 64, 128, 7, 7, 3),      # odd image size: rows at either parity
+    (5, 72, 64, 7, 7, 1),       # 1x1 on an odd image size
+    (2, 64, 64, 9, 7, 3),       # 63 positions, 7 columns
+    (2, 40, 64, 6, 9, 3),       # odd row length, even image size
 ])
 def test_conv_weight_gradient_16bit_gemm_path(maths, dt, N, C, K, H, W, R):
     """16-bit weight gradients of 1x1 and 3x3 / pad 1 stride-1 convolutions

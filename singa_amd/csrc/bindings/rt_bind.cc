@@ -11,6 +11,7 @@
 #include "../runtime/block.h"
 #include "../runtime/channel.h"
 #include "../runtime/graph.h"
+#include "../runtime/lmdbfile.h"
 #include "../runtime/logging.h"
 #include "../runtime/snapshot.h"
 #include "../runtime/textfile.h"
@@ -300,6 +301,34 @@ PYBIND11_MODULE(_rt, m) {
            })
       .def("Count", &TextFileReader::Count)
       .def("SeekToFirst", &TextFileReader::SeekToFirst);
+
+  py::class_<LMDBWriter>(m, "LMDBWriter")
+      .def(py::init<>())
+      .def("Open", &LMDBWriter::Open, py::arg("path"),
+           py::arg("append") = false, py::arg("page_size") = 4096)
+      .def("Close", &LMDBWriter::Close)
+      .def("Write",
+           [](LMDBWriter &w, py::bytes key, py::bytes val) {
+             return w.Write(std::string(key), std::string(val));
+           })
+      .def("Flush", &LMDBWriter::Flush)
+      .def("path", &LMDBWriter::path);
+  py::class_<LMDBReader>(m, "LMDBReader")
+      .def(py::init<>())
+      .def("Open", &LMDBReader::Open)
+      .def("Close", &LMDBReader::Close)
+      .def("Read",
+           [](LMDBReader &r) -> py::object {
+             std::string k, v;
+             if (!r.Read(&k, &v)) return py::none();
+             return py::make_tuple(py::bytes(k), py::bytes(v));
+           })
+      .def("Count", &LMDBReader::Count)
+      .def("SeekToFirst", &LMDBReader::SeekToFirst)
+      .def("valid", &LMDBReader::valid)
+      .def("depth", &LMDBReader::depth)
+      .def("page_size", &LMDBReader::page_size)
+      .def("path", &LMDBReader::path);
 
   // ---- snapshot -------------------------------------------------------------
   py::class_<SnapshotTensor>(m, "SnapshotTensor")

@@ -1,10 +1,12 @@
 // Record readers of the C++ API, the counterparts of io/writer.h.
 // API parity: reference include/singa/io/reader.h (Reader, BinFileReader,
-// TextFileReader; the LMDB reader needs a library this build does not have).
+// TextFileReader, LMDBReader: the LMDB file format is parsed by the runtime's
+// own code, runtime/lmdbfile.h, no library is needed).
 #pragma once
 #include <string>
 
 #include "../../../../runtime/binfile.h"
+#include "../../../../runtime/lmdbfile.h"
 #include "../../../../runtime/textfile.h"
 
 namespace singa {
@@ -54,6 +56,25 @@ class TextFileReader : public Reader {
 
  private:
   ::singa_amd::TextFileReader impl_;
+};
+
+/// Tuples of an LMDB environment in key order.
+class LMDBReader : public Reader {
+ public:
+  ~LMDBReader() override { Close(); }
+  bool Open(const std::string &path) override { return impl_.Open(path); }
+  void Close() override { impl_.Close(); }
+  bool Read(std::string *key, std::string *value) override {
+    return impl_.Read(key, value);
+  }
+  int Count() override { return impl_.Count(); }
+  void SeekToFirst() override { impl_.SeekToFirst(); }
+  const std::string &path() const { return impl_.path(); }
+  /// whether the last Read found a tuple
+  bool valid() const { return impl_.valid(); }
+
+ private:
+  ::singa_amd::LMDBReader impl_;
 };
 
 }  // namespace io

@@ -2,11 +2,13 @@
 // or one value per line to a text file.  The file formats are those of the
 // runtime's record files (runtime/binfile.h, runtime/textfile.h).
 // API parity: reference include/singa/io/writer.h (Writer, BinFileWriter,
-// TextFileWriter; the LMDB writer needs a library this build does not have).
+// TextFileWriter, LMDBWriter: the LMDB file format is written by the
+// runtime's own code, runtime/lmdbfile.h, no library is needed).
 #pragma once
 #include <string>
 
 #include "../../../../runtime/binfile.h"
+#include "../../../../runtime/lmdbfile.h"
 #include "../../../../runtime/textfile.h"
 
 namespace singa {
@@ -58,6 +60,25 @@ class TextFileWriter : public Writer {
 
  private:
   ::singa_amd::TextFileWriter impl_;
+};
+
+/// Tuples into an LMDB environment (a directory with `data.mdb`); the
+/// environment is rebuilt from the sorted tuples on every Flush.
+class LMDBWriter : public Writer {
+ public:
+  ~LMDBWriter() override { Close(); }
+  bool Open(const std::string &path, Mode mode) override {
+    return impl_.Open(path, mode == kAppend);
+  }
+  void Close() override { impl_.Close(); }
+  bool Write(const std::string &key, const std::string &value) override {
+    return impl_.Write(key, value);
+  }
+  void Flush() override { impl_.Flush(); }
+  const std::string &path() const { return impl_.path(); }
+
+ private:
+  ::singa_amd::LMDBWriter impl_;
 };
 
 }  // namespace io

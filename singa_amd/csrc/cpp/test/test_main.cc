@@ -4,6 +4,7 @@
 //                             with the host result of the same operation
 // Modelled on the reference's test/singa/test_*.cc suites (tensor math,
 // layers, optimizers, loss, metric, snapshot, feed-forward net, endpoint).
+#include <unistd.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -753,6 +754,58 @@ static void TestIo() {
     EXPECT(tr.Read(&k, &v) && k == "1" && v == "second");
     EXPECT(!tr.Read(&k, &v));
     tr.Close();
+  }
+  // LMDB environments: small values in the leaves, big values in overflow
+  // runs, several tree levels, append mode, key order
+  {
+    const std::string dir = "/tmp/singa_cpp_test_lmdb";
+    std::remove((dir + "/data.mdb").c_str());
+    rmdir(dir.c_str());
+    io::LMDBWriter lw;
+    io::Writer *w = &lw;
+    EXPECT(w->Open(dir, io::kCreate));
+    char name[16];
+    for (int i = 2999; i >= 0; --i) {  // written in reverse key order
+      snprintf(name, sizeof(name), "%08d", i);
+      EXPECT(w->Write(name, std::string(size_t(i % 97 + 1), char('a' + i % 26))));
+    }
+    EXPECT(w->Write("big", std::string(100000, 'B')));
+    EXPECT(w->Write("00000007", "overwritten"));
+    w->Close();
+    io::LMDBReader lr;
+    io::Reader *rd = &lr;
+    EXPECT(rd->Open(dir));
+    EXPECT(rd->Count() == 3001);
+    std::string k, v, prev;
+    int n = 0;
+    bool ordered = true, values_ok = true;
+    while (rd->Read(&k, &v)) {
+      if (n > 0 && !(prev < k)) ordered = false;
+      prev = k;
+      if (k == "big") {
+        values_ok = values_ok && v == std::string(100000, 'B');
+      } else if (k == "00000007") {
+        values_ok = values_ok && v == "overwritten";
+      } else {
+        int i = atoi(k.c_str());
+        values_ok = values_ok &&
+                    v == std::string(size_t(i % 97 + 1), char('a' + i % 26));
+      }
+      ++n;
+    }
+    EXPECT(n == 3001 && ordered && values_ok && k == "big");
+    EXPECT(!lr.valid());
+    rd->SeekToFirst();
+    EXPECT(rd->Read(&k, &v) && k == "00000000" && v == "a");
+    rd->Close();
+    EXPECT(w->Open(dir, io::kAppend));
+    EXPECT(w->Write("zzz", "last"));
+    w->Close();
+    EXPECT(rd->Open(dir));
+    EXPECT(rd->Count() == 3002);
+    rd->Close();
+    io::LMDBReader missing;
+    EXPECT(!missing.Open("/tmp/singa_cpp_test_lmdb_missing"));
   }
   // channel to a file, stopwatch
   {

@@ -132,3 +132,134 @@ def test_logging(tmp_path, capfd):
     assert "info message" in err and "warning message" in err
     with pytest.raises(RuntimeError):
         _rt.Log(3, "fatal message", "file.py", 12)
+
+
+# ---- LMDB environments -------------------------------------------------------
+def _lmdb_walk(raw):
+    """Independent parser of an LMDB data file (format version 1): returns the
+    (key, value) pairs of the main database in tree order plus the database
+    record of the current meta page."""
+    def meta(off):
+        flags, = struct.unpack_from("<H", raw, off + 10)
+        assert flags & 0x08
+        magic, version = struct.unpack_from("<II", raw, off + 16)
+        assert magic == 0xBEEFC0DE and version == 1
+        psize, = struct.unpack_from("<I", raw, off + 16 + 24)
+        main = struct.unpack_from("<IHHQQQQQ", raw, off + 16 + 72)
+        last_pg, txnid = struct.unpack_from("<QQ", raw, off + 16 + 120)
+        return psize, main, last_pg, txnid
+    psize = meta(0)[0]
+    m0, m1 = meta(0), meta(psize)
+    cur = m1 if m1[3] > m0[3] else m0
+    _, main, last_pg, _ = cur
+    assert (last_pg + 1) * psize == len(raw)
+    out = []
+    counts = {"branch": 0, "leaf": 0, "overflow": 0}
+
+    def walk(pgno, level):
+        off = pgno * psize
+        no, _, flags, lower, upper = struct.unpack_from("<QHHHH", raw, off)
+        assert no == pgno
+        nkeys = (lower - 16) // 2
+        ptrs = struct.unpack_from("<%dH" % nkeys, raw, off + 16)
+        assert min(ptrs) == upper and lower <= upper
+        depth = None
+        for i, p in enumerate(ptrs):
+            lo, hi, nflags, ksize = struct.unpack_from("<HHHH", raw, off + p)
+            key = raw[off + p + 8: off + p + 8 + ksize]
+            if flags & 0x01:
+                assert (ksize == 0) == (i == 0)
+                d = walk(lo | (hi << 16) | (nflags << 32), level + 1)
+                assert depth in (None, d)
+                depth = d
+            else:
+                assert flags & 0x02
+                dsize = lo | (hi << 16)
+                if nflags & 0x01:
+                    ov, = struct.unpack_from("<Q", raw, off + p + 8 + ksize)
+                    ono, _, oflags, pages = struct.unpack_from(
+                        "<QHHI", raw, ov * psize)
+                    assert ono == ov and oflags & 0x04
+                    assert pages == (15 + dsize) // psize + 1
+                    counts["overflow"] += pages
+                    val = raw[ov * psize + 16: ov * psize + 16 + dsize]
+                else:
+                    val = raw[off + p + 8 + ksize: off + p + 8 + ksize + dsize]
+                out.append((bytes(key), bytes(val)))
+        if flags & 0x01:
+            assert nkeys >= 2
+            counts["branch"] += 1
+            return depth + 1
+        counts["leaf"] += 1
+        return 1
+    root = main[7]
+    depth = walk(root, 0) if root != 2 ** 64 - 1 else 0
+    assert depth == main[2]
+    assert (counts["branch"], counts["leaf"], counts["overflow"]) == main[3:6]
+    assert main[6] == len(out)
+    return out, main
+
+
+@pytest.mark.parametrize("page_size", [4096, 512])
+def test_lmdb_file_format(tmp_path, page_size):
+    rng = np.random.RandomState(3)
+    d = os.path.join(str(tmp_path), "env")
+    items = {}
+    for i in rng.permutation(1500):
+        key = ("k%07d" % i).encode() + b"x" * int(rng.randint(0, 40))
+        items[key] = rng.bytes(int(rng.randint(1, 300)))
+    items[b"big-one"] = rng.bytes(3 * page_size + 17)
+    items[b"big-two"] = rng.bytes(page_size - 16)  # exactly one overflow page
+    items[b"k"] = b""                                # a prefix of other keys
+    w = _rt.LMDBWriter()
+    assert w.Open(d, False, page_size)
+    for k, v in items.items():
+        assert w.Write(k, v)
+    w.Close()
+    raw = open(os.path.join(d, "data.mdb"), "rb").read()
+    pairs, main = _lmdb_walk(raw)
+    assert [k for k, _ in pairs] == sorted(items)
+    assert dict(pairs) == items
+    assert main[2] >= 2          # more than one level
+    r = _rt.LMDBReader()
+    assert r.Open(d)
+    assert r.Count() == len(items) and r.page_size() == page_size
+    got = []
+    while True:
+        kv = r.Read()
+        if kv is None:
+            break
+        got.append(kv)
+    assert got == pairs
+    r.SeekToFirst()
+    assert r.Read() == pairs[0]
+    r.Close()
+
+
+def test_lmdb_append_overwrite_and_empty(tmp_path):
+    d = os.path.join(str(tmp_path), "env")
+    w = _rt.LMDBWriter()
+    assert w.Open(d)
+    w.Close()                          # an environment without tuples
+    r = _rt.LMDBReader()
+    assert r.Open(d) and r.Count() == 0 and r.Read() is None
+    r.Close()
+    assert not _rt.LMDBWriter().Open(os.path.join(str(tmp_path), "no"), True)
+    w = _rt.LMDBWriter()
+    assert w.Open(d, True)
+    w.Write(b"b", b"1")
+    w.Write(b"a", b"2")
+    w.Flush()
+    w.Write(b"b", b"3")                # the last value of a key wins
+    w.Close()
+    w = _rt.LMDBWriter()
+    assert w.Open(d, True)
+    w.Write(b"c", b"4")
+    w.Close()
+    pairs, _ = _lmdb_walk(open(os.path.join(d, "data.mdb"), "rb").read())
+    assert pairs == [(b"a", b"2"), (b"b", b"3"), (b"c", b"4")]
+    with pytest.raises(RuntimeError):
+        w2 = _rt.LMDBWriter()
+        w2.Open(d, True)
+        w2.Write(b"", b"x")
+    assert not _rt.LMDBReader().Open(os.path.join(str(tmp_path), "missing"))

@@ -86,6 +86,15 @@ def _s(v):
     return utils.force_unicode(v)
 
 
+def _window_pads(pads):
+    """ONNX lists the pads of a 2-d window as (top, left, bottom, right); the
+    layers take (top, bottom, left, right)."""
+    pads = tuple(pads)
+    if len(pads) == 4:
+        return (pads[0], pads[2], pads[1], pads[3])
+    return pads
+
+
 # ---------------------------------------------------------------------------
 # import: ONNX operator -> (target, constructor arguments, attribute inputs)
 # ---------------------------------------------------------------------------
@@ -245,7 +254,7 @@ class SingaBackend(object):
             if bias:
                 n.set_weight_inputs(n.inputs[2], 'b')
             return op(None, kernel, stride=tuple(g('strides', (1, 1))),
-                      padding=tuple(g('pads', (0, 0))), dilation=1,
+                      padding=_window_pads(g('pads', (0, 0))), dilation=1,
                       group=g('group', 1), bias=bias,
                       pad_mode=_s(g('auto_pad', 'NOTSET')))
         if t in ('MaxPool', 'AveragePool'):
@@ -256,7 +265,7 @@ class SingaBackend(object):
             if len(kernel) > 2:
                 raise ValueError("Only implemented for 1d or 2d")
             return op(kernel, tuple(g('strides', (1, 1))),
-                      tuple(g('pads', (0, 0))), t == 'MaxPool',
+                      _window_pads(g('pads', (0, 0))), t == 'MaxPool',
                       _s(g('auto_pad', 'NOTSET')))
         if t == 'ScatterElements':
             cls._attr_in(n, 1, 'indices')

@@ -428,6 +428,9 @@ case("test_conv_with_strides_no_padding", "Conv", [_cx, _cw],
 case("test_conv_with_asymmetric_padding", "Conv", [_cx, _cw],
      [_conv_ref(_cx, _cw, None, 1, [1, 0, 0, 1])], rtol=1e-4, atol=1e-4,
      kernel_shape=[3, 3], pads=[1, 0, 0, 1])
+case("test_conv_with_pads_begin_end_order", "Conv", [_cx, _cw],
+     [_conv_ref(_cx, _cw, None, 1, [2, 0, 1, 1])], rtol=1e-4, atol=1e-4,
+     kernel_shape=[3, 3], pads=[2, 0, 1, 1])
 case("test_conv_with_autopad_same_upper", "Conv", [_cx, _cw],
      [_conv_ref(_cx, _cw, None, 2, _same_pads((7, 7), (3, 3), (2, 2), True))],
      rtol=1e-4, atol=1e-4, kernel_shape=[3, 3], strides=[2, 2],
@@ -453,6 +456,15 @@ for _op, _is_max in (("MaxPool", True), ("AveragePool", False)):
     case("test_%s_2d_pads" % _n, _op, [_px],
          [_pool_ref(_px, 3, 1, [1, 1, 1, 1], _is_max)], kernel_shape=[3, 3],
          pads=[1, 1, 1, 1])
+    if _is_max:
+        # pads are (top, left, bottom, right): the stride-1 pooling of the
+        # tiny-YOLO graphs pads after the last row / column only
+        case("test_maxpool_2d_pads_end_only", _op, [_px],
+             [_pool_ref(_px, 2, 1, [0, 0, 1, 1], True)], kernel_shape=[2, 2],
+             pads=[0, 0, 1, 1], strides=[1, 1])
+        case("test_maxpool_2d_pads_bottom_only", _op, [_px],
+             [_pool_ref(_px, 3, 1, [0, 0, 2, 0], True)], kernel_shape=[3, 3],
+             pads=[0, 0, 2, 0], strides=[1, 1])
     # SAME_* with an odd total padding: max pooling pads with the lowest
     # value (the specification); average pooling replicates the border cell
     # (as the reference does, python/singa/utils.py handle_odd_pad_fwd), which

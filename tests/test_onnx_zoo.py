@@ -132,3 +132,81 @@ def test_arcface_similarity_and_preprocessing(zoo):
     assert luma.dtype == np.uint8 and luma[0, 0] == 127
     assert sr.merge_colour(np.zeros((672, 672), np.uint8), img).size == \
         (672, 672)
+
+
+# ---- text examples: tokenizers and answer extraction --------------------------
+def _text_module(sub, name):
+    path = os.path.join(ZOO, sub) if sub else ZOO
+    sys.path.insert(0, path)
+    try:
+        sys.modules.pop(name, None)
+        return importlib.import_module(name)
+    finally:
+        sys.path.remove(path)
+
+
+def test_wordpiece_windows_and_spans(zoo):
+    st = _text_module("bert", "squad_text")
+    vocab = {t: i for i, t in enumerate(
+        ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "where", "is", "the", "center",
+         "?", "mos", "##cone", "in", "san", "francisco", ".", "un", "##aff",
+         "##able"])}
+    assert st.basic_tokens("Où est-il?") == ["ou", "est", "-", "il", "?"]
+    assert st.wordpiece("moscone", vocab) == ["mos", "##cone"]
+    assert st.wordpiece("unaffable", vocab) == ["un", "##aff", "##able"]
+    assert st.wordpiece("xyz", vocab) == ["[UNK]"]
+    wins, words = st.windows("Where is the center?",
+                             "The Moscone Center is in San Francisco.", vocab,
+                             max_seq=24)
+    assert len(wins) == 1
+    w = wins[0]
+    assert w.tokens[:7] == ["[CLS]", "where", "is", "the", "center", "?",
+                            "[SEP]"]
+    assert w.tokens[7:10] == ["the", "mos", "##cone"]
+    assert w.input_ids.shape == (24,) and w.input_mask.sum() == len(w.tokens)
+    assert w.segment_ids[:7].sum() == 0 and w.segment_ids[7] == 1
+    assert w.token_to_word[8] == w.token_to_word[9] == 1   # "Moscone"
+    # logits that point at "San Francisco."
+    s = np.full(24, -5.0)
+    e = np.full(24, -5.0)
+    s[w.tokens.index("san")] = 4.0
+    e[w.tokens.index(".")] = 3.0
+    e[2] = 9.0            # inside the question: never an answer
+    spans = st.best_spans(wins, words, [s], [e])
+    assert spans[0] == ("San Francisco.", 7.0)
+    # a long context is covered by overlapping windows
+    long_ctx = " ".join(["the center in san francisco ."] * 30)
+    wins, _ = st.windows("where ?", long_ctx, vocab, max_seq=32, stride=16)
+    assert len(wins) > 5
+    assert all(x.input_ids.shape == (32,) for x in wins)
+    assert wins[1].token_to_word[wins[1].context_start] == \
+        wins[0].token_to_word[wins[0].context_start + 16]
+
+
+def test_byte_pair_tokenizer(zoo, tmp_path):
+    bp = _text_module("", "bpe")
+    import json
+    b2c = bp._byte_alphabet()
+    assert len(set(b2c.values())) == 256 and b2c[ord("a")] == "a"
+    sp = b2c[ord(" ")]
+    vocab = {c: i for i, c in enumerate(sorted(set(b2c.values())))}
+    merges = [("l", "o"), ("lo", "w"), (sp, "low"), ("e", "r")]
+    for a, b in merges:
+        vocab.setdefault(a + b, len(vocab))
+    json.dump(vocab, open(os.path.join(str(tmp_path), "vocab.json"), "w"))
+    open(os.path.join(str(tmp_path), "merges.txt"), "w").write(
+        "#version: 0.2\n" + "\n".join(a + " " + b for a, b in merges))
+    tok = bp.BPETokenizer(str(tmp_path))
+    ids = tok.encode("low lower")
+    assert [tok.decoder[i] for i in ids] == ["low", sp + "low", "er"]
+    assert tok.decode(ids) == "low lower"
+    assert tok.decode(tok.encode("héllo, wörld 42!")) == "héllo, wörld 42!"
+    bt = bp.ByteTokenizer()
+    assert bt.decode(bt.encode("añb")) == "añb"
+    g2 = _text_module("gpt2", "gpt2")
+    rng = np.random.RandomState(0)
+    logits = np.array([0.1, 5.0, 4.9, -3.0])
+    assert g2.next_token(logits, 1, rng) == 1
+    assert {g2.next_token(logits, 2, rng) for _ in range(40)} == {1, 2}
+    out = g2.generate(lambda ids: np.eye(5)[(ids[-1] + 1) % 5], [0], 4)
+    assert out == [1, 2, 3, 4]

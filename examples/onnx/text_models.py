@@ -39,9 +39,11 @@ class BertClassifier(sonnx.SONNXModel):
     through the whole encoder (the counterpart of the reference's
     examples/onnx/training/train.py:105-142 for a transformer backbone)."""
 
-    def __init__(self, onnx_model, num_classes=2, sequence_output=0):
+    def __init__(self, onnx_model, num_classes=2, sequence_output=0,
+                 dtype=None):
         super(BertClassifier, self).__init__(onnx_model,
-                                             trainable_weights=True)
+                                             trainable_weights=True,
+                                             dtype=dtype)
         self.sequence_output = sequence_output
         self.head = layer.Linear(num_classes)
         self.loss = layer.SoftMaxCrossEntropy()

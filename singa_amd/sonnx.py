@@ -736,6 +736,8 @@ class SingaRep(object):
         # set by SONNXModel(trainable_weights=True): a registry that receives
         # the float initializers as parameters
         self.weights = None
+        # None: floats stay float32; float16 / bfloat16: see set_float_dtype
+        self.float_dtype = None
 
     def initialize(self):
         self.outputs_info = {o.name: o for o in self.outputs}
@@ -756,6 +758,16 @@ class SingaRep(object):
                         list(node.weight_inputs.keys())):
                 self.tensor_count[inp] = self.tensor_count.get(inp, 0) + 1
 
+    def set_float_dtype(self, dtype):
+        """Run the float32 parts of the graph in ``dtype`` (float16 /
+        bfloat16): constants, fed float inputs and Cast-to-float nodes."""
+        self.float_dtype = dtype
+        self._const_cache = {}
+        for _, operator in self.layers:
+            if isinstance(operator, autograd.Cast) and \
+                    operator.to == tensor.float32:
+                operator.to = dtype
+
     def to_input_tensor(self, x):
         tensor_dict = {}
         for key, val in zip(self.inputs, x):
@@ -764,6 +776,9 @@ class SingaRep(object):
                 val = np.atleast_1d(val.astype(
                     onnx_type_to_singa_type(key.dtype)))
                 val = tensor.Tensor(device=self.dev, data=val)
+            if self.float_dtype is not None and \
+                    val.dtype == tensor.float32:
+                val = val.as_type(self.float_dtype)
             tensor_dict[key.name] = val
         return tensor_dict
 
@@ -816,6 +831,15 @@ class SingaRep(object):
                     if t is None:
                         val = np.atleast_1d(self.states[inp])
                         t = tensor.Tensor(device=self.dev, data=val)
+                        if self.float_dtype is not None and \
+                                val.dtype.kind == 'f':
+                            # converted now, also while a step is recorded
+                            prev = self.dev.graph_enabled()
+                            self.dev.EnableGraph(False)
+                            try:
+                                t = t.as_type(self.float_dtype)
+                            finally:
+                                self.dev.EnableGraph(prev)
                         t.requires_grad = False
                         if self.weights is not None and \
                                 val.dtype.kind == 'f' and val.size > 1:
@@ -907,11 +931,16 @@ class SONNXModel(model.Model):
     ``trainable_weights=True`` also turns the float initializers that the
     graph feeds to MatMul / Add / Gather into parameters (the weights of a
     transformer export), not only those owned by Conv / Gemm / BatchNorm
-    layers."""
+    layers.  ``dtype=tensor.float16`` (or ``bfloat16``) runs a float32 graph
+    in 16 bits: float initializers are converted when they are uploaded, float
+    inputs when they are fed, and Cast-to-float nodes produce that type (the
+    reference imports float32 graphs as float32 only)."""
 
-    def __init__(self, onnx_model, trainable_weights=False):
+    def __init__(self, onnx_model, trainable_weights=False, dtype=None):
         super(SONNXModel, self).__init__()
         self.sg_ir = prepare(onnx_model)
+        if dtype is not None:
+            self.sg_ir.set_float_dtype(dtype)
         for node, operator in self.sg_ir.layers:
             if isinstance(operator, layer.Layer):
                 # registered as sub-layer: its weights become parameters of

@@ -210,3 +210,51 @@ def test_byte_pair_tokenizer(zoo, tmp_path):
     assert {g2.next_token(logits, 2, rng) for _ in range(40)} == {1, 2}
     out = g2.generate(lambda ids: np.eye(5)[(ids[-1] + 1) % 5], [0], 4)
     assert out == [1, 2, 3, 4]
+
+
+# ---- a float32 transformer graph imported in 16 bits ---------------------------
+@pytest.mark.parametrize("dtype_name,tol", [("float16", 0.02),
+                                            ("bfloat16", 0.15)])
+@pytest.mark.parametrize("graph", [False, True])
+def test_bert_import_in_16_bits(zoo, dev, dtype_name, tol, graph):
+    """Inference against the float64 evaluation of the same weights, then a
+    few fine-tuning steps (float32 master weights) that must lower the loss;
+    with ``graph`` the steps are recorded and replayed, which covers the
+    conversion of the initializers while a step is being recorded."""
+    from singa_amd import opt, tensor
+    tm = importlib.import_module("text_models")
+    dt = getattr(tensor, dtype_name)
+    cfg = dict(seq=16, hidden=128, heads=2, layers=2, ffn=256, vocab=100)
+    model, W = tm.bert_encoder(batch=2, squad_head=False, **cfg)
+    rs = np.random.RandomState(0)
+    ids = rs.randint(0, 100, (2, 16)).astype(np.int32)
+    mask = np.ones((2, 16), np.int32)
+    mask[1, 10:] = 0
+    seg = np.zeros((2, 16), np.int32)
+    seg[:, 8:] = 1
+    xs = [tensor.from_numpy(a, dev) for a in (ids, mask, seg)]
+    want = tm.bert_encoder_numpy(W, *[a.astype(np.int64)
+                                      for a in (ids, mask, seg)], 2, 2)
+    m = tm.TextModel(model, dtype=dt)
+    m.compile(xs, is_train=False, use_graph=graph, sequential=True)
+    m.eval()
+    for _ in range(3 if graph else 1):
+        y = m(*xs)[0]
+    assert y.dtype == dt
+    got = tensor.to_numpy(y.as_type(tensor.float32))
+    assert np.abs(got - want).max() < tol * np.abs(want).max()
+    dev.ResetGraph()
+    ty = tensor.from_numpy(np.array([0, 1], np.int32), dev)
+    clf = tm.BertClassifier(model, 2, dtype=dt)
+    clf.set_optimizer(opt.SGD(lr=1e-2, momentum=0.9))
+    clf.compile(xs, is_train=True, use_graph=graph, sequential=False)
+    clf.train()
+    losses = []
+    for _ in range(5):
+        _, loss = clf(*xs, ty)
+        losses.append(float(tensor.to_numpy(
+            loss.as_type(tensor.float32)).reshape(-1)[0]))
+    assert np.isfinite(losses).all() and losses[-1] < 0.2 * losses[0], losses
+    params = clf.get_params()
+    assert any(p.dtype == dt for p in params.values())
+    dev.ResetGraph()

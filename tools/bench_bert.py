@@ -60,6 +60,11 @@ def main():
     ap.add_argument("--train-batches", default="8,32")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--no-unfused", action="store_true")
+    ap.add_argument("--dtype", choices=["fp32", "fp16", "bf16"],
+                    default="fp32",
+                    help="16-bit: the float32 graph is imported with its "
+                         "weights and activations in that type (float32 "
+                         "master weights in the optimizer)")
     ap.add_argument("--check", action="store_true",
                     help="compare fused and unfused outputs with float64")
     args = ap.parse_args()
@@ -67,7 +72,10 @@ def main():
     rs = np.random.RandomState(0)
     cfg = dict(seq=args.seq, hidden=args.hidden, heads=args.heads,
                layers=args.layers, ffn=args.ffn, vocab=args.vocab)
-    out = {"config": cfg, "dtype": "fp32", "data": "synthetic", "results": []}
+    out = {"config": cfg, "dtype": args.dtype, "data": "synthetic",
+           "results": []}
+    dt = {"fp32": None, "fp16": tensor.float16,
+          "bf16": tensor.bfloat16}[args.dtype]
     modes = [True] if args.no_unfused else [True, False]
 
     # ---- inference, batch 1, eager (the reference's script) and graph mode
@@ -77,11 +85,12 @@ def main():
     for fuse in modes:
         sonnx.SingaBackend.fuse_patterns = fuse
         for graph in (False, True):
-            m = tm.TextModel(model1)
+            m = tm.TextModel(model1, dtype=dt)
             m.compile(xs, is_train=False, use_graph=graph, sequential=True)
             m.eval()
             t = timed(lambda: m(*xs), args.steps, 3)
-            outs[fuse] = tensor.to_numpy(m(*xs)[0])
+            outs[fuse] = tensor.to_numpy(
+                m(*xs)[0].as_type(tensor.float32))
             out["results"].append({"task": "inference", "batch": 1,
                                    "fused": fuse, "graph": graph,
                                    "ms": round(t * 1e3, 3),
@@ -107,16 +116,20 @@ def main():
         ty = tensor.from_numpy(rs.randint(0, 2, B).astype(np.int32), dev)
         for fuse in modes:
             sonnx.SingaBackend.fuse_patterns = fuse
-            m = tm.BertClassifier(modelB, num_classes=2)
+            m = tm.BertClassifier(modelB, num_classes=2, dtype=dt)
             m.set_optimizer(opt.SGD(lr=1e-3, momentum=0.9))
             m.compile(xs, is_train=True, use_graph=True, sequential=False)
             m.train()
             def step():
                 return m(*xs, ty)[1]
 
-            first = float(tensor.to_numpy(step()).reshape(-1)[0])
+            def loss_value():
+                return float(tensor.to_numpy(
+                    step().as_type(tensor.float32)).reshape(-1)[0])
+
+            first = loss_value()
             t = timed(step, args.steps, 4)
-            lv = [first, float(tensor.to_numpy(step()).reshape(-1)[0])]
+            lv = [first, loss_value()]
             out["results"].append({"task": "fine-tune", "batch": B,
                                    "fused": fuse, "graph": True,
                                    "ms": round(t * 1e3, 3),

@@ -954,6 +954,36 @@ class Matmul(Operator):
 
 
 
+class LinearBias(Operator):
+    """y = x @ w + b for x of any rank (..., K), w (K, N), b (N,): the bias is
+    added by the product kernel, its gradient is one column sum that reads
+    ``dy`` in its own precision.  The importer maps MatMul(x, W) -> Add(b)
+    with constant W and b to this operator (the reference keeps the two nodes,
+    python/singa/sonnx.py)."""
+
+    def forward(self, x, w, b):
+        if training:
+            self.input = (x, w)
+        return singa.LinearBias(x, w, b)
+
+    def backward(self, dy):
+        x, w = self.input
+        K, N = w.shape()
+        M = int(np.prod(x.shape())) // K
+        dy2 = singa.Reshape(dy, [M, N])
+        dx = dw = None
+        if self.x_needs_grad[0]:
+            dx = singa.Reshape(singa.Mult(dy2, _t_last2(w)), list(x.shape()))
+        if self.x_needs_grad[1]:
+            dw = singa.Mult(_t_last2(singa.Reshape(x, [M, K])), dy2)
+        db = singa.Sum(dy2, 0)
+        return dx, dw, db
+
+
+def linear_bias(x, w, b):
+    return LinearBias()(x, w, b)[0]
+
+
 class AddBias(Operator):
     """Add a vector to every row (axis 0) or column (axis 1) of a matrix, in
     place."""
@@ -970,11 +1000,8 @@ class AddBias(Operator):
         return x
 
     def backward(self, dy):
-        dtype = dy.data_type()
-        _dy = dy.AsType(tensor.float32)
-        if self.axis == 0:
-            return dy, singa.Sum(_dy, 0).AsType(dtype)
-        return dy, singa.Sum(_dy, 1).AsType(dtype)
+        # the reductions accumulate in float32 whatever the type of dy
+        return dy, singa.Sum(dy, 0 if self.axis == 0 else 1)
 
 
 def add_bias(x, b, axis=0):
@@ -1577,7 +1604,8 @@ def split(x, axis, parts, num_output=None):
 
 
 class Gather(Operator):
-    """ONNX Gather with host-side indices (1-d or 2-d list)."""
+    """ONNX Gather; ``indices`` is a host-side list / array or an int32
+    tensor on the device."""
 
     def __init__(self, axis, indices):
         super(Gather, self).__init__()
@@ -1588,15 +1616,25 @@ class Gather(Operator):
         self.x_shape = list(x.shape())
         self.axis = self.axis % len(self.x_shape)
         n = self.x_shape[self.axis]
-        if isinstance(self.indices, Tensor):
-            idx = tensor.to_numpy(self.indices)
+        if isinstance(self.indices, Tensor) and \
+                self.indices.dtype == tensor.int32:
+            # indices computed on the device (token ids fed to the model):
+            # read in place at every run, also when a recorded step is
+            # replayed on new inputs; the kernels wrap negative entries
+            self.idx_shape = list(self.indices.shape)
+            self.index = singa.Reshape(self.indices.data,
+                                       [int(np.prod(self.idx_shape))])
         else:
-            idx = np.asarray(self.indices)
-        self.idx_shape = list(idx.shape)
-        flat = np.mod(idx.reshape(-1).astype(np.int64), n).astype(np.int32)
-        it = tensor.from_numpy(flat)
-        it.to_device(x.device())
-        self.index = it.data
+            if isinstance(self.indices, Tensor):
+                idx = tensor.to_numpy(self.indices)
+            else:
+                idx = np.asarray(self.indices)
+            self.idx_shape = list(idx.shape)
+            flat = np.mod(idx.reshape(-1).astype(np.int64),
+                          n).astype(np.int32)
+            it = tensor.from_numpy(flat)
+            it.to_device(x.device())
+            self.index = it.data
         y = singa.IndexSelect(x, self.axis, self.index)
         out_shape = (self.x_shape[:self.axis] + self.idx_shape +
                      self.x_shape[self.axis + 1:])

@@ -114,11 +114,15 @@ class CpuMath(object):
         out_flat[:r.numel()].copy_(r.reshape(-1))
 
     def index_select(self, x, axis, idx, out):
-        out.copy_(torch.index_select(x, axis, idx.long()))
+        idx = idx.long()
+        idx = torch.where(idx < 0, idx + x.shape[axis], idx)
+        out.copy_(torch.index_select(x, axis, idx))
 
     def index_add(self, dy, axis, idx, out):
+        idx = idx.long()
+        idx = torch.where(idx < 0, idx + out.shape[axis], idx)
         out.zero_()
-        out.index_add_(axis, idx.long(), dy)
+        out.index_add_(axis, idx, dy)
 
     def row_max(self, x, out):
         out.copy_(x.max(dim=1).values.reshape(out.shape))
@@ -133,11 +137,17 @@ class CpuMath(object):
         return float(x.sum())
 
     # ---- linear algebra ---------------------------------------------------------
-    def gemm(self, alpha, a, b, beta, c):
-        """c = alpha * a @ b + beta * c for 2-d (or batched 3-d) views."""
+    def gemm(self, alpha, a, b, beta, c, bias=None, act=0):
+        """c = act(alpha * a @ b + bias + beta * c) for 2-d (or batched 3-d)
+        views; ``bias`` has one value per column, ``act`` 1 is ReLU."""
         r = torch.matmul(a, b)
         if alpha != 1.0:
             r = r * alpha
+        if bias is not None:
+            r = r + bias
+        if act == 1:
+            assert not beta
+            r = torch.relu(r)
         if beta:
             c.mul_(beta).add_(r)
         else:

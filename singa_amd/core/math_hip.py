@@ -34,6 +34,9 @@ _CODE = {torch.float32: 0, torch.float16: 1, torch.int32: 2,
          torch.bfloat16: 7}
 
 
+_FLOATS = (torch.float32, torch.float16, torch.bfloat16)
+
+
 def _code(t):
     try:
         return _CODE[t.dtype]
@@ -288,14 +291,15 @@ class HipMath(object):
         if axis == 1:
             self._rows("sum", x, o)
             return
-        xf = self._f32c(x)
+        # 16-bit input is read as it is; sums are accumulated in float32
+        xf = x if x.dtype in _FLOATS else self._f32c(x)
         if o.dtype == torch.float32 and o.is_contiguous():
-            self.k.reduce_cols(0, xf.data_ptr(), o.data_ptr(), rows, cols,
-                               self._s())
+            self.k.reduce_cols(_code(xf), xf.data_ptr(), o.data_ptr(), rows,
+                               cols, self._s())
         else:
             tmp = self._tmp(cols)
-            self.k.reduce_cols(0, xf.data_ptr(), tmp.data_ptr(), rows, cols,
-                               self._s())
+            self.k.reduce_cols(_code(xf), xf.data_ptr(), tmp.data_ptr(), rows,
+                               cols, self._s())
             self.copy(tmp, o)
 
     def row_max(self, x, out):
@@ -317,11 +321,12 @@ class HipMath(object):
             self._rows(op, x2, o)
         elif op in ("sum", "mean") and axes == list(range(len(axes))):
             # leading axes: column sums of the (cols, rows) matrix
-            x2 = self._f32c(x).reshape(cols, rows)
+            x2 = (x if x.dtype in _FLOATS and x.is_contiguous()
+                  else self._f32c(x)).reshape(cols, rows)
             tmp = o if (o.dtype == torch.float32 and o.is_contiguous()) \
                 else self._tmp(rows)
-            self.k.reduce_cols(0, x2.data_ptr(), tmp.data_ptr(), cols, rows,
-                               self._s())
+            self.k.reduce_cols(_code(x2), x2.data_ptr(), tmp.data_ptr(), cols,
+                               rows, self._s())
             if op == "mean":
                 self._unary(_U["mul_s"], tmp, tmp, 1.0 / cols)
             if tmp is not o:

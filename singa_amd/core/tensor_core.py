@@ -857,6 +857,24 @@ def MultWithScale(alpha, A, B, beta, C):
     return C
 
 
+def LinearBias(x, w, b):
+    """x (..., K) @ w (K, N) + b (N,) with the bias added in the epilogue of
+    the product: one kernel, no broadcast addition."""
+    if x._shape[-1] != w._shape[0] or w.nDim() != 2 or \
+            Product(b._shape) != w._shape[1]:
+        raise ValueError("linear: %s x %s + %s" % (x._shape, w._shape,
+                                                     b._shape))
+    out = Tensor(list(x._shape[:-1]) + [w._shape[1]], x._dev, x._dtype)
+    src = x if x.is_contiguous() else Contiguous(x)
+    K, N = w._shape
+
+    def body(a, wt, bias, c):
+        c._dev.math.gemm(1.0, a.view().reshape(-1, K), wt.view(), 0.0,
+                         c.view().reshape(-1, N), bias=bias.view().reshape(-1))
+    _submit(x._dev, "LinearBias", body, [src, w, b], [out])
+    return out
+
+
 def MultWithRet(A, B, C):
     return MultWithScale(1.0, A, B, 0.0, C)
 

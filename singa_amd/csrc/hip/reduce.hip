@@ -106,6 +106,45 @@ __global__ void reduce_cols_kernel(const T *__restrict__ x,
   }
 }
 
+// the same with one 16-byte load per thread and row: a block covers
+// 64 * VEC columns, rows r0 + ry, r0 + ry + 4, ...
+template <typename T>
+__global__ void reduce_cols_vec_kernel(const T *__restrict__ x,
+                                       float *__restrict__ out, int64_t rows,
+                                       int64_t cols, int64_t rows_per_block) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  __shared__ float part[4][64 * VEC];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t c = ((int64_t)blockIdx.x * 64 + cx) * VEC;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + ry; r < r1; r += 4) {
+      const uint4 w = *reinterpret_cast<const uint4 *>(x + r * cols + c);
+      T e[VEC];
+      __builtin_memcpy(e, &w, 16);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += to_f<T>(e[k]);
+    }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) part[ry][cx + 64 * k] = acc[k];
+  __syncthreads();
+  if (ry == 0 && c < cols) {
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float v = part[0][cx + 64 * k] + part[1][cx + 64 * k] +
+                      part[2][cx + 64 * k] + part[3][cx + 64 * k];
+      if (gridDim.y == 1)
+        out[c + k] = v;
+      else
+        atomicAdd(out + c + k, v);
+    }
+  }
+}
+
 template <typename T>
 __global__ void cast_from_f32_kernel(const float *__restrict__ in,
                                      T *__restrict__ out, int64_t n) {
@@ -199,29 +238,29 @@ int sa_reduce_rows(int op, int dtype, const void *x, void *out, int64_t rows,
 int sa_reduce_cols(int dtype, const void *x, void *out, int64_t rows,
                    int64_t cols, hipStream_t s) {
   if (cols <= 0) return 0;
-  // split the rows so that the launch has a few thousand blocks at most
-  const int64_t col_blocks = (cols + 63) / 64;
-  int64_t splits = 1;
-  if (rows > 256) {
-    splits = i64min((rows + 255) / 256,
-                          i64max(1, 1024 / col_blocks));
-  }
-  const int64_t rpb = (rows + splits - 1) / splits;
-  splits = (rows + rpb - 1) / rpb;
-  if (dtype == kF32) {
-    if (splits > 1) zero_async(out, cols * sizeof(float), s);
-    hipLaunchKernelGGL((reduce_cols_kernel<float>),
-                       dim3((unsigned)col_blocks, (unsigned)splits), dim3(256),
-                       0, s, (const float *)x, (float *)out, rows, cols, rpb);
-    return 0;
-  }
-  // half types: single pass per column block, accumulate in float, no split
+  int rc = 0;
   SA_DISPATCH_FLOAT(dtype, T, {
-    // reuse the kernel with splits = 1 writing float into a temp is not
-    // possible without workspace, so accumulate per column block serially
-    return -3;
+    constexpr int VEC = 16 / (int)sizeof(T);
+    const bool vec = cols % VEC == 0 &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    // split the rows so that the launch has a few thousand blocks at most
+    const int64_t per_block = vec ? 64 * VEC : 64;
+    const int64_t col_blocks = (cols + per_block - 1) / per_block;
+    int64_t splits = 1;
+    if (rows > 256)
+      splits = i64min((rows + 255) / 256, i64max(1, 1024 / col_blocks));
+    const int64_t rpb = (rows + splits - 1) / splits;
+    splits = (rows + rpb - 1) / rpb;
+    if (splits > 1) zero_async(out, cols * sizeof(float), s);
+    const dim3 grid((unsigned)col_blocks, (unsigned)splits);
+    if (vec)
+      hipLaunchKernelGGL((reduce_cols_vec_kernel<T>), grid, dim3(256), 0, s,
+                         (const T *)x, (float *)out, rows, cols, rpb);
+    else
+      hipLaunchKernelGGL((reduce_cols_kernel<T>), grid, dim3(256), 0, s,
+                         (const T *)x, (float *)out, rows, cols, rpb);
   });
-  return 0;
+  return rc;
 }
 
 int sa_reduce_all(int op, int dtype, const void *x, void *out, int64_t n,

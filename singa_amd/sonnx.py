@@ -121,6 +121,7 @@ class SingaBackend(object):
         'Ceil': 'Ceil', 'Floor': 'Floor', 'Abs': 'Abs', 'Exp': 'Exp',
         'Round': 'Rounde', 'Erf': 'Erf', 'LayerNormalization': 'LayerNorm',
         'Gelu': 'Gelu', 'FusedAttention': 'Attention',
+        'FusedLinear': 'LinearBias',
         'Unsqueeze': 'Unsqueeze', 'ScatterElements': 'ScatterElements',
         'Cast': 'Cast', 'Split': 'Split', 'Squeeze': 'Squeeze',
         'GlobalAveragePool': 'GlobalAveragePool', 'LeakyRelu': 'LeakyRelu',
@@ -433,7 +434,9 @@ def _fuse_transformer_patterns(graph):
 
     Each chain whose intermediate tensors have no other consumer is replaced
     by one LayerNormalization / Gelu node (one kernel instead of nine / five,
-    no intermediate tensors).  Returns the new node list."""
+    no intermediate tensors).  The attention chain becomes FusedAttention and
+    MatMul -> Add of a constant matrix and vector becomes FusedLinear (bias in
+    the epilogue of the product).  Returns the new node list."""
     nodes = list(graph.node)
     consts = {t.name: numpy_helper.to_array(t) for t in graph.initializer}
     for n in nodes:
@@ -708,6 +711,27 @@ def _fuse_transformer_patterns(graph):
             name=(nodes[rs].name or "attn_%d" % rs) + "_fused",
             scale=float(scale))
 
+    # ---- linear layer: MatMul(x, W) -> Add(b), W (K, N) and b (N,) constant --
+    for i, n in enumerate(nodes):
+        if i in dead or n.op_type != 'MatMul':
+            continue
+        wname = n.input[1]
+        if wname not in consts or consts[wname].ndim != 2 or \
+                consts[wname].dtype.kind != 'f':
+            continue
+        c = only(n.output[0])
+        if not c or c[0] in dead or nodes[c[0]].op_type != 'Add':
+            continue
+        bname = other(nodes[c[0]], n.output[0])
+        if bname not in consts or \
+                consts[bname].shape != (consts[wname].shape[1],):
+            continue
+        dead.update([i, c[0]])
+        replace[c[0]] = helper.make_node(
+            'FusedLinear', [n.input[0], wname, bname],
+            [nodes[c[0]].output[0]],
+            name=(nodes[c[0]].name or "linear_%d" % c[0]) + "_fused")
+
     out = []
     for i, n in enumerate(nodes):
         if i in replace:
@@ -859,6 +883,12 @@ class SingaRep(object):
                 ts = tensor_dict[key] if key in tensor_dict \
                     else self.states[key]
                 if isinstance(ts, tensor.Tensor):
+                    if name == 'indices' and ts.dtype == tensor.int32 and \
+                            isinstance(op, autograd.Gather):
+                        # stays on the device: no synchronisation, and a
+                        # replayed step gathers with the ids of its own batch
+                        op.indices = ts
+                        continue
                     ts = tensor.to_numpy(ts)
                 if name in ('W', 'b', 'scale', 'bias', 'running_mean',
                             'running_var'):

@@ -336,3 +336,66 @@ def test_conv_hands_batchnorm_statistics_cpu(monkeypatch):
     np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
     for a, b in zip(stats, ref_stats):
         np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-6)
+
+
+# ---- linear layer with the bias in the product's epilogue ----------------------
+@pytest.mark.parametrize("dtype_name,tol", [("float32", 2e-5),
+                                            ("float16", 2e-2),
+                                            ("bfloat16", 1e-1)])
+@pytest.mark.parametrize("shape", [(6, 5, 24), (33, 40), (2, 3, 4, 8)])
+def test_linear_bias_forward_backward(dev, dtype_name, tol, shape):
+    from singa_amd import autograd, tensor
+    dt = getattr(tensor, dtype_name)
+    rs = np.random.RandomState(0)
+    K, N = shape[-1], 16
+    x = rs.randn(*shape).astype(np.float32)
+    w = (rs.randn(K, N) * 0.3).astype(np.float32)
+    b = rs.randn(N).astype(np.float32)
+    dy = rs.randn(*shape[:-1], N).astype(np.float32)
+
+    def T(a, grad=True):
+        t = tensor.from_numpy(a, dev).as_type(dt)
+        t.requires_grad = grad
+        t.stores_grad = grad
+        return t
+    prev = autograd.training
+    autograd.training = True
+    try:
+        tx, tw, tb = T(x), T(w), T(b)
+        y = autograd.linear_bias(tx, tw, tb)
+        assert y.shape == tuple(shape[:-1]) + (N,) and y.dtype == dt
+        dx, dw, db = y.creator.backward(T(dy, False).data)
+    finally:
+        autograd.training = prev
+
+    def N_(core):
+        return tensor.to_numpy(tensor.from_raw_tensor(core).as_type(
+            tensor.float32)) if not isinstance(core, tensor.Tensor) else \
+            tensor.to_numpy(core.as_type(tensor.float32))
+    x2, dy2 = x.reshape(-1, K).astype(np.float64), dy.reshape(-1, N)
+    scale = max(1.0, float(np.abs(x2 @ w).max()))
+    np.testing.assert_allclose(N_(y), x @ w + b, atol=tol * scale)
+    np.testing.assert_allclose(N_(dx), (dy2 @ w.T).reshape(shape),
+                               atol=tol * scale)
+    np.testing.assert_allclose(N_(dw), x2.T @ dy2,
+                               atol=tol * max(1.0, np.abs(x2.T @ dy2).max()))
+    np.testing.assert_allclose(N_(db), dy2.sum(0),
+                               atol=tol * max(1.0, np.abs(dy2.sum(0)).max()))
+
+
+@pytest.mark.parametrize("dtype_name", ["float32", "float16", "bfloat16"])
+@pytest.mark.parametrize("rows,cols", [(1, 8), (300, 768), (1025, 36),
+                                       (700, 13)])
+def test_column_sums_read_the_input_type(dev, dtype_name, rows, cols):
+    """Sum over axis 0 of a matrix of any float type (float accumulation;
+    16-byte loads when the row length allows, single elements otherwise)."""
+    from singa_amd import singa_wrap as singa
+    from singa_amd import tensor
+    dt = getattr(tensor, dtype_name)
+    a = np.random.RandomState(1).randn(rows, cols).astype(np.float32)
+    t = tensor.from_numpy(a, dev).as_type(dt)
+    ref = tensor.to_numpy(t.as_type(tensor.float32)).astype(np.float64).sum(0)
+    got = tensor.to_numpy(tensor.from_raw_tensor(
+        singa.Sum(t.data, 0)).as_type(tensor.float32))
+    tol = {"float32": 1e-4, "float16": 4e-3, "bfloat16": 3e-2}[dtype_name]
+    np.testing.assert_allclose(got, ref, atol=tol * max(1.0, np.abs(ref).max()))

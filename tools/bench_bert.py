@@ -60,6 +60,7 @@ def main():
     ap.add_argument("--train-batches", default="8,32")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--no-unfused", action="store_true")
+    ap.add_argument("--no-inference", action="store_true")
     ap.add_argument("--dtype", choices=["fp32", "fp16", "bf16"],
                     default="fp32",
                     help="16-bit: the float32 graph is imported with its "
@@ -82,7 +83,7 @@ def main():
     model1, W = tm.bert_encoder(batch=1, **cfg)
     xs = inputs(dev, 1, args.seq, args.vocab, rs)
     outs = {}
-    for fuse in modes:
+    for fuse in ([] if args.no_inference else modes):
         sonnx.SingaBackend.fuse_patterns = fuse
         for graph in (False, True):
             m = tm.TextModel(model1, dtype=dt)

@@ -96,15 +96,19 @@ def run_onnx(onnx_model, x_np, dev, use_graph=True, repeat=0):
     model = ZooModel(onnx_model)
     x = tensor.Tensor(device=dev, data=x_np)
     model.compile([x], is_train=False, use_graph=use_graph, sequential=True)
-    y = tensor.to_numpy(model.forward(x))
+    # with use_graph the forward pass is recorded and replayed (one hipGraph
+    # launch per inference on a GPU)
+    model.graph_inference = use_graph
+    model.eval()
+    y = tensor.to_numpy(model(x))
     if not repeat:
         return y
-    for _ in range(2):
-        model.forward(x)
+    for _ in range(3):
+        model(x)
     dev.Sync()
     t0 = time.perf_counter()
     for _ in range(repeat):
-        out = model.forward(x)
+        out = model(x)
     tensor.to_numpy(out)
     dev.Sync()
     return y, (time.perf_counter() - t0) * 1e3 / repeat

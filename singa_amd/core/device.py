@@ -13,6 +13,7 @@ Behaviour parity: reference include/singa/core/device.h:57-174 (Exec, RunGraph,
 ResetGraph, EnableGraph, Sync, SetRandSeed, SetVerbosity, SetSkipIteration,
 PrintTimeProfiling), src/core/device/{device,cpp_cpu,cuda_gpu,platform}.cc.
 """
+import contextlib
 import os
 import time
 
@@ -108,6 +109,36 @@ class Device(object):
         self.SyncNow()
         self.ResetGraph()
         self.SetVerbosity(0)
+
+    # -- more than one recorded graph per device ------------------------------
+    # The device records into and replays ONE graph at a time.  A second
+    # recorded computation (a model's inference pass next to its training
+    # step) owns a graph state of its own and swaps it in while it records or
+    # replays.
+    def new_graph_state(self):
+        g = _rt.Graph()
+        g.set_hooks(self._timed_exec, self.SyncNow, self._collect)
+        g.set_verbosity(self._verbosity)
+        g.set_skip_iteration(self._skip_iteration)
+        return {"graph": g, "clock": {}}
+
+    def _get_graph_state(self):
+        return {"graph": self._graph, "clock": self._node_clock}
+
+    def _set_graph_state(self, st):
+        self._graph, self._node_clock = st["graph"], st["clock"]
+
+    @contextlib.contextmanager
+    def graph_state(self, st):
+        """Record / replay with the graph state ``st`` (from
+        ``new_graph_state``) in place of the device's current one."""
+        outer = self._get_graph_state()
+        self._set_graph_state(st)
+        try:
+            yield st
+        finally:
+            st.update(self._get_graph_state())
+            self._set_graph_state(outer)
 
     def graph(self):
         return self._graph
@@ -246,6 +277,22 @@ class HipGPU(Device):
         self._replay = None
         self._eager_done = 0
         self._stamps = None
+
+    def new_graph_state(self):
+        st = super().new_graph_state()
+        st.update(replay=None, eager_done=0, stamps=None, events={})
+        return st
+
+    def _get_graph_state(self):
+        st = super()._get_graph_state()
+        st.update(replay=self._replay, eager_done=self._eager_done,
+                  stamps=self._stamps, events=self._events)
+        return st
+
+    def _set_graph_state(self, st):
+        super()._set_graph_state(st)
+        self._replay, self._eager_done = st["replay"], st["eager_done"]
+        self._stamps, self._events = st["stamps"], st["events"]
 
     def hipgraph_segments(self):
         """Number of hipGraph launches one replayed iteration issues (0 while

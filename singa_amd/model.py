@@ -94,6 +94,60 @@ class _RecordedStep(object):
         return self.outputs
 
 
+class _RecordedInference(object):
+    """The forward pass of a model in evaluation mode, recorded once per input
+    signature (shapes, types, non-tensor arguments) and replayed afterwards --
+    on a GPU as one captured hipGraph, so that a small-batch inference costs
+    one launch instead of one Python dispatch per operator.  Every signature
+    owns a graph state of the device (``Device.new_graph_state``), next to the
+    one of the training step.  Inputs passed later are copied into the
+    tensors the recording read, unless they are those tensors.
+
+    Only meaningful for a forward pass whose sequence of operators does not
+    depend on tensor values read on the host.  The reference never records
+    evaluation (python/singa/model.py:214-228 dispatches it eagerly)."""
+
+    def __init__(self):
+        self.plans = {}
+
+    def reset(self):
+        self.plans = {}
+
+    @staticmethod
+    def _signature(args, kwargs):
+        sig = []
+        for a in list(args) + sorted(kwargs.items()):
+            ts = list(_walk_tensors([a]))
+            if ts:
+                sig.append(tuple((tuple(t.shape), t.dtype) for t in ts))
+            else:
+                sig.append(repr(a))
+        return tuple(sig)
+
+    def run(self, model, args, kwargs):
+        tensors = list(_walk_tensors([list(args), kwargs]))
+        assert tensors, 'a recorded inference takes at least one tensor'
+        dev = tensors[0].device
+        key = self._signature(args, kwargs)
+        plan = self.plans.get(key)
+        if plan is None:
+            plan = dict(state=dev.new_graph_state(), inputs=tensors)
+            with dev.graph_state(plan["state"]):
+                with _recording(dev):
+                    plan["outputs"] = model.forward(*args, **kwargs)
+                    dev.Sync()
+            for t in _walk_tensors(plan["outputs"]):
+                t.creator = None
+            self.plans[key] = plan
+        else:
+            for dst, src in zip(plan["inputs"], tensors):
+                if dst is not src and dst.data is not src.data:
+                    dst.copy_data(src)
+        with dev.graph_state(plan["state"]):
+            dev.RunGraph(model.sequential)
+        return plan["outputs"]
+
+
 def _graphed(body):
     """Wrap ``train_one_batch``: replay through the model's recorded step in
     graph mode, plain call otherwise."""
@@ -131,6 +185,11 @@ class Model(layer.Layer, metaclass=ModelMeta):
         super(Model, self).__init__()
         self.training, self.graph_mode, self.sequential = True, True, False
         self._step = _RecordedStep()
+        # evaluation through a recorded forward pass as well (graph mode
+        # only); off unless asked for, see _RecordedInference
+        self.graph_inference = os.environ.get("SINGA_GRAPH_INFERENCE",
+                                              "0") == "1"
+        self._inference = _RecordedInference()
 
     # ---- execution mode ---------------------------------------------------------
     def compile(self, inputs, is_train=True, use_graph=False, sequential=False):
@@ -146,6 +205,7 @@ class Model(layer.Layer, metaclass=ModelMeta):
         finally:
             lead.device.ResetGraph()
         self._step.reset()
+        self._inference.reset()
         self.train(is_train)
         self.graph(use_graph, sequential)
 
@@ -169,8 +229,11 @@ class Model(layer.Layer, metaclass=ModelMeta):
         return type(self).__name__
 
     def __call__(self, *input, **kwargs):
-        run = self.train_one_batch if self.training else self.forward
-        return run(*input, **kwargs)
+        if self.training:
+            return self.train_one_batch(*input, **kwargs)
+        if self.graph_mode and self.graph_inference:
+            return self._inference.run(self, input, kwargs)
+        return self.forward(*input, **kwargs)
 
     def set_optimizer(self, optimizer):
         self.optimizer = optimizer

@@ -378,3 +378,60 @@ def test_graph_profiling_output(dev, capsys):
     finally:
         dev.SetVerbosity(0)
     assert "Time Profiling" in capsys.readouterr().out
+
+
+def test_recorded_inference_matches_eager(dev):
+    """Evaluation through a recorded forward pass: per input signature one
+    recording; later inputs (other tensor objects, other values, another
+    batch size) give the eager results; a training step recorded on the same
+    device keeps working next to it."""
+    from singa_amd import layer, model, opt, tensor
+
+    class Net(model.Model):
+        def __init__(self):
+            super().__init__()
+            self.fc1 = layer.Linear(16)
+            self.act = layer.ReLU()
+            self.fc2 = layer.Linear(3)
+            self.loss = layer.SoftMaxCrossEntropy()
+
+        def forward(self, x):
+            return self.fc2(self.act(self.fc1(x)))
+
+        def train_one_batch(self, x, y):
+            out = self.forward(x)
+            loss = self.loss(out, y)
+            self.optimizer(loss)
+            return out, loss
+
+    rs = np.random.RandomState(0)
+    m = Net()
+    m.set_optimizer(opt.SGD(lr=0.05))
+    x8 = tensor.from_numpy(rs.randn(8, 5).astype(np.float32), dev)
+    y8 = tensor.from_numpy(rs.randint(0, 3, 8).astype(np.int32), dev)
+    m.compile([x8], is_train=True, use_graph=True, sequential=False)
+    m.graph_inference = True
+
+    def eager(xn):
+        m.graph_inference = False
+        try:
+            return tensor.to_numpy(m(tensor.from_numpy(xn, dev)))
+        finally:
+            m.graph_inference = True
+
+    for rnd in range(3):
+        m.train()
+        for _ in range(3):
+            _, loss = m(x8, y8)
+        m.eval()
+        for batch in (8, 8, 3, 8, 3):
+            xn = rs.randn(batch, 5).astype(np.float32)
+            got = tensor.to_numpy(m(tensor.from_numpy(xn, dev)))
+            np.testing.assert_allclose(got, eager(xn), rtol=1e-5, atol=1e-6)
+        assert len(m._inference.plans) == 2
+    first = float(tensor.to_numpy(loss)[0])
+    m.train()
+    for _ in range(20):
+        _, loss = m(x8, y8)
+    assert float(tensor.to_numpy(loss)[0]) < first
+    dev.ResetGraph()

@@ -88,6 +88,7 @@ def main():
         for graph in (False, True):
             m = tm.TextModel(model1, dtype=dt)
             m.compile(xs, is_train=False, use_graph=graph, sequential=True)
+            m.graph_inference = graph   # recorded forward pass -> hipGraph
             m.eval()
             t = timed(lambda: m(*xs), args.steps, 3)
             outs[fuse] = tensor.to_numpy(

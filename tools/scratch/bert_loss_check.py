@@ -1,0 +1,50 @@
+"""Loss trajectory of the BERT fine-tune step with and without the fused
+linear operator (same seed): the two must agree."""
+import sys, os
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "examples", "onnx"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import text_models as tm
+from singa_amd import device, opt, sonnx, tensor
+from singa_amd.onnx_proto import helper
+
+dev = device.create_cuda_gpu()
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+dt = {"fp32": None, "fp16": tensor.float16}[sys.argv[2] if len(sys.argv) > 2 else "fp32"]
+cfg = dict(seq=256, hidden=768, heads=12, layers=12, ffn=3072, vocab=30522)
+model, _ = tm.bert_encoder(batch=B, squad_head=False, **cfg)
+rs = np.random.RandomState(0)
+ids = rs.randint(0, 30522, (B, 256)).astype(np.int32)
+mask = np.ones((B, 256), np.int32)
+seg = np.zeros((B, 256), np.int32)
+y = rs.randint(0, 2, B).astype(np.int32)
+orig = sonnx._fuse_transformer_patterns
+
+def no_linear(graph):
+    nodes = orig(graph)
+    out = []
+    for n in nodes:
+        if n.op_type == "FusedLinear":
+            mid = n.output[0] + "_mm"
+            out.append(helper.make_node("MatMul", [n.input[0], n.input[1]], [mid], name=n.name + "_mm"))
+            out.append(helper.make_node("Add", [mid, n.input[2]], [n.output[0]], name=n.name + "_add"))
+        else:
+            out.append(n)
+    return out
+
+for label, fn in (("fused-linear", orig), ("matmul+add", no_linear)):
+    sonnx._fuse_transformer_patterns = fn
+    dev.SetRandSeed(3)
+    xs = [tensor.from_numpy(a, dev) for a in (ids, mask, seg)]
+    ty = tensor.from_numpy(y, dev)
+    m = tm.BertClassifier(model, 2, dtype=dt)
+    m.set_optimizer(opt.SGD(lr=1e-3, momentum=0.9))
+    m.compile(xs, is_train=True, use_graph=True, sequential=False)
+    m.train()
+    ls = []
+    for i in range(24):
+        _, loss = m(*xs, ty)
+        ls.append(float(tensor.to_numpy(loss.as_type(tensor.float32)).reshape(-1)[0]))
+    print(label, " ".join("%.4f" % v for v in ls), flush=True)
+    dev.ResetGraph()
+    del m

@@ -51,11 +51,11 @@ def main():
         x = tensor.from_numpy(np.ascontiguousarray(x_np), dev)
         eager, y0 = latency(model, x, dev, False, args.repeat)
         graph, y1 = latency(model, x, dev, True, args.repeat)
-        diff = float(np.abs(y0 - y1).max())
+        diff = float(np.abs(y0 - y1).max() / max(1.0, np.abs(y0).max()))
         print(json.dumps({"model": name, "nodes": len(model.graph.node),
                           "eager_ms": round(eager, 3),
                           "graph_ms": round(graph, 3),
-                          "max_abs_diff": diff}), flush=True)
+                          "max_rel_diff": diff, "out_scale": float(np.abs(y0).max())}), flush=True)
 
 
 if __name__ == "__main__":

@@ -84,6 +84,7 @@ def test_attention_operator_matches_numpy_and_unfused_chain(D):
     (1, 2, 40, 75, True),      # ragged tiles in both directions
     (2, 1, 130, 33, False),    # no mask, a single partial key tile
     (1, 12, 128, 128, True),
+    (2, 2, 96, 96, "causal"),  # a mask that depends on the query
 ])
 def test_attention_kernels_match_host(dt, B, H, Sq, Sk, masked):
     """Forward and backward of the HIP kernels on strided (B, S, H, D) views
@@ -99,7 +100,10 @@ def test_attention_kernels_match_host(dt, B, H, Sq, Sk, masked):
     v = torch.randn(B, Sk, H, D, generator=g).to(dt)
     q[0, Sq // 2] *= 4.0          # a row whose maximum jumps between tiles
     mask = None
-    if masked:
+    if masked == "causal":
+        mask = torch.triu(torch.full((Sq, Sk), -10000.0), 1)[None, None]
+        mask = mask.to(dt)
+    elif masked:
         mask = torch.zeros(B, 1, 1, Sk)
         mask[0, :, :, : Sk - 3] = -10000.0
         mask[-1, :, :, 5::7] = -10000.0

@@ -1,59 +1,54 @@
--- In-database entry points for the model-selection engine, as PL/Python
--- functions (the reference ships a Rust pgrx extension that embeds Python via
--- pyo3: internal/pg_extension/src/lib.rs; the UDF names and JSON-in / JSON-out
--- convention are kept).  Requires the plpython3u language and the repository's
--- examples/model_selection directory on the server's PYTHONPATH.
+-- In-database entry points of the model-selection application, as PL/Python
+-- functions over examples/model_selection/trails/pg_interface.py.  The
+-- reference ships a Rust pgrx extension that embeds Python through pyo3 and
+-- forwards JSON text to pg_interface.py (internal/pg_extension/src/lib.rs:
+-- 34-150); function names, argument lists and the JSON-in / JSON-out
+-- convention are the same here, the host language of the thin forwarding
+-- layer is PL/Python instead of Rust.  Requires the plpython3u language and
+-- the directory examples/model_selection on the server's PYTHONPATH.  The
+-- Python functions are covered by tests/test_model_selection.py; this file
+-- itself was not run (no PostgreSQL server in the build environment).
 --
 --   CREATE EXTENSION plpython3u;
 --   \i model_selection--1.0.sql
---   SELECT model_selection('frappe', '{"n_candidates": 16, "top_k": 4}');
+--   SELECT model_selection(
+--       (SELECT json_agg(t)::text FROM (SELECT * FROM frappe_train LIMIT 2000) t),
+--       '60', '{"num_layers": 3}');
 
-CREATE OR REPLACE FUNCTION _ms_load(tbl text, label_col text DEFAULT 'label')
+CREATE OR REPLACE FUNCTION profiling_filtering_phase(mini_batch text, config_file text)
 RETURNS text AS $$
-    import json
-    rows = plpy.execute("SELECT * FROM %s" % plpy.quote_ident(tbl))
-    cols = [c for c in rows.colnames() if c != label_col]
-    x = [[float(r[c]) for c in cols] for r in rows]
-    y = [int(r[label_col]) for r in rows]
-    return json.dumps({"x": x, "y": y})
+    from trails import pg_interface
+    return pg_interface.profiling_filtering_phase(mini_batch, config_file)
 $$ LANGUAGE plpython3u;
 
-CREATE OR REPLACE FUNCTION filtering_phase(tbl text, config text)
+CREATE OR REPLACE FUNCTION profiling_refinement_phase(mini_batch text, config_file text)
 RETURNS text AS $$
-    import json, numpy as np, engine
-    d = json.loads(plpy.execute("SELECT _ms_load(%s) AS j" % plpy.quote_literal(tbl))[0]["j"])
-    cfg = json.loads(config or "{}")
-    x = np.asarray(d["x"], np.float32); y = np.asarray(d["y"], np.int32)
-    ranked = engine.filtering_phase(engine.MlpSpace(), (x, y, int(y.max()) + 1),
-                                    cfg.get("n_candidates", 16),
-                                    cfg.get("sampler", "evolution"),
-                                    cfg.get("score", "synflow"))
-    return json.dumps([[list(a), s] for a, s in ranked])
+    from trails import pg_interface
+    return pg_interface.profiling_refinement_phase(mini_batch, config_file)
 $$ LANGUAGE plpython3u;
 
-CREATE OR REPLACE FUNCTION refinement_phase(tbl text, candidates text, config text)
+CREATE OR REPLACE FUNCTION coordinator(time_score text, time_train text, time_budget text,
+                                       only_phase1 boolean, config_file text)
 RETURNS text AS $$
-    import json, numpy as np, engine
-    d = json.loads(plpy.execute("SELECT _ms_load(%s) AS j" % plpy.quote_literal(tbl))[0]["j"])
-    x = np.asarray(d["x"], np.float32); y = np.asarray(d["y"], np.int32)
-    cut = int(0.75 * len(x))
-    archs = [tuple(a) for a in json.loads(candidates)]
-    arch, acc, _ = engine.refinement_phase(archs, (x[:cut], y[:cut], int(y.max()) + 1),
-                                           (x[cut:], y[cut:]))
-    return json.dumps({"best_arch": list(arch), "val_acc": acc})
+    from trails import pg_interface
+    return pg_interface.coordinator(time_score, time_train, time_budget,
+                                    only_phase1, config_file)
 $$ LANGUAGE plpython3u;
 
-CREATE OR REPLACE FUNCTION model_selection(tbl text, config text)
+CREATE OR REPLACE FUNCTION filtering_phase(mini_batch text, n integer, k integer, config_file text)
 RETURNS text AS $$
-    import json, numpy as np, engine
-    d = json.loads(plpy.execute("SELECT _ms_load(%s) AS j" % plpy.quote_literal(tbl))[0]["j"])
-    cfg = json.loads(config or "{}")
-    x = np.asarray(d["x"], np.float32); y = np.asarray(d["y"], np.int32)
-    cut = int(0.75 * len(x))
-    out = engine.model_selection((x[:cut], y[:cut], int(y.max()) + 1), (x[cut:], y[cut:]),
-                                 n_candidates=cfg.get("n_candidates", 16),
-                                 top_k=cfg.get("top_k", 4),
-                                 sampler=cfg.get("sampler", "evolution"),
-                                 score=cfg.get("score", "synflow"))
-    return json.dumps(out, default=list)
+    from trails import pg_interface
+    return pg_interface.filtering_phase(mini_batch, n, k, config_file)
+$$ LANGUAGE plpython3u;
+
+CREATE OR REPLACE FUNCTION refinement_phase(config_file text)
+RETURNS text AS $$
+    from trails import pg_interface
+    return pg_interface.refinement_phase(config_file)
+$$ LANGUAGE plpython3u;
+
+CREATE OR REPLACE FUNCTION model_selection(mini_batch text, time_budget text, config_file text)
+RETURNS text AS $$
+    from trails import pg_interface
+    return pg_interface.model_selection(mini_batch, time_budget, config_file)
 $$ LANGUAGE plpython3u;

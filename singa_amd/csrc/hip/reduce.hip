@@ -121,14 +121,30 @@ __global__ void reduce_cols_vec_kernel(const T *__restrict__ x,
   float acc[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
-  if (c < cols)
-    for (int64_t r = r0 + ry; r < r1; r += 4) {
+  if (c < cols) {
+    // four rows in flight per thread
+    int64_t r = r0 + ry;
+    for (; r + 12 < r1; r += 16) {
+      uint4 w[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        w[u] = *reinterpret_cast<const uint4 *>(x + (r + 4 * u) * cols + c);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        T e[VEC];
+        __builtin_memcpy(e, &w[u], 16);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += to_f<T>(e[k]);
+      }
+    }
+    for (; r < r1; r += 4) {
       const uint4 w = *reinterpret_cast<const uint4 *>(x + r * cols + c);
       T e[VEC];
       __builtin_memcpy(e, &w, 16);
 #pragma unroll
       for (int k = 0; k < VEC; ++k) acc[k] += to_f<T>(e[k]);
     }
+  }
 #pragma unroll
   for (int k = 0; k < VEC; ++k) part[ry][cx + 64 * k] = acc[k];
   __syncthreads();
@@ -246,9 +262,11 @@ int sa_reduce_cols(int dtype, const void *x, void *out, int64_t rows,
     // split the rows so that the launch has a few thousand blocks at most
     const int64_t per_block = vec ? 64 * VEC : 64;
     const int64_t col_blocks = (cols + per_block - 1) / per_block;
+    // enough workgroups to occupy the chip: about 1024, each with at least
+    // 32 rows (a few atomic adds per output and workgroup)
     int64_t splits = 1;
-    if (rows > 256)
-      splits = i64min((rows + 255) / 256, i64max(1, 1024 / col_blocks));
+    if (rows > 64)
+      splits = i64min((rows + 31) / 32, i64max(1, 1024 / col_blocks));
     const int64_t rpb = (rows + splits - 1) / splits;
     splits = (rows + rpb - 1) / rpb;
     if (splits > 1) zero_async(out, cols * sizeof(float), s);

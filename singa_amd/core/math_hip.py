@@ -35,6 +35,9 @@ _CODE = {torch.float32: 0, torch.float16: 1, torch.int32: 2,
 
 
 _FLOATS = (torch.float32, torch.float16, torch.bfloat16)
+# workgroups a split reduction of a mid-sized product aims at (256 CUs, two
+# resident 128 x 128 workgroups each); SINGA_GEMM_SPLIT_TARGET overrides
+_SPLIT_TARGET = int(os.environ.get("SINGA_GEMM_SPLIT_TARGET", "512"))
 
 
 def _code(t):
@@ -411,7 +414,12 @@ class HipMath(object):
         if tiles64 <= 64 and K >= 512:
             most, depth = min(32, 256 // tiles64), 64
         elif tiles128 <= 96 and K >= 1024 and M >= 96 and N >= 96:
-            most, depth = 256 // tiles128, 512
+            most, depth = _SPLIT_TARGET // tiles128, 512
+        elif tiles128 < 384 and K >= 2048 and M >= 96 and N >= 96:
+            # a weight gradient over many tokens: a few hundred tiles with a
+            # long reduction each; aim at two workgroups per CU
+            most = (_SPLIT_TARGET + tiles128 // 2) // tiles128
+            depth = 1024
         else:
             return 1
         best = 1

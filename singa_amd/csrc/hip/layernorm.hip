@@ -16,6 +16,8 @@
 // backward: dx per row with two row reductions; dgamma / dbeta are column
 // sums over all rows, done by a second kernel that strides rows with a
 // [8 row-lanes][32 columns] workgroup and reduces through LDS.
+#include <initializer_list>
+
 #include "common.cuh"
 #include "kernels.h"
 
@@ -157,6 +159,144 @@ __global__ void layernorm_bwd_param_kernel(const T *__restrict__ dy,
   }
 }
 
+// ---- one wave per row ------------------------------------------------------
+// Rows of up to 2048 elements (a multiple of 4): the 64 lanes of a wave keep the
+// row in registers as NV groups of four consecutive elements (8- or 16-byte
+// accesses), the two row statistics are wave reductions -- no LDS, no
+// barrier, four rows per 256-thread workgroup.
+template <typename T>
+__device__ __forceinline__ void ld4(const T *p, float *f) {
+  T e[4];
+  if (sizeof(T) == 4) {
+    const float4 w = *reinterpret_cast<const float4 *>(p);
+    __builtin_memcpy(e, &w, 16);
+  } else {
+    const uint2 w = *reinterpret_cast<const uint2 *>(p);
+    __builtin_memcpy(e, &w, 8);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) f[k] = to_f<T>(e[k]);
+}
+template <typename T>
+__device__ __forceinline__ void st4(T *p, const float *f) {
+  T e[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) e[k] = from_f<T>(f[k]);
+  if (sizeof(T) == 4) {
+    float4 w;
+    __builtin_memcpy(&w, e, 16);
+    *reinterpret_cast<float4 *>(p) = w;
+  } else {
+    uint2 w;
+    __builtin_memcpy(&w, e, 8);
+    *reinterpret_cast<uint2 *>(p) = w;
+  }
+}
+
+template <typename T, int NV>
+__global__ void __launch_bounds__(256)
+layernorm_fwd_wave_kernel(const T *__restrict__ x, const T *__restrict__ gamma,
+                          const T *__restrict__ beta, T *__restrict__ y,
+                          float *__restrict__ mean_out,
+                          float *__restrict__ rstd_out, int64_t rows, int D,
+                          float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const T *xr = x + r * D;
+  float v[NV][4];
+  float sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = (lane + 64 * k) * 4;
+    if (i < D) {
+      ld4<T>(xr + i, v[k]);
+    } else {
+      v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.f;
+    }
+    sum += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+  }
+  const float mean = wave_sum(sum) / (float)D;
+  float sq = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if ((lane + 64 * k) * 4 < D) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = v[k][j] - mean;
+        sq += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(sq) / (float)D + eps);
+  if (lane == 0) {
+    mean_out[r] = mean;
+    rstd_out[r] = rstd;
+  }
+  T *yr = y + r * D;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = (lane + 64 * k) * 4;
+    if (i < D) {
+      float g[4] = {1.f, 1.f, 1.f, 1.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+      if (gamma) ld4<T>(gamma + i, g);
+      if (beta) ld4<T>(beta + i, b);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[k][j] - mean) * rstd * g[j] + b[j];
+      st4<T>(yr + i, o);
+    }
+  }
+}
+
+template <typename T, int NV>
+__global__ void __launch_bounds__(256)
+layernorm_bwd_dx_wave_kernel(const T *__restrict__ dy, const T *__restrict__ x,
+                             const T *__restrict__ gamma,
+                             const float *__restrict__ mean,
+                             const float *__restrict__ rstd,
+                             T *__restrict__ dx, int64_t rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const T *xr = x + r * D, *dr = dy + r * D;
+  const float m = mean[r], rs = rstd[r];
+  float gd[NV][4], xh[NV][4];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = (lane + 64 * k) * 4;
+    if (i < D) {
+      float g[4] = {1.f, 1.f, 1.f, 1.f}, d[4], xv[4];
+      if (gamma) ld4<T>(gamma + i, g);
+      ld4<T>(dr + i, d);
+      ld4<T>(xr + i, xv);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        gd[k][j] = g[j] * d[j];
+        xh[k][j] = (xv[j] - m) * rs;
+        s1 += gd[k][j];
+        s2 += gd[k][j] * xh[k][j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) gd[k][j] = xh[k][j] = 0.f;
+    }
+  }
+  s1 = wave_sum(s1) / (float)D;
+  s2 = wave_sum(s2) / (float)D;
+  T *or_ = dx + r * D;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = (lane + 64 * k) * 4;
+    if (i < D) {
+      float o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = rs * (gd[k][j] - s1 - xh[k][j] * s2);
+      st4<T>(or_ + i, o);
+    }
+  }
+}
+
 __device__ __forceinline__ float gelu_f(float v) {
   return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
 }
@@ -185,9 +325,56 @@ __global__ void gelu_bwd_kernel(const T *__restrict__ dy,
     dx[i] = from_f<T>(to_f<T>(dy[i]) * gelu_grad_f(to_f<T>(x[i])));
 }
 
+// 16 bytes per thread and step
+template <typename T, bool BWD>
+__global__ void gelu_vec_kernel(const T *__restrict__ dy,
+                                const T *__restrict__ x, T *__restrict__ out,
+                                int64_t nvec) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += step) {
+    const uint4 xw = reinterpret_cast<const uint4 *>(x)[i];
+    T xe[VEC], de[VEC], oe[VEC];
+    __builtin_memcpy(xe, &xw, 16);
+    if (BWD) {
+      const uint4 dw = reinterpret_cast<const uint4 *>(dy)[i];
+      __builtin_memcpy(de, &dw, 16);
+    }
+#pragma unroll
+    for (int k = 0; k < VEC; ++k) {
+      const float v = to_f<T>(xe[k]);
+      oe[k] = from_f<T>(BWD ? to_f<T>(de[k]) * gelu_grad_f(v) : gelu_f(v));
+    }
+    uint4 ow;
+    __builtin_memcpy(&ow, oe, 16);
+    reinterpret_cast<uint4 *>(out)[i] = ow;
+  }
+}
+
 }  // namespace sa
 
 using namespace sa;
+
+// rows a wave can hold: a multiple of 4 elements, at most 8 groups per lane,
+// every operand 16-byte aligned (rows then start on 8 / 16-byte boundaries)
+static inline bool ln_wave_ok(int D, std::initializer_list<const void *> ps) {
+  if (D % 4 != 0 || D > 2048) return false;
+  for (const void *p : ps)
+    if (p != nullptr && (reinterpret_cast<uintptr_t>(p) & 15) != 0) return false;
+  return true;
+}
+
+#define SA_LN_NV(D, NV, ...)                         \
+  do {                                               \
+    const int groups_ = ((D) / 4 + 63) / 64;         \
+    if (groups_ <= 1) { constexpr int NV = 1; __VA_ARGS__; }       \
+    else if (groups_ == 2) { constexpr int NV = 2; __VA_ARGS__; }  \
+    else if (groups_ == 3) { constexpr int NV = 3; __VA_ARGS__; }  \
+    else if (groups_ == 4) { constexpr int NV = 4; __VA_ARGS__; }  \
+    else if (groups_ <= 6) { constexpr int NV = 6; __VA_ARGS__; }  \
+    else { constexpr int NV = 8; __VA_ARGS__; }      \
+  } while (0)
 
 static inline int ln_block(int D) {
   return D >= 2048 ? 512 : (D >= 512 ? 256 : (D > 64 ? 128 : 64));
@@ -198,6 +385,16 @@ int sa_layernorm_fwd(int dtype, const void *x, const void *gamma,
                      int64_t rows, int D, float eps, hipStream_t s) {
   if (rows <= 0 || D <= 0) return 0;
   if (rows >= ((int64_t)1 << 31)) return -2;
+  if (ln_wave_ok(D, {x, gamma, beta, y})) {
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    SA_DISPATCH_FLOAT(dtype, T, {
+      SA_LN_NV(D, NV, hipLaunchKernelGGL(
+          (layernorm_fwd_wave_kernel<T, NV>), grid, dim3(256), 0, s,
+          (const T *)x, (const T *)gamma, (const T *)beta, (T *)y, mean, rstd,
+          rows, D, eps));
+    });
+    return 0;
+  }
   SA_DISPATCH_FLOAT(dtype, T, {
     hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3((unsigned)rows),
                        dim3(ln_block(D)), 0, s, (const T *)x, (const T *)gamma,
@@ -214,10 +411,18 @@ int sa_layernorm_bwd(int dtype, const void *dy, const void *x,
   if (rows <= 0 || D <= 0) return 0;
   if (rows >= ((int64_t)1 << 31)) return -2;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return -5;
+  const bool wave = ln_wave_ok(D, {dy, x, gamma, dx});
   SA_DISPATCH_FLOAT(dtype, T, {
-    hipLaunchKernelGGL((layernorm_bwd_dx_kernel<T>), dim3((unsigned)rows),
-                       dim3(ln_block(D)), 0, s, (const T *)dy, (const T *)x,
-                       (const T *)gamma, mean, rstd, (T *)dx, rows, D);
+    if (wave) {
+      SA_LN_NV(D, NV, hipLaunchKernelGGL(
+          (layernorm_bwd_dx_wave_kernel<T, NV>),
+          dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const T *)dy,
+          (const T *)x, (const T *)gamma, mean, rstd, (T *)dx, rows, D));
+    } else {
+      hipLaunchKernelGGL((layernorm_bwd_dx_kernel<T>), dim3((unsigned)rows),
+                         dim3(ln_block(D)), 0, s, (const T *)dy, (const T *)x,
+                         (const T *)gamma, mean, rstd, (T *)dx, rows, D);
+    }
     if (dgamma) {
       zero_async(dgamma, (size_t)D * sizeof(float), s);
       zero_async(dbeta, (size_t)D * sizeof(float), s);
@@ -232,11 +437,26 @@ int sa_layernorm_bwd(int dtype, const void *dy, const void *x,
   return 0;
 }
 
+static inline bool gelu_vec_ok(int64_t n, size_t elem,
+                               std::initializer_list<const void *> ps) {
+  if (n % (int64_t)(16 / elem) != 0) return false;
+  for (const void *p : ps)
+    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) return false;
+  return true;
+}
+
 int sa_gelu_fwd(int dtype, const void *x, void *y, int64_t n, hipStream_t s) {
   if (n <= 0) return 0;
   SA_DISPATCH_FLOAT(dtype, T, {
-    hipLaunchKernelGGL((gelu_fwd_kernel<T>), dim3(grid_for(n, 256, 4)),
-                       dim3(256), 0, s, (const T *)x, (T *)y, n);
+    if (gelu_vec_ok(n, sizeof(T), {x, y})) {
+      const int64_t nvec = n / (16 / (int64_t)sizeof(T));
+      hipLaunchKernelGGL((gelu_vec_kernel<T, false>),
+                         dim3(grid_for(nvec, 256, 2)), dim3(256), 0, s,
+                         (const T *)nullptr, (const T *)x, (T *)y, nvec);
+    } else {
+      hipLaunchKernelGGL((gelu_fwd_kernel<T>), dim3(grid_for(n, 256, 4)),
+                         dim3(256), 0, s, (const T *)x, (T *)y, n);
+    }
   });
   return 0;
 }
@@ -245,9 +465,16 @@ int sa_gelu_bwd(int dtype, const void *dy, const void *x, void *dx, int64_t n,
                 hipStream_t s) {
   if (n <= 0) return 0;
   SA_DISPATCH_FLOAT(dtype, T, {
-    hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3(grid_for(n, 256, 4)),
-                       dim3(256), 0, s, (const T *)dy, (const T *)x, (T *)dx,
-                       n);
+    if (gelu_vec_ok(n, sizeof(T), {dy, x, dx})) {
+      const int64_t nvec = n / (16 / (int64_t)sizeof(T));
+      hipLaunchKernelGGL((gelu_vec_kernel<T, true>),
+                         dim3(grid_for(nvec, 256, 2)), dim3(256), 0, s,
+                         (const T *)dy, (const T *)x, (T *)dx, nvec);
+    } else {
+      hipLaunchKernelGGL((gelu_bwd_kernel<T>), dim3(grid_for(n, 256, 4)),
+                         dim3(256), 0, s, (const T *)dy, (const T *)x, (T *)dx,
+                         n);
+    }
   });
   return 0;
 }

@@ -106,38 +106,40 @@ __global__ void reduce_cols_kernel(const T *__restrict__ x,
   }
 }
 
-// the same with one 16-byte load per thread and row: a block covers
-// 64 * VEC columns, rows r0 + ry, r0 + ry + 4, ...
+// the same with 16-byte loads: a workgroup is 16 column lanes (16 * VEC
+// columns, 256 contiguous bytes of a row) x 16 row lanes, eight rows in flight
+// per thread; the row lanes are combined through LDS, so a workgroup issues
+// one atomic add per column
 template <typename T>
-__global__ void reduce_cols_vec_kernel(const T *__restrict__ x,
-                                       float *__restrict__ out, int64_t rows,
-                                       int64_t cols, int64_t rows_per_block) {
+__global__ void __launch_bounds__(256)
+reduce_cols_vec_kernel(const T *__restrict__ x, float *__restrict__ out,
+                       int64_t rows, int64_t cols, int64_t rows_per_block) {
   constexpr int VEC = 16 / (int)sizeof(T);
-  __shared__ float part[4][64 * VEC];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int64_t c = ((int64_t)blockIdx.x * 64 + cx) * VEC;
+  constexpr int W = 16 * VEC;  // columns of a workgroup
+  __shared__ float part[16][W + 1];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int64_t c = ((int64_t)blockIdx.x * 16 + cx) * VEC;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = min(rows, r0 + rows_per_block);
   float acc[VEC];
 #pragma unroll
   for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
   if (c < cols) {
-    // four rows in flight per thread
     int64_t r = r0 + ry;
-    for (; r + 12 < r1; r += 16) {
-      uint4 w[4];
+    for (; r + 16 * 7 < r1; r += 16 * 8) {
+      uint4 w[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        w[u] = *reinterpret_cast<const uint4 *>(x + (r + 4 * u) * cols + c);
+      for (int u = 0; u < 8; ++u)
+        w[u] = *reinterpret_cast<const uint4 *>(x + (r + 16 * u) * cols + c);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < 8; ++u) {
         T e[VEC];
         __builtin_memcpy(e, &w[u], 16);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) acc[k] += to_f<T>(e[k]);
       }
     }
-    for (; r < r1; r += 4) {
+    for (; r < r1; r += 16) {
       const uint4 w = *reinterpret_cast<const uint4 *>(x + r * cols + c);
       T e[VEC];
       __builtin_memcpy(e, &w, 16);
@@ -146,17 +148,18 @@ __global__ void reduce_cols_vec_kernel(const T *__restrict__ x,
     }
   }
 #pragma unroll
-  for (int k = 0; k < VEC; ++k) part[ry][cx + 64 * k] = acc[k];
+  for (int k = 0; k < VEC; ++k) part[ry][cx * VEC + k] = acc[k];
   __syncthreads();
-  if (ry == 0 && c < cols) {
+  if (threadIdx.x < W) {
+    const int64_t col = (int64_t)blockIdx.x * W + threadIdx.x;
+    if (col < cols) {
+      float v = 0.f;
 #pragma unroll
-    for (int k = 0; k < VEC; ++k) {
-      const float v = part[0][cx + 64 * k] + part[1][cx + 64 * k] +
-                      part[2][cx + 64 * k] + part[3][cx + 64 * k];
+      for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
       if (gridDim.y == 1)
-        out[c + k] = v;
+        out[col] = v;
       else
-        atomicAdd(out + c + k, v);
+        atomicAdd(out + col, v);
     }
   }
 }
@@ -254,31 +257,38 @@ int sa_reduce_rows(int op, int dtype, const void *x, void *out, int64_t rows,
 int sa_reduce_cols(int dtype, const void *x, void *out, int64_t rows,
                    int64_t cols, hipStream_t s) {
   if (cols <= 0) return 0;
-  int rc = 0;
   SA_DISPATCH_FLOAT(dtype, T, {
     constexpr int VEC = 16 / (int)sizeof(T);
     const bool vec = cols % VEC == 0 &&
                      (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-    // split the rows so that the launch has a few thousand blocks at most
-    const int64_t per_block = vec ? 64 * VEC : 64;
-    const int64_t col_blocks = (cols + per_block - 1) / per_block;
-    // enough workgroups to occupy the chip: about 1024, each with at least
-    // 32 rows (a few atomic adds per output and workgroup)
-    int64_t splits = 1;
-    if (rows > 64)
-      splits = i64min((rows + 31) / 32, i64max(1, 1024 / col_blocks));
-    const int64_t rpb = (rows + splits - 1) / splits;
-    splits = (rows + rpb - 1) / rpb;
-    if (splits > 1) zero_async(out, cols * sizeof(float), s);
-    const dim3 grid((unsigned)col_blocks, (unsigned)splits);
-    if (vec)
-      hipLaunchKernelGGL((reduce_cols_vec_kernel<T>), grid, dim3(256), 0, s,
-                         (const T *)x, (float *)out, rows, cols, rpb);
-    else
-      hipLaunchKernelGGL((reduce_cols_kernel<T>), grid, dim3(256), 0, s,
-                         (const T *)x, (float *)out, rows, cols, rpb);
+    if (vec) {
+      // 128 rows per workgroup (eight per thread, all in flight); fewer row
+      // slices when the columns alone fill the chip
+      const int64_t col_blocks = (cols + 16 * VEC - 1) / (16 * VEC);
+      int64_t splits = i64min((rows + 127) / 128,
+                              i64max(1, 2048 / col_blocks));
+      const int64_t rpb = (rows + splits - 1) / splits;
+      splits = (rows + rpb - 1) / rpb;
+      if (splits > 1) zero_async(out, cols * sizeof(float), s);
+      hipLaunchKernelGGL((reduce_cols_vec_kernel<T>),
+                         dim3((unsigned)col_blocks, (unsigned)splits),
+                         dim3(256), 0, s, (const T *)x, (float *)out, rows,
+                         cols, rpb);
+    } else {
+      const int64_t col_blocks = (cols + 63) / 64;
+      int64_t splits = 1;
+      if (rows > 256)
+        splits = i64min((rows + 255) / 256, i64max(1, 1024 / col_blocks));
+      const int64_t rpb = (rows + splits - 1) / splits;
+      splits = (rows + rpb - 1) / rpb;
+      if (splits > 1) zero_async(out, cols * sizeof(float), s);
+      hipLaunchKernelGGL((reduce_cols_kernel<T>),
+                         dim3((unsigned)col_blocks, (unsigned)splits),
+                         dim3(256), 0, s, (const T *)x, (float *)out, rows,
+                         cols, rpb);
+    }
   });
-  return rc;
+  return 0;
 }
 
 int sa_reduce_all(int op, int dtype, const void *x, void *out, int64_t n,

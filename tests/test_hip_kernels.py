@@ -1151,3 +1151,58 @@ def test_batchnorm_forward_from_producer_sums(maths, dt, N, C, HW, act):
         np.testing.assert_allclose(a, b, rtol=2e-3 if dt != torch.float32
                                    else 1e-4, atol=2e-3 if dt != torch.float32
                                    else 1e-5)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,D", [(9, 768), (5, 100), (3, 2048), (7, 1026),
+                                    (4, 516), (2, 4096), (130, 64)])
+def test_layernorm_and_gelu_kernels_all_types(maths, dt, rows, D):
+    """Layer normalisation (rows held by one wave, rows held by a workgroup,
+    rows re-read) and GELU (vector and element kernels) in every float type
+    against float64 PyTorch on the same rounded inputs."""
+    hm, cm, dev = maths
+    d = dev.torch_device
+    gen = torch.Generator().manual_seed(rows * 131 + D)
+    x = (torch.randn(rows, D, generator=gen) * 2 + 0.3).to(dt)
+    gam = (torch.rand(D, generator=gen) + 0.5).to(dt)
+    bet = torch.randn(D, generator=gen).to(dt)
+    dy = torch.randn(rows, D, generator=gen).to(dt)
+    y = torch.empty(rows, D, dtype=dt, device=d)
+    mean = torch.empty(rows, device=d)
+    rstd = torch.empty(rows, device=d)
+    hm.layernorm_fwd(x.to(d), gam.to(d), bet.to(d), y, mean, rstd, 1e-5)
+    dx = torch.empty(rows, D, dtype=dt, device=d)
+    dg = torch.empty(D, dtype=dt, device=d)
+    db = torch.empty(D, dtype=dt, device=d)
+    hm.layernorm_bwd(dy.to(d), x.to(d), gam.to(d), mean, rstd, dx, dg, db)
+    x64 = x.double().requires_grad_(True)
+    g64 = gam.double().requires_grad_(True)
+    b64 = bet.double().requires_grad_(True)
+    y64 = torch.nn.functional.layer_norm(x64, (D,), g64, b64, 1e-5)
+    (y64 * dy.double()).sum().backward()
+    eps = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dt]
+
+    def close(got, want, name, extra=1.0):
+        want = want.detach().numpy()
+        np.testing.assert_allclose(
+            got.double().cpu().numpy(), want, rtol=eps * 4,
+            atol=eps * extra * max(1.0, float(np.abs(want).max())),
+            err_msg=name)
+    close(y, y64, "y")
+    close(mean, x.double().mean(1), "mean")
+    close(dx, x64.grad, "dx", 4.0)
+    close(dg, g64.grad, "dgamma", 4.0)
+    close(db, b64.grad, "dbeta", 4.0)
+    # GELU on the same data; an odd length takes the element kernel
+    for n in (rows * D, rows * D - 3):
+        xv = x.reshape(-1)[:n].contiguous()
+        dv = dy.reshape(-1)[:n].contiguous()
+        out = torch.empty(n, dtype=dt, device=d)
+        hm.gelu_fwd(xv.to(d), out)
+        xg = xv.double().requires_grad_(True)
+        ref = torch.nn.functional.gelu(xg)
+        close(out, ref, "gelu")
+        gx = torch.empty(n, dtype=dt, device=d)
+        hm.gelu_bwd(dv.to(d), xv.to(d), gx)
+        (ref * dv.double()).sum().backward()
+        close(gx, xg.grad, "gelu grad", 2.0)

@@ -96,18 +96,25 @@ _CONV_S2_GATHER = os.environ.get("SINGA_CONV_S2_GATHER", "1") != "0"
 _CONV_WGRAD_GEMM = os.environ.get("SINGA_CONV_WGRAD_GEMM", "1") != "0"
 _CONV3X3_GEMM_MIN_HW = int(os.environ.get("SINGA_CONV3X3_GEMM_MIN_HW", "2000"))
 
+def _raw_stream(index):
+    return torch._C._cuda_getCurrentRawStream(index)
+
+
 class HipMath(object):
     name = "hip"
 
     def __init__(self, dev):
         self.dev = dev
+        self._dev_index = dev.torch_device.index or 0
         self.k = dev.kernels
         HipMath._kernel_file = getattr(self.k, "__file__", "") or ""
         self.conv_prof = None
 
     # ---- plumbing -----------------------------------------------------------
     def _s(self):
-        return torch.cuda.current_stream(self.dev.torch_device).cuda_stream
+        # raw handle of the current stream of this device (follows stream
+        # contexts and graph capture) without building a Stream object
+        return _raw_stream(self._dev_index)
 
     def _tmp(self, n, dtype=torch.float32):
         return torch.empty(n, dtype=dtype, device=self.dev.torch_device)

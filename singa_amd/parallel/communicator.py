@@ -73,6 +73,11 @@ _CAPTURE = os.environ.get("SINGA_DIST_CAPTURE", "1") != "0"
 # SINGA_RCCL_DIRECT=0 routes device collectives through torch.distributed's
 # work objects instead of calling RCCL on the communicator's stream directly
 _DIRECT = os.environ.get("SINGA_RCCL_DIRECT", "1") != "0"
+# SINGA_ALLREDUCE_TWO_PHASE=<elements>: buckets of at least that many elements
+# are summed as reduce-scatter + all-gather instead of one all-reduce (0 = off,
+# the default: which of the two is faster on a given node is a measurement,
+# tools/bench_allreduce.py prints both)
+_TWO_PHASE = int(os.environ.get("SINGA_ALLREDUCE_TWO_PHASE", "0"))
 
 
 class _Rccl(object):
@@ -103,6 +108,8 @@ class _Rccl(object):
         self.lib.ncclAllReduce.restype = ci
         self.lib.ncclAllGather.argtypes = [vp, vp, sz, ci, vp, vp]
         self.lib.ncclAllGather.restype = ci
+        self.lib.ncclReduceScatter.argtypes = [vp, vp, sz, ci, ci, vp, vp]
+        self.lib.ncclReduceScatter.restype = ci
         self.lib.ncclGetErrorString.argtypes = [ci]
         self.lib.ncclGetErrorString.restype = ctypes.c_char_p
         group = dist.distributed_c10d._get_default_group()
@@ -132,6 +139,24 @@ class _Rccl(object):
         self._check(self.lib.ncclAllGather(
             flat.data_ptr(), out.data_ptr(), flat.numel(),
             self._DTYPES[flat.dtype], self.comm, stream), "ncclAllGather")
+
+    def reduce_scatter(self, out, flat):
+        """out (n / world elements) = this rank's slice of the sum of every
+        rank's ``flat`` (n elements)."""
+        stream = torch.cuda.current_stream(flat.device).cuda_stream
+        self._check(self.lib.ncclReduceScatter(
+            flat.data_ptr(), out.data_ptr(), out.numel(),
+            self._DTYPES[flat.dtype], self._SUM, self.comm, stream),
+            "ncclReduceScatter")
+
+    def all_reduce_two_phase(self, flat, world, rank):
+        """Sum over ranks as reduce-scatter + all-gather, in place; ``flat``
+        must hold a multiple of ``world`` elements.  On a fully connected
+        xGMI node both phases send every slice over its own link."""
+        n = flat.numel() // world
+        mine = flat[rank * n:(rank + 1) * n]
+        self.reduce_scatter(mine, flat)
+        self.all_gather(flat, mine)
 
 
 def _env_int(names, default):
@@ -287,7 +312,12 @@ class Communicator(object):
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             flat.copy_(host)
         elif self._direct(flat):
-            self._rccl.all_reduce(flat)
+            if _TWO_PHASE and flat.numel() >= _TWO_PHASE and \
+                    flat.numel() % self.world_size == 0:
+                self._rccl.all_reduce_two_phase(flat, self.world_size,
+                                                self.global_rank)
+            else:
+                self._rccl.all_reduce(flat)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if _DEBUG:

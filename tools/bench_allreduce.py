@@ -1,0 +1,97 @@
+"""All-reduce bandwidth / latency over message sizes on the ranks of one node.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
+        --master-addr 127.0.0.1 --master-port 29611 tools/bench_allreduce.py
+    SINGA_DIST_FORCE=1 python tools/bench_allreduce.py      # one rank: the
+                                                            # launch floor
+
+For every size three ways of summing a float32 buffer over the ranks are
+timed: ``torch.distributed.all_reduce`` (work object, process-group stream),
+the direct RCCL call on the caller's stream that the communicator uses, and
+reduce-scatter + all-gather on the same communicator; the direct call is also
+timed as a captured hipGraph replay (the way a training step issues it).
+Reported: microseconds per call, algorithm bandwidth (bytes / time) and bus
+bandwidth (algorithm bandwidth x 2 (N - 1) / N, the per-link load of a ring).
+xGMI gives every GPU 7 links of about 153 GB/s peer to peer."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from singa_amd import device  # noqa: E402
+from singa_amd.parallel.communicator import Communicator  # noqa: E402
+
+
+def timed(fn, iters, dev):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize(dev)
+    if dist.is_initialized():
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize(dev)
+    return (time.perf_counter() - t0) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--min-log2", type=int, default=12)
+    ap.add_argument("--max-log2", type=int, default=27)
+    ap.add_argument("--iters", type=int, default=20)
+    args = ap.parse_args()
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dev = device.create_cuda_gpu_on(local)
+    torch.cuda.set_device(local)
+    comm = Communicator(1 << 22)       # rendezvous from the environment
+    td = dev.torch_device
+    world, rank = comm.world_size, comm.global_rank
+    rccl = comm._rccl if getattr(comm, "_rccl", None) is not None else None
+    rows = []
+    for lg in range(args.min_log2, args.max_log2 + 1):
+        n = (1 << lg) // 4
+        n -= n % max(world, 1)
+        buf = torch.ones(n, dtype=torch.float32, device=td)
+        res = {"bytes": n * 4}
+
+        def torch_call():
+            dist.all_reduce(buf)
+        res["torch_us"] = timed(torch_call, args.iters, td) * 1e6
+        if rccl is not None:
+            res["direct_us"] = timed(lambda: rccl.all_reduce(buf),
+                                     args.iters, td) * 1e6
+            res["two_phase_us"] = timed(
+                lambda: rccl.all_reduce_two_phase(buf, world, rank),
+                args.iters, td) * 1e6
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=td)
+            side.wait_stream(torch.cuda.current_stream(td))
+            with torch.cuda.stream(side):
+                rccl.all_reduce(buf)
+                torch.cuda.synchronize(td)
+                with torch.cuda.graph(g, stream=side):
+                    for _ in range(8):
+                        rccl.all_reduce(buf)
+            res["graph_us"] = timed(g.replay, max(args.iters // 4, 2),
+                                    td) * 1e6 / 8
+        best = min(v for k, v in res.items() if k.endswith("_us"))
+        res["algbw_GBps"] = res["bytes"] / best / 1e3
+        res["busbw_GBps"] = res["algbw_GBps"] * 2 * (world - 1) / max(world, 1)
+        rows.append(res)
+        if rank == 0:
+            print(json.dumps({k: (round(v, 2) if isinstance(v, float) else v)
+                              for k, v in res.items()}), flush=True)
+    if rank == 0:
+        print(json.dumps({"world": world, "peak_busbw_GBps": round(max(
+            r["busbw_GBps"] for r in rows), 1)}))
+
+
+if __name__ == "__main__":
+    main()

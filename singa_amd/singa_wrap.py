@@ -28,7 +28,7 @@ USE_CUDNN = USE_CUDA      # conv / bn / pool / rnn handles are available
 USE_DNNL = True           # the host path implements conv / bn / pool as well
 USE_OPENCL = False
 USE_PYTHON = True
-USE_JAVA = False
+USE_JAVA = False     # the Java classes (java/) bind the C interface at run time
 USE_DIST = True
 CUDNN_VERSION = 0
 SINGA_MAJOR_VERSION = 4

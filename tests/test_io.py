@@ -263,3 +263,30 @@ def test_lmdb_append_overwrite_and_empty(tmp_path):
         w2.Open(d, True)
         w2.Write(b"", b"x")
     assert not _rt.LMDBReader().Open(os.path.join(str(tmp_path), "missing"))
+
+
+def test_python_io_package_round_trips(tmp_path):
+    from singa_amd import io
+    items = [("k%03d" % i, bytes([i % 251]) * (i + 1)) for i in range(40)]
+    for name in ("a.bin", "env.lmdb"):
+        path = os.path.join(str(tmp_path), name)
+        with io.open_writer(path) as w:
+            for k, v in reversed(items):
+                assert w.write(k, v)
+        with io.open_reader(path) as r:
+            assert r.count() == len(items)
+            got = list(r)
+            # record files keep the write order, LMDB sorts by key
+            assert got == (items if name.endswith("lmdb") else items[::-1])
+            r.seek_to_first()
+            assert r.read() == got[0]
+        with io.open_writer(path, io.kAppend) as w:
+            w.write("zzz", b"tail")
+        assert io.open_reader(path).count() == len(items) + 1
+    txt = os.path.join(str(tmp_path), "lines.txt")
+    with io.open_writer(txt) as w:
+        w.write("", "first")
+        w.write("", b"second")
+    assert list(io.open_reader(txt)) == [("0", "first"), ("1", "second")]
+    with pytest.raises(IOError):
+        io.open_reader(os.path.join(str(tmp_path), "missing.bin"))

@@ -40,4 +40,12 @@ run autograd_resnet_cifar python examples/cnn/autograd/resnet_cifar10.py -m 1 --
 run autograd_xception python examples/cnn/autograd/xceptionnet.py -n 10
 run autograd_resnet_dist python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29641 examples/cnn/autograd/resnet_dist.py -n 20
 run autograd_sparsification python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29642 examples/cnn/autograd/sparsification_mnist.py -m 1 --max-batches 20
+run onnx_zoo_resnet18 python examples/onnx/resnet18.py --repeat 10
+run onnx_zoo_mobilenet python examples/onnx/mobilenet.py --repeat 10
+run onnx_zoo_yolo python examples/onnx/tiny_yolov2.py
+run onnx_zoo_sr python examples/onnx/superresolution.py
+run onnx_bert_squad python examples/onnx/bert/bert-squad.py
+run onnx_gpt2 python examples/onnx/gpt2/gpt2.py --length 5
+run onnx_roberta python examples/onnx/ro_bert_a/ro_bert_a.py
+run model_selection env PYTHONPATH=examples/model_selection:. python -m trails.run_ms --budget 15
 echo ALL-EXAMPLES-OK

@@ -15,6 +15,7 @@ PrintTimeProfiling), src/core/device/{device,cpp_cpu,cuda_gpu,platform}.cc.
 """
 import contextlib
 import os
+import sys
 import time
 
 import torch
@@ -327,7 +328,19 @@ class HipGPU(Device):
                         finally:
                             g.set_verbosity(self._verbosity)
                         return
-                    self._replay = _HipGraphReplay(self, serial)
+                    try:
+                        self._replay = _HipGraphReplay(self, serial)
+                    except Exception as e:      # noqa: BLE001
+                        if not self.collectives_capturable:
+                            raise
+                        # the step could not be captured with its collectives
+                        # inside: keep them between captured segments instead
+                        print("capture of the step with its collectives "
+                              "failed (%s); capturing around them" % (e,),
+                              file=sys.stderr, flush=True)
+                        self.collectives_capturable = False
+                        torch.cuda.synchronize(self.torch_device)
+                        self._replay = _HipGraphReplay(self, serial)
                 if self._stamps is not None:
                     self._stamps.before_replay(g.iteration(),
                                                self._skip_iteration)

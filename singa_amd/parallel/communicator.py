@@ -29,6 +29,7 @@ fewer, larger buckets amortise the ring's latency better than many small ones.
 """
 import math
 import os
+import time
 import socket
 
 import torch
@@ -228,6 +229,10 @@ class Communicator(object):
         if _DIRECT and self._active and not self._host_backend and self._gpu:
             self._rccl = _Rccl(torch.device("cuda",
                                             torch.cuda.current_device()))
+        probe = os.environ.get("SINGA_DIST_CAPTURE_PROBE", "1")
+        if self.capturable and self._rccl is not None and probe != "0" and \
+                (self.world_size > 1 or probe == "force"):
+            self.capturable = self._probe_capture()
         self._dev = None          # device of the last synchronised tensors
         self._blocks = []         # their blocks: what wait() orders against
         self._buffers = {}        # (slot, kind, dtype) -> persistent buffer
@@ -291,6 +296,55 @@ class Communicator(object):
                 "the first collective of a process must not be captured"
             self._rccl = _Rccl(t.device)
         return True
+
+    def _probe_capture(self):
+        """Capture one small all-reduce on a side stream into a hipGraph,
+        replay it and check the sum: the training step relies on exactly this
+        (a collective as a graph node, forked from and joined to the capturing
+        stream).  Any failure, on any rank, makes every rank keep its
+        collectives outside the captured graphs (the step is then cut into
+        several hipGraphs around them)."""
+        device = torch.device("cuda", torch.cuda.current_device())
+        ok = 1.0
+        try:
+            x = torch.ones(4096, dtype=torch.float32, device=device)
+            self._rccl.all_reduce(x)
+            torch.cuda.synchronize(device)
+            # nothing from this group may still be with the watchdog thread
+            # when a capture starts (its event queries fail during capture)
+            time.sleep(float(os.environ.get("SINGA_CAPTURE_DRAIN_MS",
+                                            "350")) / 1e3)
+            g = torch.cuda.CUDAGraph()
+            cap = torch.cuda.Stream(device=device)
+            side = torch.cuda.Stream(device=device)
+            with torch.cuda.graph(g, stream=cap,
+                                  capture_error_mode="thread_local"):
+                x.mul_(1.0)
+                side.wait_stream(torch.cuda.current_stream(device))
+                with torch.cuda.stream(side):
+                    self._rccl.all_reduce(x)
+                torch.cuda.current_stream(device).wait_stream(side)
+                x.mul_(1.0)
+            x.fill_(1.0)
+            g.replay()
+            g.replay()
+            torch.cuda.synchronize(device)
+            want = float(self.world_size) ** 2
+            if abs(float(x[0].item()) - want) > 1e-3 * want or \
+                    abs(float(x[-1].item()) - want) > 1e-3 * want:
+                ok = 0.0
+        except Exception as e:          # noqa: BLE001 (capability probe)
+            print("[rank %d] captured all-reduce probe failed: %s" % (
+                self.global_rank, e), flush=True)
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize(device)
+        agreed = bool(flag.item() > 0.5)
+        if not agreed and self.global_rank == 0:
+            print("collectives stay outside the captured step "
+                  "(SINGA_DIST_CAPTURE_PROBE=0 skips this check)", flush=True)
+        return agreed
 
     @staticmethod
     def _to_host(t):

@@ -1,7 +1,7 @@
 """cProfile of the eager (operator by operator) BERT-base inference path."""
 import cProfile, pstats, sys, os, io
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples", "onnx"))
 import text_models as tm
 from singa_amd import device, tensor

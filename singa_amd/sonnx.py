@@ -1101,6 +1101,9 @@ class SingaFrontend(object):
         if n == 'Tile':
             return n, {}, [("repeats", _np_i64(op.repeats))]
         if n == 'Gather':
+            if isinstance(op.indices, tensor.Tensor):
+                # indices fed at run time: named as an input by the caller
+                return n, dict(axis=int(op.axis)), []
             return n, dict(axis=int(op.axis)), [
                 ("indices", np.asarray(op.indices, dtype=np.int64))]
         if n == 'Clip':
@@ -1181,6 +1184,46 @@ class SingaFrontend(object):
                                       name=op.name + "_relu"))
 
     @classmethod
+    def _expand_linear_bias(cls, op, nodes):
+        """x @ W + b as MatMul -> Add, the chain the importer fuses."""
+        x, w, b = cls._input_names(op)
+        out = op.output_name(0)
+        nodes.append(helper.make_node('MatMul', [x, w], [out + "_mm"],
+                                      name=op.name + "_mm"))
+        nodes.append(helper.make_node('Add', [out + "_mm", b], [out],
+                                      name=op.name + "_add"))
+
+    @classmethod
+    def _expand_attention(cls, op, nodes, initializers):
+        """The fused attention operator as the chain exporters write (and the
+        importer recognises): MatMul -> Mul(scale) -> [Add(mask)] -> Softmax
+        -> MatMul -> Transpose -> Reshape (merge heads)."""
+        ins = cls._input_names(op)            # q, kt, v[, mask]
+        out = op.output_name(0)
+
+        def const(suffix, arr):
+            nm = "%s_%s" % (op.name, suffix)
+            initializers.append(numpy_helper.from_array(arr, nm))
+            return nm
+
+        def node(kind, inputs, suffix, **attrs):
+            nm = out + "_" + suffix
+            nodes.append(helper.make_node(kind, inputs, [nm],
+                                          name=op.name + "_" + suffix,
+                                          **attrs))
+            return nm
+        s_ = node('MatMul', [ins[0], ins[1]], "qk")
+        s_ = node('Mul', [s_, const("scale", np.float32(op.scale))], "scaled")
+        if len(ins) > 3:
+            s_ = node('Add', [s_, ins[3]], "masked")
+        p_ = node('Softmax', [s_], "prob", axis=-1)
+        c_ = node('MatMul', [p_, ins[2]], "ctx")
+        c_ = node('Transpose', [c_], "heads", perm=[0, 2, 1, 3])
+        nodes.append(helper.make_node(
+            'Reshape', [c_, const("merge", np.array([0, 0, -1], np.int64))],
+            [out], name=op.name + "_merge"))
+
+    @classmethod
     def singa_to_onnx_graph(cls, inputs, y, model_name="sonnx"):
         """GraphProto of the computation that produced ``y`` (a Tensor or a
         list of Tensors) from ``inputs`` (list of Tensors)."""
@@ -1199,8 +1242,22 @@ class SingaFrontend(object):
                 if type(op).__name__ == '_BatchNormAct2d':
                     cls._expand_batchnorm_act(op, nodes, initializers)
                     continue
+                if type(op).__name__ == 'LinearBias':
+                    cls._expand_linear_bias(op, nodes)
+                    continue
+                if type(op).__name__ == 'Attention':
+                    cls._expand_attention(op, nodes, initializers)
+                    continue
                 op_type, attrs, extra = cls._attrs_and_extra(op)
                 in_names = cls._input_names(op)
+                if op_type == 'Gather' and isinstance(
+                        getattr(op, "indices", None), tensor.Tensor):
+                    src = op.indices.creator
+                    if type(src).__name__ != 'Dummy':
+                        raise NotImplementedError(
+                            "Gather indices computed inside the graph cannot "
+                            "be exported")
+                    in_names.append(src.name)
                 for suffix, arr in extra:
                     nm = "%s_%s" % (op.name, suffix)
                     initializers.append(numpy_helper.from_array(arr, nm))
@@ -1220,10 +1277,15 @@ class SingaFrontend(object):
         for x in inputs:
             g_in.append(helper.make_tensor_value_info(
                 x.creator.name, _singa_dtype_to_onnx(x.dtype), list(x.shape)))
-        for name in graph_inputs:
-            if name not in known_inputs:
+        for name, leaf in graph_inputs.items():
+            if name in known_inputs:
+                continue
+            if leaf is None:
                 raise ValueError(
                     "graph input %s is not among the given inputs" % name)
+            # a constant of the computation (e.g. of an imported graph)
+            initializers.append(numpy_helper.from_array(
+                tensor.to_numpy(leaf), name))
         g_out = [helper.make_tensor_value_info(
             yy.creator.output_name(yy.creator.y_id2idx[yy.uid]),
             _singa_dtype_to_onnx(yy.dtype), list(yy.shape)) for yy in ys]

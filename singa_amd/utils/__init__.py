@@ -175,7 +175,9 @@ def post_order_recursive(root, root_t):
             elif t is not None:
                 weights[op.name] = t
             else:
-                inputs[op.name] = t
+                # the leaf's own tensor: a fed input, or a constant the
+                # computation captured (exported as an initializer)
+                inputs[op.name] = op.__dict__.get("tensor")
             continue
         if not leaf:
             if id(op) in seen:

@@ -284,3 +284,39 @@ def test_recorded_transformer_reads_the_ids_of_each_batch(zoo, dev):
                                           for a in (ids, mask, seg)], 1, 1)
         np.testing.assert_allclose(got, want, atol=2e-4)
     dev.ResetGraph()
+
+
+def test_fused_transformer_exports_and_reimports(zoo, dev):
+    """An imported encoder runs on the fused operators (attention, linear
+    with bias, layer norm, GELU); exporting that computation writes the
+    standard chains again, and importing the export reproduces the output."""
+    from singa_amd import autograd, sonnx, tensor
+    tm = importlib.import_module("text_models")
+    cfg = dict(seq=16, hidden=128, heads=2, layers=1, ffn=256, vocab=60)
+    model, W = tm.bert_encoder(batch=2, squad_head=False, **cfg)
+    rs = np.random.RandomState(5)
+    ids = rs.randint(0, 60, (2, 16)).astype(np.int32)
+    mask = np.ones((2, 16), np.int32)
+    mask[0, 12:] = 0
+    seg = np.zeros((2, 16), np.int32)
+    xs = [tensor.from_numpy(a, dev) for a in (ids, mask, seg)]
+    m = tm.TextModel(model)
+    m.compile(xs, is_train=False, use_graph=False, sequential=True)
+    m.eval()
+    y = m(*xs)[0]
+    kinds = [type(o).__name__ for _, o in m.sg_ir.layers]
+    assert "Attention" in kinds and "LinearBias" in kinds
+    exported = sonnx.to_onnx(xs, [y])
+    ops = [n.op_type for n in exported.graph.node]
+    assert "Softmax" in ops and "MatMul" in ops       # standard nodes only
+    assert not any(o.startswith("Fused") for o in ops)
+    again = tm.TextModel(exported)
+    again.compile(xs, is_train=False, use_graph=False, sequential=True)
+    again.eval()
+    y2 = again(*xs)[0]
+    assert "Attention" in [type(o).__name__ for _, o in again.sg_ir.layers]
+    np.testing.assert_allclose(tensor.to_numpy(y2), tensor.to_numpy(y),
+                               atol=2e-5)
+    want = tm.bert_encoder_numpy(W, *[a.astype(np.int64)
+                                      for a in (ids, mask, seg)], 2, 1)
+    np.testing.assert_allclose(tensor.to_numpy(y2), want, atol=2e-3)

@@ -1012,8 +1012,7 @@ class SingaFrontend(object):
         'Negative': 'Neg', 'Reciprocal': 'Reciprocal', 'NonZero': 'NonZero',
         'Ceil': 'Ceil', 'Floor': 'Floor', 'Abs': 'Abs', 'Exp': 'Exp',
         'Rounde': 'Round', 'Erf': 'Erf', 'AddBias': 'Add',
-        'LayerNorm': 'LayerNormalization', 'Gelu': 'Gelu',
-        'GlobalAveragePool': 'GlobalAveragePool',
+        'Gelu': 'Gelu', 'GlobalAveragePool': 'GlobalAveragePool',
     }
 
     @classmethod

@@ -17,6 +17,8 @@ SHAPES = [(4096, 4096, 4096), (8192, 8192, 8192), (8192, 8192, 1024),
           (1024, 1024, 1024), (1024, 1024, 4096), (2048, 1024, 2048), (32, 1000, 2048),
           # BERT-base, 32 x 256 tokens: QKV / out projection, FFN
           (8192, 768, 768), (8192, 3072, 768), (8192, 768, 3072)]
+# weight gradients of the same layers: x^T (K x M tokens, read transposed) @ dy
+WGRAD_SHAPES = [(768, 768, 8192), (768, 3072, 8192), (3072, 768, 8192)]
 
 
 def main():
@@ -39,6 +41,24 @@ def main():
             args.dtype, M, N, K, t, 2.0 * M * N * K / t / 1e9)
         if args.vendor:
             tv = timeit(lambda: torch.matmul(a, b, out=c), args.iters)
+            line += "   vendor %8.3f ms %7.1f TF/s" % (
+                tv, 2.0 * M * N * K / tv / 1e9)
+        print(line, flush=True)
+    wgrad(args, sdev)
+
+
+def wgrad(args, sdev):
+    dev, m = sdev.torch_device, sdev.math
+    dt = getattr(torch, args.dtype)
+    for (M, N, K) in WGRAD_SHAPES:
+        x = torch.randn(K, M, device=dev, dtype=dt)     # tokens x features
+        dy = torch.randn(K, N, device=dev, dtype=dt)
+        c = torch.empty(M, N, device=dev, dtype=dt)
+        t = timeit(lambda: m.gemm(1.0, x.t(), dy, 0.0, c), args.iters)
+        line = "wgrad %s %5dx%5dx%5d: %8.3f ms %7.1f TF/s" % (
+            args.dtype, M, N, K, t, 2.0 * M * N * K / t / 1e9)
+        if args.vendor:
+            tv = timeit(lambda: torch.matmul(x.t(), dy, out=c), args.iters)
             line += "   vendor %8.3f ms %7.1f TF/s" % (
                 tv, 2.0 * M * N * K / tv / 1e9)
         print(line, flush=True)

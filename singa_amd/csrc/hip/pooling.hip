@@ -76,6 +76,61 @@ __global__ void pool_bwd_kernel(PoolGeom g, const T *__restrict__ dy,
   }
 }
 
+// Max-pooling gradient with one (n, c) plane per blockIdx.y and four
+// consecutive columns per thread (W a multiple of 4): 32-bit index arithmetic,
+// 8- / 16-byte loads of x and stores of dx, the few rows of dy / y a thread
+// needs stay in L1 across its four columns.
+template <typename T>
+__global__ void __launch_bounds__(256)
+maxpool_bwd_plane_kernel(PoolGeom g, const T *__restrict__ dy,
+                         const T *__restrict__ x, const T *__restrict__ y,
+                         T *__restrict__ dx, int planes) {
+  const int quads = g.W >> 2, per_plane = g.H * quads;
+  for (int nc = blockIdx.y; nc < planes; nc += gridDim.y) {
+    const T *dyp = dy + (int64_t)nc * g.P * g.Q;
+    const T *yp = y + (int64_t)nc * g.P * g.Q;
+    const T *xp = x + (int64_t)nc * g.H * g.W;
+    T *dxp = dx + (int64_t)nc * g.H * g.W;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < per_plane;
+         e += gridDim.x * blockDim.x) {
+      const int h = e / quads, w0 = (e - h * quads) << 2;
+      T xe[4], oe[4];
+      if (sizeof(T) == 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(xp + h * g.W + w0);
+        __builtin_memcpy(xe, &v, 16);
+      } else {
+        const uint2 v = *reinterpret_cast<const uint2 *>(xp + h * g.W + w0);
+        __builtin_memcpy(xe, &v, 8);
+      }
+      const int hp = h + g.ph;
+      const int p_lo = hp < g.kh ? 0 : (hp - g.kh) / g.sh + 1;
+      const int p_hi = min(hp / g.sh, g.P - 1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int wp = w0 + k + g.pw;
+        const int q_lo = wp < g.kw ? 0 : (wp - g.kw) / g.sw + 1;
+        const int q_hi = min(wp / g.sw, g.Q - 1);
+        const float xv = to_f<T>(xe[k]);
+        float acc = 0.f;
+        for (int p = p_lo; p <= p_hi; ++p)
+          for (int q = q_lo; q <= q_hi; ++q)
+            if (to_f<T>(yp[p * g.Q + q]) == xv)
+              acc += to_f<T>(dyp[p * g.Q + q]);
+        oe[k] = from_f<T>(acc);
+      }
+      if (sizeof(T) == 4) {
+        float4 v;
+        __builtin_memcpy(&v, oe, 16);
+        *reinterpret_cast<float4 *>(dxp + h * g.W + w0) = v;
+      } else {
+        uint2 v;
+        __builtin_memcpy(&v, oe, 8);
+        *reinterpret_cast<uint2 *>(dxp + h * g.W + w0) = v;
+      }
+    }
+  }
+}
+
 }  // namespace sa
 
 using namespace sa;
@@ -95,6 +150,22 @@ int sa_pool_bwd(int dtype, const PoolGeom *g, const void *dy, const void *x,
                 const void *y, void *dx, hipStream_t s) {
   const int64_t total = (int64_t)g->N * g->C * g->H * g->W;
   if (total <= 0) return 0;
+  const int64_t planes = (int64_t)g->N * g->C;
+  const bool plane_path =
+      g->is_max && g->W % 4 == 0 && (int64_t)g->H * g->W < (1 << 28) &&
+      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx)) &
+       15) == 0;
+  if (plane_path) {
+    const int per_plane = g->H * (g->W / 4);
+    const dim3 grid((unsigned)((per_plane + 255) / 256),
+                    (unsigned)i64min(planes, 32768));
+    SA_DISPATCH_FLOAT(dtype, T, {
+      hipLaunchKernelGGL((maxpool_bwd_plane_kernel<T>), grid, dim3(256), 0, s,
+                         *g, (const T *)dy, (const T *)x, (const T *)y,
+                         (T *)dx, (int)planes);
+    });
+    return 0;
+  }
   SA_DISPATCH_FLOAT(dtype, T, {
     hipLaunchKernelGGL((pool_bwd_kernel<T>), dim3(grid_for(total, 256)),
                        dim3(256), 0, s, *g, (const T *)dy, (const T *)x,

@@ -1206,3 +1206,41 @@ def test_layernorm_and_gelu_kernels_all_types(maths, dt, rows, D):
         hm.gelu_bwd(dv.to(d), xv.to(d), gx)
         (ref * dv.double()).sum().backward()
         close(gx, xg.grad, "gelu grad", 2.0)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("k,s,p,H,W", [(3, 2, 1, 28, 28), (2, 2, 0, 10, 16),
+                                       (3, 1, 1, 9, 12), (3, 2, 1, 112, 112)])
+def test_max_pooling_gradient_by_planes(maths, dt, k, s, p, H, W):
+    """Max-pooling gradient on images whose width is a multiple of four (the
+    plane kernel with four columns per thread).  Inputs come after a ReLU and
+    are quantised, so equal maxima inside a window occur: every position equal
+    to the window maximum receives the window's gradient (the rule of both
+    GPU kernels, stated in pooling.hip; the host backend picks one position,
+    so the expectation is computed here)."""
+    hm, cm, dev = maths
+    x = torch.relu(rnd(2, 3, H, W, seed=70) * 4).round().div(4).to(dt)
+    P, Q = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    ry = torch.empty(2, 3, P, Q)
+    cm.pool_fwd(x.float(), ry, (k, k), (s, s), (p, p), True)
+    dy = rnd(2, 3, P, Q, seed=71).to(dt)
+    xf, dyf = x.float().numpy(), dy.float().numpy()
+    want = np.zeros_like(xf)
+    yv = ry.numpy()
+    for ph in range(P):
+        for qw in range(Q):
+            h0, w0 = ph * s - p, qw * s - p
+            hs, ws = max(h0, 0), max(w0, 0)
+            he, we = min(h0 + k, H), min(w0 + k, W)
+            win = xf[:, :, hs:he, ws:we]
+            hit = win == yv[:, :, ph, qw][:, :, None, None]
+            want[:, :, hs:he, ws:we] += hit * dyf[:, :, ph, qw][:, :, None,
+                                                                 None]
+    y = torch.empty(2, 3, P, Q, dtype=dt, device=dev.torch_device)
+    hm.pool_fwd(g(x, dev), y, (k, k), (s, s), (p, p), True)
+    np.testing.assert_array_equal(y.float().cpu().numpy(), yv)
+    dx = torch.empty(2, 3, H, W, dtype=dt, device=dev.torch_device)
+    hm.pool_bwd(g(dy, dev), g(x, dev), y, dx, (k, k), (s, s), (p, p), True)
+    eps = {torch.float32: 1e-6, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dt]
+    np.testing.assert_allclose(dx.float().cpu().numpy(), want, rtol=eps,
+                               atol=eps * 8)

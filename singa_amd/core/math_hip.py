@@ -378,6 +378,38 @@ class HipMath(object):
             torch.float32, torch.float16, torch.bfloat16) else 1
         if splits > 1 and c.dtype != torch.float32 and (K // splits) % 64:
             splits = 1          # the 16-bit tiles are 64 deep
+        if splits == 1 and batch == 1 and K % 8 == 0 and c.dtype in (
+                torch.float16, torch.bfloat16):
+            # 64-deep tiles: slices of a multiple of 64, the last one shorter
+            n_sl, kc = self._gemm_uneven_slices(M, N, K, 64)
+            if n_sl > 1:
+                part = torch.empty(n_sl * M * N, dtype=torch.float32,
+                                   device=c.device)
+                if self.k.gemm_h16_partial(
+                        _code(c), M, N, kc, a.data_ptr(), a_rs, a_cs,
+                        kc * a_cs, b.data_ptr(), b_rs, b_cs, kc * b_rs,
+                        part.data_ptr(), n_sl, self._s(), K) == 0:
+                    self.k.gemm_splitk_reduce(
+                        _code(c), part.data_ptr(), n_sl, M, N, float(alpha),
+                        float(beta), c.data_ptr(), ldc,
+                        bias.data_ptr() if bias is not None else 0, act,
+                        self._s())
+                    return
+        if splits == 1 and batch == 1 and c.dtype == torch.float32:
+            # no divisor of K fits (an odd reduction length): unequal slices
+            n_sl, kc = self._gemm_uneven_slices(M, N, K)
+            if n_sl > 1:
+                part = torch.empty(n_sl * M * N, dtype=torch.float32,
+                                   device=c.device)
+                self.k.gemm_f32_slices(M, N, kc, K, a.data_ptr(), a_rs, a_cs,
+                                       b.data_ptr(), b_rs, b_cs,
+                                       part.data_ptr(), n_sl, self._s())
+                self.k.gemm_splitk_reduce(
+                    _code(c), part.data_ptr(), n_sl, M, N, float(alpha),
+                    float(beta), c.data_ptr(), ldc,
+                    bias.data_ptr() if bias is not None else 0, act,
+                    self._s())
+                return
         if splits > 1:
             # too few output tiles to occupy the chip: the reduction is cut
             # into `splits` equal slices computed as a batch of float partial
@@ -410,30 +442,53 @@ class HipMath(object):
                     bias.data_ptr() if bias is not None else 0, act, self._s())
 
     @staticmethod
-    def _gemm_splits(M, N, K):
-        """Number of equal reduction slices for a product with too few output
-        tiles to occupy the chip: the largest divisor of K that keeps the
-        launch within about one workgroup per CU, with slices 4-aligned (for
-        the vector loads) and at least 64 deep for skinny products (counted
-        in 64 x 64 tiles) or 512 deep for mid-sized ones (128 x 128 tiles)."""
+    def _split_rule(M, N, K):
+        """(most slices, least slice depth) for a product with too few output
+        tiles to occupy the chip, or None: skinny products are counted in
+        64 x 64 tiles and may be cut down to 64-deep slices, mid-sized ones in
+        128 x 128 tiles with 512- or 1024-deep slices."""
         tiles64 = -(-M // 64) * -(-N // 64)
         tiles128 = -(-M // 128) * -(-N // 128)
         if tiles64 <= 64 and K >= 512:
-            most, depth = min(32, 256 // tiles64), 64
-        elif tiles128 <= 96 and K >= 1024 and M >= 96 and N >= 96:
-            most, depth = _SPLIT_TARGET // tiles128, 512
-        elif tiles128 < 384 and K >= 2048 and M >= 96 and N >= 96:
+            return min(32, 256 // tiles64), 64
+        if tiles128 <= 96 and K >= 1024 and M >= 96 and N >= 96:
+            return _SPLIT_TARGET // tiles128, 512
+        if tiles128 < 384 and K >= 2048 and M >= 96 and N >= 96:
             # a weight gradient over many tokens: a few hundred tiles with a
             # long reduction each; aim at two workgroups per CU
-            most = (_SPLIT_TARGET + tiles128 // 2) // tiles128
-            depth = 1024
-        else:
+            return (_SPLIT_TARGET + tiles128 // 2) // tiles128, 1024
+        return None
+
+    @classmethod
+    def _gemm_splits(cls, M, N, K):
+        """Number of equal reduction slices: the largest divisor of K within
+        the rule's limits, with slices 4-aligned (for the vector loads)."""
+        rule = cls._split_rule(M, N, K)
+        if rule is None:
             return 1
+        most, depth = rule
         best = 1
         for d in range(2, most + 1):
             if K % d == 0 and (K // d) >= depth and (K // d) % 4 == 0:
                 best = d
         return best
+
+    @classmethod
+    def _gemm_uneven_slices(cls, M, N, K, align=4):
+        """(slices, slice depth) for a reduction length without a suitable
+        divisor (e.g. an odd one): slices of a multiple of ``align`` indices,
+        the last one shorter."""
+        rule = cls._split_rule(M, N, K)
+        if rule is None:
+            return 1, K
+        most, depth = rule
+        d = max(1, min(most, K // max(depth, align)))
+        if d < 2:
+            return 1, K
+        kc = -(-K // d)
+        kc += -kc % align
+        n = -(-K // kc)
+        return (n, kc) if n > 1 else (1, K)
 
     def gemv(self, alpha, a, v, beta, out):
         self.gemm(alpha, a, v.reshape(-1, 1), beta, out.reshape(-1, 1))

@@ -171,15 +171,28 @@ PYBIND11_MODULE(_hip, m) {
           "gemm");
   });
 
+  m.def("gemm_f32_slices", [](int64_t M, int64_t N, int64_t kc, int64_t k_total,
+                              uintptr_t A, int64_t a_rs, int64_t a_cs,
+                              uintptr_t B, int64_t b_rs, int64_t b_cs,
+                              uintptr_t part, int64_t splits, uintptr_t s) {
+    check(sa_gemm_f32_slices(M, N, kc, k_total, CP(A), a_rs, a_cs, CP(B), b_rs,
+                             b_cs, (float *)P(part), splits, S(s)),
+          "gemm_f32_slices");
+  });
+
   // returns the status instead of raising: -3 = layout not eligible
   m.def("gemm_h16_partial", [](int dt, int64_t M, int64_t N, int64_t K,
                                uintptr_t A, int64_t a_rs, int64_t a_cs,
                                int64_t a_bs, uintptr_t B, int64_t b_rs,
                                int64_t b_cs, int64_t b_bs, uintptr_t part,
-                               int64_t batch, uintptr_t s) {
+                               int64_t batch, uintptr_t s, int64_t k_total) {
     return sa_gemm_h16_partial(dt, M, N, K, CP(A), a_rs, a_cs, a_bs, CP(B),
-                               b_rs, b_cs, b_bs, (float *)P(part), batch, S(s));
-  });
+                               b_rs, b_cs, b_bs, (float *)P(part), batch,
+                               k_total, S(s));
+  }, py::arg("dt"), py::arg("M"), py::arg("N"), py::arg("K"), py::arg("A"),
+     py::arg("a_rs"), py::arg("a_cs"), py::arg("a_bs"), py::arg("B"),
+     py::arg("b_rs"), py::arg("b_cs"), py::arg("b_bs"), py::arg("part"),
+     py::arg("batch"), py::arg("s"), py::arg("k_total") = 0);
   m.def("gemm_splitk_reduce", [](int dt, uintptr_t part, int splits, int64_t M,
                                  int64_t N, float alpha, float beta,
                                  uintptr_t C, int64_t ldc, uintptr_t bias,

@@ -48,6 +48,10 @@ struct GemmArgs {
   // 16-bit tiled kernel only: tensor of C's shape and layout added to the
   // product (a residual gradient that reached the same tensor)
   const void *addend = nullptr;
+  // float32 kernel only: total reduction length when the batch index walks
+  // slices of K reduction indices each (the last slice may be shorter); 0 when
+  // every batch entry reduces over K
+  int64_t k_total = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -84,6 +88,11 @@ gemm_f32_kernel(GemmArgs g) {
   const float *A = (const float *)g.A + (int64_t)blockIdx.z * g.a_bs;
   const float *B = (const float *)g.B + (int64_t)blockIdx.z * g.b_bs;
   float *C = (float *)g.C + (int64_t)blockIdx.z * g.c_bs;
+  // reduction length of this batch entry
+  const int64_t Kz = g.k_total
+                         ? max((int64_t)0, min(g.K, g.k_total -
+                                                        (int64_t)blockIdx.z * g.K))
+                         : g.K;
 
   float ra[A_PER], rb[B_PER];
 
@@ -97,7 +106,7 @@ gemm_f32_kernel(GemmArgs g) {
         const int m = e % BM, kq = e / BM;
         const int64_t gm = m0 + m, gk = k0 + 4 * kq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gm < g.M && gk < g.K)
+        if (gm < g.M && gk < Kz)
           v = *reinterpret_cast<const float4 *>(A + gm * g.a_rs + gk);
         ra[4 * j + 0] = v.x; ra[4 * j + 1] = v.y;
         ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
@@ -110,7 +119,7 @@ gemm_f32_kernel(GemmArgs g) {
         const int mq = e % (BM / 4), k = e / (BM / 4);
         const int64_t gm = m0 + 4 * mq, gk = k0 + k;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gm < g.M && gk < g.K)
+        if (gm < g.M && gk < Kz)
           v = *reinterpret_cast<const float4 *>(A + gk * g.a_cs + gm);
         ra[4 * j + 0] = v.x; ra[4 * j + 1] = v.y;
         ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
@@ -121,7 +130,7 @@ gemm_f32_kernel(GemmArgs g) {
         const int e = tid + 256 * j;
         const int m = e % BM, k = e / BM;
         const int64_t gm = m0 + m, gk = k0 + k;
-        ra[j] = (gm < g.M && gk < g.K) ? A[gm * g.a_rs + gk * g.a_cs] : 0.f;
+        ra[j] = (gm < g.M && gk < Kz) ? A[gm * g.a_rs + gk * g.a_cs] : 0.f;
       }
     }
     // ---- B tile: BK x BN ----
@@ -132,7 +141,7 @@ gemm_f32_kernel(GemmArgs g) {
         const int nq = e % (BN / 4), k = e / (BN / 4);
         const int64_t gn = n0 + 4 * nq, gk = k0 + k;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gn < g.N && gk < g.K)
+        if (gn < g.N && gk < Kz)
           v = *reinterpret_cast<const float4 *>(B + gk * g.b_rs + gn);
         rb[4 * j + 0] = v.x; rb[4 * j + 1] = v.y;
         rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w;
@@ -144,7 +153,7 @@ gemm_f32_kernel(GemmArgs g) {
         const int n = e % BN, kq = e / BN;
         const int64_t gn = n0 + n, gk = k0 + 4 * kq;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gn < g.N && gk < g.K)
+        if (gn < g.N && gk < Kz)
           v = *reinterpret_cast<const float4 *>(B + gn * g.b_cs + gk);
         rb[4 * j + 0] = v.x; rb[4 * j + 1] = v.y;
         rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w;
@@ -155,7 +164,7 @@ gemm_f32_kernel(GemmArgs g) {
         const int e = tid + 256 * j;
         const int n = e % BN, k = e / BN;
         const int64_t gn = n0 + n, gk = k0 + k;
-        rb[j] = (gn < g.N && gk < g.K) ? B[gk * g.b_rs + gn * g.b_cs] : 0.f;
+        rb[j] = (gn < g.N && gk < Kz) ? B[gk * g.b_rs + gn * g.b_cs] : 0.f;
       }
     }
   };
@@ -217,7 +226,7 @@ gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nt = (int)((g.K + BK - 1) / BK);
+  const int nt = (int)((Kz + BK - 1) / BK);
   load_tiles(0);
   store_tiles();
   __syncthreads();
@@ -701,7 +710,12 @@ gemm_h16_fast_kernel(GemmArgs g, int ntm, int ntn) {
     pid_n = in_band / rows;
   }
   const int m0 = pid_m * BM, n0 = pid_n * BN;
-  const int K = (int)g.K;
+  // reduction length of this batch entry (slices of a split reduction: the
+  // last one may be shorter)
+  const int K = g.k_total ? (int)max((int64_t)0,
+                                     min(g.K, g.k_total -
+                                                  (int64_t)blockIdx.z * g.K))
+                          : (int)g.K;
 
   const T *Ab = (const T *)g.A + (int64_t)blockIdx.z * g.a_bs;
   const T *Bb = (const T *)g.B + (int64_t)blockIdx.z * g.b_bs;
@@ -1867,17 +1881,54 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
 // 16-bit operands, float output: part[b] = A[b] * B[b] for b < batch (the
 // slices of a split reduction).  Returns -3 when the operand layout does not
 // fit the tiled kernel (the caller then takes the unsplit path).
+// float32 product cut into `splits` slices of `kc` reduction indices (the
+// last one holds what is left of `k_total`): slice z writes its partial
+// product to part + z * M * N.  Any k_total; kc a multiple of 4.
+int sa_gemm_f32_slices(int64_t M, int64_t N, int64_t kc, int64_t k_total,
+                       const void *A, int64_t a_rs, int64_t a_cs,
+                       const void *B, int64_t b_rs, int64_t b_cs, float *part,
+                       int64_t splits, hipStream_t s) {
+  if (M <= 0 || N <= 0 || splits <= 0) return 0;
+  if (kc <= 0 || kc % 4 != 0 || (splits - 1) * kc >= k_total) return -2;
+  GemmArgs g{M, N, kc, 1.f, 0.f, A, a_rs, a_cs, kc * a_cs, B, b_rs, b_cs,
+             kc * b_rs, part, N, M * N, nullptr, 0};
+  g.k_total = k_total;
+  auto al16 = [](const void *p) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+  };
+  // vector loads along k need every slice to end on a group of four
+  int amode = LD_GENERIC, bmode = LD_GENERIC;
+  if (a_cs == 1 && (a_rs % 4) == 0 && (k_total % 4) == 0 && al16(A))
+    amode = LD_VEC_K;
+  else if (a_rs == 1 && (a_cs % 4) == 0 && (M % 4) == 0 && al16(A))
+    amode = LD_VEC_MN;
+  if (b_cs == 1 && (b_rs % 4) == 0 && (N % 4) == 0 && al16(B))
+    bmode = LD_VEC_MN;
+  else if (b_rs == 1 && (b_cs % 4) == 0 && (k_total % 4) == 0 && al16(B))
+    bmode = LD_VEC_K;
+  if (amode == LD_GENERIC || bmode == LD_GENERIC)
+    amode = bmode = LD_GENERIC;
+  dim3 grid((unsigned)((((N + 63) / 64) * ((M + 63) / 64) + 7) / 8 * 8), 1,
+            (unsigned)splits);
+  launch_f32<64, 64>(g, amode, bmode, grid, s);
+  return 0;
+}
+
 int sa_gemm_h16_partial(int dtype, int64_t M, int64_t N, int64_t K,
                         const void *A, int64_t a_rs, int64_t a_cs,
                         int64_t a_bs, const void *B, int64_t b_rs,
                         int64_t b_cs, int64_t b_bs, float *part, int64_t batch,
-                        hipStream_t s) {
+                        int64_t k_total, hipStream_t s) {
   if (dtype != kF16 && dtype != kBF16) return -1;
   if (M <= 0 || N <= 0 || batch <= 0) return 0;
   GemmArgs g{M, N, K, 1.f, 0.f, A, a_rs, a_cs, a_bs, B, b_rs, b_cs, b_bs,
              part, N, M * N, nullptr, 0};
   g.c_float = 1;
   if (!h16_fast_ok(g)) return -3;
+  // unequal slices: K indices each, the last one what is left of k_total
+  if (k_total > 0 && (k_total % 8 != 0 || (batch - 1) * K >= k_total))
+    return -3;
+  g.k_total = k_total;
   const bool a_kc = a_cs == 1, b_kc = b_rs == 1;
   if (dtype == kF16) launch_h16_fast<__half>(g, a_kc, b_kc, batch, s);
   else launch_h16_fast<__hip_bfloat16>(g, a_kc, b_kc, batch, s);

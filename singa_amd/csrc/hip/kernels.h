@@ -102,10 +102,14 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
 
 // 16-bit A / B, float partial products part[b] = A[b] * B[b]; -3 when the
 // operand layout does not fit the tiled kernel
+int sa_gemm_f32_slices(int64_t M, int64_t N, int64_t kc, int64_t k_total,
+                       const void *A, int64_t a_rs, int64_t a_cs,
+                       const void *B, int64_t b_rs, int64_t b_cs, float *part,
+                       int64_t splits, hipStream_t s);
 int sa_gemm_h16_partial(int dtype, int64_t M, int64_t N, int64_t K,
                         const void *A, int64_t a_rs, int64_t a_cs,
                         int64_t a_bs, const void *B, int64_t b_rs,
-                        int64_t b_cs, int64_t b_bs, float *part, int64_t batch,
+                        int64_t b_cs, int64_t b_bs, float *part, int64_t batch, int64_t k_total,
                         hipStream_t s);
 // epilogue of a reduction split over `splits` partial products [splits][M][N]
 int sa_gemm_splitk_reduce(int dtype, const float *part, int splits, int64_t M,

@@ -1244,3 +1244,55 @@ def test_max_pooling_gradient_by_planes(maths, dt, k, s, p, H, W):
     eps = {torch.float32: 1e-6, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dt]
     np.testing.assert_allclose(dx.float().cpu().numpy(), want, rtol=eps,
                                atol=eps * 8)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 1595), (64, 2048, 1605),
+                                   (32, 1000, 2047), (100, 70, 1537),
+                                   (64, 2048, 1598)])
+def test_gemm_unequal_reduction_slices(maths, M, N, K):
+    """A long reduction whose length has no usable divisor (odd lengths of the
+    reference's product micro-benchmark, 64 x {1595, 1605} x 2048): slices of
+    a multiple of four indices, the last one shorter; row-major and transposed
+    operands, scaling, previous C, bias and ReLU in the summing epilogue."""
+    hm, cm, dev = maths
+    assert hm._gemm_splits(M, N, K) == 1
+    n_sl, kc = hm._gemm_uneven_slices(M, N, K)
+    assert n_sl > 1 and kc % 4 == 0 and (n_sl - 1) * kc < K <= n_sl * kc
+    a, b = rnd(M, K, seed=80), rnd(K, N, seed=81)
+    bias, c0 = rnd(N, seed=82), rnd(M, N, seed=83)
+    ref = a.double() @ b.double()
+    c = torch.empty(M, N, device=dev.torch_device)
+    hm.gemm(1.0, g(a, dev), g(b, dev), 0.0, c)
+    np.testing.assert_allclose(c.cpu().numpy(), ref.numpy(), atol=2e-4)
+    c = g(c0, dev).clone()
+    hm.gemm(0.5, g(a.t().contiguous(), dev).t(),
+            g(b.t().contiguous(), dev).t(), 2.0, c, bias=g(bias, dev), act=1)
+    want = torch.relu(0.5 * ref + 2.0 * c0.double() + bias.double())
+    np.testing.assert_allclose(c.cpu().numpy(), want.numpy(), atol=3e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 1600), (32, 1000, 2040),
+                                   (128, 256, 1096)])
+def test_gemm_16bit_unequal_reduction_slices(maths, dt, M, N, K):
+    """16-bit products whose reduction length is a multiple of 8 but not of
+    the 64-deep tiles times a slice count: slices of a multiple of 64, the
+    last one shorter, summed from float partial products."""
+    hm, cm, dev = maths
+    n_sl, kc = hm._gemm_uneven_slices(M, N, K, 64)
+    assert n_sl > 1 and kc % 64 == 0 and (n_sl - 1) * kc < K
+    a, b = rnd(M, K, seed=90).to(dt), rnd(K, N, seed=91).to(dt)
+    bias = rnd(N, seed=92).to(dt)
+    ref = a.double() @ b.double()
+    c = torch.empty(M, N, dtype=dt, device=dev.torch_device)
+    hm.gemm(1.0, g(a, dev), g(b, dev), 0.0, c)
+    eps = {torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dt]
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(c.double().cpu().numpy(), ref.numpy(),
+                               atol=eps * scale)
+    c2 = torch.empty(M, N, dtype=dt, device=dev.torch_device)
+    hm.gemm(0.5, g(a.t().contiguous(), dev).t(), g(b, dev), 0.0, c2,
+            bias=g(bias, dev), act=1)
+    want = torch.relu(0.5 * ref + bias.double())
+    np.testing.assert_allclose(c2.double().cpu().numpy(), want.numpy(),
+                               atol=eps * scale)

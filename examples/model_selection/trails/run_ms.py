@@ -73,9 +73,15 @@ class RunModelSelection(object):
         t1 = self.profile_filtering()
         t2 = self.profile_refinement()
         left = budget - (time.perf_counter() - t0)
-        plan = coordinator.schedule(max(left, 1e-3), t1, t2, self.strategy,
-                                    kn_rate, self.eta, only_phase1=only_phase1,
-                                    space_size=len(self.space))
+        try:
+            plan = coordinator.schedule(max(left, 1e-3), t1, t2,
+                                        self.strategy, kn_rate, self.eta,
+                                        only_phase1=only_phase1,
+                                        space_size=len(self.space))
+        except ValueError:
+            # the budget is gone after profiling: the smallest useful run
+            plan = dict(K=1, U=1, N=min(kn_rate, len(self.space)),
+                        phase1_time=kn_rate * t1, phase2_time=0.0)
         kept = self.filtering_phase(plan["N"], max(plan["K"], 1))
         if only_phase1 or len(kept) <= 1:
             best, epochs, trace = kept[0], 0, []

@@ -226,9 +226,21 @@ class Communicator(object):
         # without accumulation the capacity is the whole bucket
         self.spars_cap = float(os.environ.get("SINGA_SPARS_CAP", "1.0"))
         self._rccl = None         # direct RCCL calls
+        self._no_direct = False   # set when the communicator handle is out of reach
         if _DIRECT and self._active and not self._host_backend and self._gpu:
-            self._rccl = _Rccl(torch.device("cuda",
-                                            torch.cuda.current_device()))
+            try:
+                self._rccl = _Rccl(torch.device(
+                    "cuda", torch.cuda.current_device()))
+            except (OSError, AttributeError, RuntimeError) as e:
+                # no direct handle on the communicator: collectives go through
+                # torch.distributed's work objects, which must stay outside
+                # captured graphs (its watchdog polls their events)
+                print("[rank %d] direct RCCL calls unavailable (%s); using "
+                      "torch.distributed collectives outside the captured "
+                      "step" % (self.global_rank, e), flush=True)
+                self._rccl = None
+                self._no_direct = True
+                self.capturable = False
         probe = os.environ.get("SINGA_DIST_CAPTURE_PROBE", "1")
         if self.capturable and self._rccl is not None and probe != "0" and \
                 (self.world_size > 1 or probe == "force"):
@@ -291,10 +303,17 @@ class Communicator(object):
                 t.dtype in _Rccl._DTYPES):
             return False
         if self._rccl is None:
+            if self._no_direct:
+                return False
             # first use is in the eager iteration that precedes any capture
             assert not torch.cuda.is_current_stream_capturing(), \
                 "the first collective of a process must not be captured"
-            self._rccl = _Rccl(t.device)
+            try:
+                self._rccl = _Rccl(t.device)
+            except (OSError, AttributeError, RuntimeError):
+                self._no_direct = True
+                self.capturable = False
+                return False
         return True
 
     def _probe_capture(self):

@@ -421,29 +421,52 @@ template <> struct Frag<__hip_bfloat16> {
   }
 };
 
-// ROWS x 64 tile of a row-major 16-bit operand -> row-major image `rm` (pitch
-// kRowPitch) and / or transposed image `tr` ([64][kTrPitch]); rows at or
-// beyond `limit` are zero.  256 threads, 16-byte global loads.
-template <typename T, int ROWS, bool RM, bool TR>
-__device__ __forceinline__ void stage16(u16 *rm, u16 *tr, const T *base,
-                                        int64_t row_stride, int first_row,
-                                        int limit, int tid) {
-#pragma unroll
-  for (int e = tid; e < ROWS * 8; e += 256) {
-    const int row = e >> 3, c = e & 7, gr = first_row + row;
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (gr < limit)
-      v = *reinterpret_cast<const u32x4 *>(base + (int64_t)gr * row_stride +
-                                           8 * c);
-    if (RM) *reinterpret_cast<u32x4 *>(rm + row * kRowPitch + 8 * c) = v;
+// A 64 x 64 tile of a row-major 16-bit operand on its way from memory to LDS:
+// `load` issues the thread's two 16-byte global loads (the same eight columns
+// of two adjacent rows; rows at or beyond `limit` are zero), `store` writes the
+// row-major image `rm` (pitch kRowPitch) and / or the transposed image `tr`
+// ([64][kTrPitch]).  Keeping the two phases apart lets the loads of the next
+// tile fly while the current one is multiplied.  The transposed image is
+// written in 32-bit words (two rows of one column): the 32 lanes of a
+// half-wave write 32 consecutive words.  256 threads.
+struct Tile16 {
+  u32x4 v0, v1;
+
+  template <typename T>
+  __device__ __forceinline__ void load(const T *base, int64_t row_stride,
+                                       int first_row, int limit, int tid) {
+    const int rp = tid & 31, c = tid >> 5;
+    const int g0 = first_row + 2 * rp;
+    v0 = u32x4{0u, 0u, 0u, 0u};
+    v1 = u32x4{0u, 0u, 0u, 0u};
+    if (g0 < limit)
+      v0 = *reinterpret_cast<const u32x4 *>(base + (int64_t)g0 * row_stride +
+                                            8 * c);
+    if (g0 + 1 < limit)
+      v1 = *reinterpret_cast<const u32x4 *>(
+          base + (int64_t)(g0 + 1) * row_stride + 8 * c);
+  }
+
+  template <bool RM, bool TR>
+  __device__ __forceinline__ void store(u16 *rm, u16 *tr, int tid) const {
+    const int rp = tid & 31, c = tid >> 5, r0 = 2 * rp;
+    if (RM) {
+      *reinterpret_cast<u32x4 *>(rm + r0 * kRowPitch + 8 * c) = v0;
+      *reinterpret_cast<u32x4 *>(rm + (r0 + 1) * kRowPitch + 8 * c) = v1;
+    }
     if (TR) {
-      u16 h[8];
-      __builtin_memcpy(h, &v, 16);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) tr[(8 * c + i) * kTrPitch + row] = h[i];
+      for (int j = 0; j < 4; ++j) {
+        const unsigned a = v0[j], b = v1[j];
+        // columns 8 c + 2 j and 8 c + 2 j + 1: (row r0 | row r0 + 1 << 16)
+        *reinterpret_cast<unsigned *>(tr + (8 * c + 2 * j) * kTrPitch + r0) =
+            (a & 0xffffu) | (b << 16);
+        *reinterpret_cast<unsigned *>(tr + (8 * c + 2 * j + 1) * kTrPitch +
+                                      r0) = (a >> 16) | (b & 0xffff0000u);
+      }
     }
   }
-}
+};
 
 // the lane's own row as the four 16-deep operands of a product over d
 template <typename T>
@@ -539,16 +562,30 @@ __global__ void __launch_bounds__(256) attn16_query_kernel(AttnArgs a) {
   for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
   float m_run = kMasked, l_run = 0.f;
 
+  // The forward kernel keeps the next chunk of K and V in flight while it
+  // multiplies the current one; the dQ kernel has no registers to spare for
+  // that at three waves per SIMD and loads each chunk when it needs it.
+  Tile16 kt_, vt_;
+  if (MODE == 0) {
+    kt_.load<T>(kp, a.k_ss, 0, a.Sk, tid);
+    vt_.load<T>(vp, a.v_ss, 0, a.Sk, tid);
+  }
   for (int c0 = 0; c0 < a.Sk; c0 += 64) {
     __syncthreads();  // the previous chunk has been consumed by every wave
     if (MODE == 0) {
-      stage16<T, 64, true, false>(Ks, nullptr, kp, a.k_ss, c0, a.Sk, tid);
-      stage16<T, 64, false, true>(nullptr, Mt, vp, a.v_ss, c0, a.Sk, tid);
+      kt_.store<true, false>(Ks, nullptr, tid);
+      vt_.store<false, true>(nullptr, Mt, tid);
     } else {
-      stage16<T, 64, true, true>(Ks, Mt, kp, a.k_ss, c0, a.Sk, tid);
-      stage16<T, 64, true, false>(Vs, nullptr, vp, a.v_ss, c0, a.Sk, tid);
+      kt_.load<T>(kp, a.k_ss, c0, a.Sk, tid);
+      vt_.load<T>(vp, a.v_ss, c0, a.Sk, tid);
+      kt_.store<true, true>(Ks, Mt, tid);
+      vt_.store<true, false>(Vs, nullptr, tid);
     }
     __syncthreads();
+    if (MODE == 0 && c0 + 64 < a.Sk) {
+      kt_.load<T>(kp, a.k_ss, c0 + 64, a.Sk, tid);
+      vt_.load<T>(vp, a.v_ss, c0 + 64, a.Sk, tid);
+    }
 #pragma unroll 1
     for (int kt = 0; kt < 2; ++kt) {
       const int kb = c0 + 32 * kt;
@@ -664,16 +701,23 @@ __global__ void __launch_bounds__(256) attn16_key_kernel(AttnArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) dk0[r] = dk1[r] = dv0[r] = dv1[r] = 0.f;
 
+  Tile16 qt_, dt_;  // the next chunk of Q and dO, in flight
+  qt_.load<T>(qp, a.q_ss, 0, a.Sq, tid);
+  dt_.load<T>(dop, do_ss, 0, a.Sq, tid);
   for (int q0 = 0; q0 < a.Sq; q0 += 64) {
     __syncthreads();
-    stage16<T, 64, true, true>(Qs, Qt, qp, a.q_ss, q0, a.Sq, tid);
-    stage16<T, 64, true, true>(Ds, Dt, dop, do_ss, q0, a.Sq, tid);
+    qt_.store<true, true>(Qs, Qt, tid);
+    dt_.store<true, true>(Ds, Dt, tid);
     if (tid < 64) {
       const bool ok = q0 + tid < a.Sq;
       Lq[tid] = ok ? a.lse[sbase + q0 + tid] : 0.f;
       Dq[tid] = ok ? a.delta[sbase + q0 + tid] : 0.f;
     }
     __syncthreads();
+    if (q0 + 64 < a.Sq) {
+      qt_.load<T>(qp, a.q_ss, q0 + 64, a.Sq, tid);
+      dt_.load<T>(dop, do_ss, q0 + 64, a.Sq, tid);
+    }
 #pragma unroll 1
     for (int qt = 0; qt < 2; ++qt) {
       const int qb = q0 + 32 * qt;

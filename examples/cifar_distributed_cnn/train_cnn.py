@@ -19,7 +19,22 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [os.path.join(_HERE, "..", "cnn"), os.path.join(_HERE, ".."),
                 os.path.join(_HERE, "..", "..")]
 
-import train_cnn as base  # noqa: E402  (examples/cnn/train_cnn.py)
+import importlib.util  # noqa: E402
+
+
+def _load_base():
+    """examples/cnn/train_cnn.py under a name of its own: this file has the
+    same module name, so a plain import would find this file again when it
+    is imported by train_mpi.py / train_multiprocess.py."""
+    spec = importlib.util.spec_from_file_location(
+        "cnn_train_cnn", os.path.join(_HERE, "..", "cnn", "train_cnn.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["cnn_train_cnn"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+base = _load_base()
 from singa_amd import opt, tensor  # noqa: E402
 import data as datasets  # noqa: E402
 

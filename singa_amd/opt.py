@@ -566,13 +566,27 @@ class DistOpt(object):
         wire (optionally clipped first)."""
 
         def prepare(p, g):
-            assert p.dtype == tensor.float32, \
-                'fp16 transport is for float32 gradients (got %s)' % p.dtype
             return autograd.clip(g, -clip_Value, clip_Value) if clipping \
                 else g
 
-        self.update_many(self._exchange(loss, threshold, self.all_reduce_half,
-                                        self.fused_all_reduce_half, prepare))
+        # gradients that already are 16-bit (a model trained in fp16 / bf16)
+        # travel as they are; only float32 ones are converted for the wire
+        def is_f32(t):
+            return t.data_type() == tensor.float32
+
+        def single(t):
+            (self.all_reduce_half if is_f32(t) else self.all_reduce)(t)
+
+        def fused(members, send=True):
+            wide = [t for t in members if is_f32(t)]
+            narrow = [t for t in members if not is_f32(t)]
+            if wide:
+                self.fused_all_reduce_half(wide, send=send)
+            if narrow:
+                self.fused_all_reduce(narrow, send=send)
+
+        self.update_many(self._exchange(loss, threshold, single, fused,
+                                        prepare))
         self.opt.step()
 
     def backward_and_partial_update(self, loss, threshold=2097152):

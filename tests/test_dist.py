@@ -270,6 +270,7 @@ def test_distopt_partial_update_runs_and_syncs():
 @pytest.mark.gpu
 @pytest.mark.parametrize("option,dtype,verbosity", [
     ("plain", "fp32", 0), ("plain", "fp16", 0), ("half", "fp32", 0),
+    ("half", "fp16", 0),
     ("sparseTopK", "fp32", 0), ("sparseThreshold", "fp32", 0),
     ("plain", "fp32", 3)])
 def test_rccl_collectives_are_captured(option, dtype, verbosity):

@@ -40,6 +40,10 @@ run autograd_resnet_cifar python examples/cnn/autograd/resnet_cifar10.py -m 1 --
 run autograd_xception python examples/cnn/autograd/xceptionnet.py -n 10
 run autograd_resnet_dist python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29641 examples/cnn/autograd/resnet_dist.py -n 20
 run autograd_sparsification python -m torch.distributed.run --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29642 examples/cnn/autograd/sparsification_mnist.py -m 1 --max-batches 20
+for opt in plain half partialUpdate sparseTopK sparseThreshold; do
+  run cifar_dist_$opt env SINGA_DIST_FORCE=1 MASTER_PORT=29651 python examples/cifar_distributed_cnn/train_mpi.py resnet cifar10 -b 32 -d $opt
+done
+run cifar_dist_half_fp16 env SINGA_DIST_FORCE=1 MASTER_PORT=29652 python examples/cifar_distributed_cnn/train_mpi.py resnet cifar10 -b 32 -d half -p float16
 run onnx_zoo_resnet18 python examples/onnx/resnet18.py --repeat 10
 run onnx_zoo_mobilenet python examples/onnx/mobilenet.py --repeat 10
 run onnx_zoo_yolo python examples/onnx/tiny_yolov2.py

@@ -16,7 +16,9 @@ import time
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [os.path.join(_HERE, "..", "cnn"), os.path.join(_HERE, ".."),
+# this directory first: children started by multiprocessing inherit the path
+# and must find THIS train_cnn.py, not the one in examples/cnn
+sys.path[:0] = [_HERE, os.path.join(_HERE, ".."),
                 os.path.join(_HERE, "..", "..")]
 
 import importlib.util  # noqa: E402

@@ -27,6 +27,7 @@ over, but the data path is laid out for MI355X:
 Ring collectives over xGMI are bound by the per-link rate, not by a switch:
 fewer, larger buckets amortise the ring's latency better than many small ones.
 """
+import atexit
 import math
 import os
 import time
@@ -214,6 +215,7 @@ class Communicator(object):
                 init_method=init_method, rank=self.global_rank,
                 world_size=self.world_size)
             self._owns_group = True
+            atexit.register(self.close)
         # without a process group a lone rank's all-reduce is the identity
         self._active = dist.is_initialized()
         self._host_backend = self._active and dist.get_backend() != "nccl"
@@ -252,12 +254,21 @@ class Communicator(object):
         self._warmed = False
 
     # ------------------------------------------------------------------ helpers
-    def __del__(self):
+    def close(self):
+        """Leave the process group this communicator created (also run at
+        interpreter exit: a process that ends with the group's worker threads
+        alive aborts in their destructors)."""
         try:
             if self._owns_group and dist.is_initialized():
+                if self._gpu:
+                    torch.cuda.synchronize()
                 dist.destroy_process_group()
-        except Exception:
+            self._owns_group = False
+        except Exception:       # noqa: BLE001 (best effort at shutdown)
             pass
+
+    def __del__(self):
+        self.close()
 
     def _buffer(self, dev, slot, kind, n, tdtype):
         """Persistent scratch of this iteration slot: allocated on first use

@@ -152,3 +152,28 @@ def test_model_selection_two_phase():
         s = eng.SCORES[name]((16,), data[0][:32], data[1][:32], data[2],
                              eng.device.get_default_device())
         assert np.isfinite(s) and s > 0
+
+
+@pytest.mark.parametrize("script,args", [
+    ("cifar_distributed_cnn/train_mpi.py",
+     ["cnn", "mnist", "-b", "8", "--iters", "2"]),
+    ("cifar_distributed_cnn/train_multiprocess.py",
+     ["cnn", "mnist", "-b", "8", "--iters", "2", "-w", "2"]),
+    ("cnn/train_multiprocess.py",
+     ["cnn", "mnist", "-m", "1", "--max-batches", "2", "-w", "2"]),
+    ("cnn/train_mpi.py", ["cnn", "mnist", "-m", "1", "--max-batches", "2"]),
+])
+def test_distributed_example_launchers(script, args, tmp_path):
+    """The launcher scripts as a user starts them (own process, any working
+    directory): the harness modules import the right files, ranks started by
+    multiprocessing find them too, and the processes end cleanly."""
+    import subprocess
+    env = dict(os.environ, MASTER_PORT=str(29700 + os.getpid() % 200),
+               CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, script)] + args,
+                         cwd=str(tmp_path), env=env, capture_output=True,
+                         text=True, timeout=600)
+    tail = out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.returncode == 0, tail
+    assert "terminate called" not in tail and "Traceback" not in tail, tail
+    assert "Throughput" in out.stdout or "accuracy" in out.stdout, tail

@@ -136,6 +136,33 @@ def test_folder_dataset_with_prefetch(tmp_path, monkeypatch):
     assert val_acc > 0.6
 
 
+def test_malaria_folder_pipeline_and_models(tmp_path):
+    """Drawn stand-in dataset -> decode / resize / cache -> standardise; the
+    CNN separates the two classes within a few epochs."""
+    import subprocess
+    root = os.path.join(ROOT, "malaria_cnn")
+    code = (
+        "import sys, numpy as np; sys.argv=['x'];"
+        "sys.path.insert(0, %r); import train_cnn as t;"
+        "from data import malaria as m;"
+        "d = m.write_synthetic(%r, 96, 32);"
+        "x, y = m.load_train_data(d, (64, 64));"
+        "assert x.shape == (96, 3, 64, 64) and x.dtype == np.uint8;"
+        "assert sorted(np.bincount(y)) == [48, 48];"
+        "x2, _ = m.load_train_data(d, (64, 64));"      # from the cache file
+        "assert (x2 == x).all();"
+        "n = m.normalize(x); assert abs(float(n.mean())) < 2.5;"
+        "h = t.run(t.parse(['cnn', 'malaria', '-dir', d, '--image-size',"
+        " '64', '-m', '6', '-b', '16', '-l', '0.01']));"
+        "assert h[-1][0] < h[0][0] and h[-1][2] > 0.8, h;"
+        "h = t.run(t.parse(['mlp', 'malaria', '-dir', d, '--image-size',"
+        " '64', '-m', '1', '-b', '16']));"
+        "print('MALARIA-OK')" % (root, str(tmp_path)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True,
+                       text=True, timeout=600)
+    assert "MALARIA-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_lime_finds_the_informative_region():
     mod = _import("singa_easy", "lime")
     label, w = mod.demo()

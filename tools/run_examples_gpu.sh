@@ -45,7 +45,8 @@ for opt in plain half partialUpdate sparseTopK sparseThreshold; do
 done
 run cifar_dist_half_fp16 env SINGA_DIST_FORCE=1 MASTER_PORT=29652 python examples/cifar_distributed_cnn/train_mpi.py resnet cifar10 -b 32 -d half -p float16
 run cnn_multiprocess_gloo env SINGA_DIST_BACKEND=gloo python examples/cnn/train_multiprocess.py cnn mnist -m 1 --max-batches 5 -w 2
-run malaria python examples/malaria_cnn/train_cnn.py cnn -m 1 --max-batches 3
+run malaria python examples/malaria_cnn/train_cnn.py cnn malaria --synthetic -m 3 -b 32
+run malaria_mlp python examples/malaria_cnn/train_cnn.py mlp malaria --synthetic -m 2 -b 32
 run bloodmnist python examples/demos/Classification/BloodMnist/ClassDemo.py -m 1 --max-batches 3
 run lime python examples/singa_easy/lime.py
 run onnx_zoo_resnet18 python examples/onnx/resnet18.py --repeat 10

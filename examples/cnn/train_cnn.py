@@ -84,8 +84,11 @@ def resize_dataset(x, image_size):
 
 
 def create_device(local_rank=0):
-    if device.get_num_gpus() > 0:
-        return device.create_cuda_gpu_on(local_rank)
+    gpus = device.get_num_gpus()
+    if gpus > 0:
+        # more ranks than GPUs only happens in a rehearsal over gloo, where
+        # the ranks may share a card
+        return device.create_cuda_gpu_on(local_rank % gpus)
     return device.get_default_device()
 
 

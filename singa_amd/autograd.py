@@ -1969,7 +1969,14 @@ class NonZero(_NoGrad):
 
 
 class ScatterElements(Operator):
-    """ONNX ScatterElements with host-side indices / updates."""
+    """ONNX ScatterElements for any rank: ``y = x`` except
+    ``y[.., indices[p], ..] = updates[p]`` along ``axis``.  The index tensor
+    is host data (an ONNX initializer); it is turned once into flat offsets,
+    of which the last write to a cell wins, and the data itself never leaves
+    the device: one scatter kernel places the updates, one builds the mask of
+    untouched cells, which is also the gradient of ``x``.  (The reference's
+    python/singa/autograd.py:5555-5641 copies x to the host and loops over a
+    2-d index.)"""
 
     def __init__(self, indices, updates, axis=0):
         super(ScatterElements, self).__init__()
@@ -1977,59 +1984,68 @@ class ScatterElements(Operator):
         self.updates = updates
         self.axis = axis
 
+    def _offsets(self, x_shape):
+        """(flat offsets into x, positions in the flattened updates)."""
+        idx = self.indices
+        if isinstance(idx, Tensor):
+            idx = tensor.to_numpy(idx)
+        idx = np.asarray(idx).astype(np.int64)
+        rank = len(x_shape)
+        assert idx.ndim == rank, (
+            "indices have rank %d, the input rank %d" % (idx.ndim, rank))
+        assert -rank <= self.axis < rank, "axis %d out of range" % self.axis
+        axis = self.axis % rank
+        extent = x_shape[axis]
+        assert ((idx >= -extent) & (idx < extent)).all(), (
+            "indices must lie in [%d, %d]" % (-extent, extent - 1))
+        assert all(i <= d for i, d in zip(idx.shape, x_shape)), \
+            "indices reach outside the input"
+        coords = list(np.indices(idx.shape))
+        coords[axis] = np.where(idx < 0, idx + extent, idx)
+        flat = np.ravel_multi_index(coords, x_shape).reshape(-1)
+        # keep the last occurrence of every target cell
+        _, first_rev = np.unique(flat[::-1], return_index=True)
+        keep = np.sort(flat.size - 1 - first_rev)
+        return flat[keep].astype(np.int32), keep.astype(np.int32)
+
     def forward(self, x):
-        x_shape = x.shape()
-        x_rank = len(x_shape)
-        if isinstance(self.indices, Tensor):
-            self.indices = tensor.to_numpy(self.indices)
-        elif isinstance(self.indices, (list, tuple)):
-            self.indices = np.array(self.indices)
-        if isinstance(self.updates, Tensor):
-            self.updates = tensor.to_numpy(self.updates)
-        elif isinstance(self.updates, (list, tuple)):
-            self.updates = np.array(self.updates)
-        self.updates.astype(np.int32)
-        _x = tensor.to_numpy(tensor.from_raw_tensor(x))
-        _x = _x.astype(np.float32)
-
-        assert x_rank == 2, "Only support 2D input."
-        assert x_rank == len(
-            self.indices.shape
-        ), "Index should have the same number of dimensions as output"
-        assert -x_rank < self.axis <= x_rank, "Axis is out of range"
-        assert np.logical_and(
-            -_x.shape[self.axis] < self.indices,
-            self.indices <= _x.shape[self.axis]).all(
-            ), "The values of the indexes should be between %d and %d" % (
-                -_x.shape[self.axis], _x.shape[self.axis] - 1)
-
-        self.axis = self.axis % x_rank
-        u_shape = self.updates.shape
-        y = _x.copy()
-        for i in range(u_shape[0]):
-            for j in range(u_shape[1]):
-                idx = int(self.indices[i][j])
-                if self.axis == 1:
-                    y[i][idx] = self.updates[i][j]
-                else:
-                    y[idx][j] = self.updates[i][j]
-        y = tensor.from_numpy(y)
-        y.to_device(x.device())
-        return y.data
+        shape = list(x.shape())
+        n = int(np.prod(shape))
+        dev = x.device()
+        flat, which = self._offsets(shape)
+        upd = self.updates
+        if isinstance(upd, Tensor):
+            chosen = singa.IndexSelect(
+                singa.Reshape(upd.data, [upd.size()]), 0,
+                _device_ints(which, dev))
+        else:
+            chosen = tensor.from_numpy(
+                np.asarray(upd, np.float32).reshape(-1)[which]).data
+            chosen.ToDevice(dev)
+        if chosen.data_type() != x.data_type():
+            chosen = chosen.AsType(x.data_type())
+        k = int(flat.size)
+        where = _device_ints(flat, dev)
+        placed = singa.ScatterAddRows(singa.Reshape(chosen, [k, 1]), where,
+                                      [n, 1])
+        ones = CTensor([k, 1], dev, x.data_type())
+        ones.SetFloatValue(1.0)
+        hit = singa.ScatterAddRows(ones, where, [n, 1])
+        untouched = singa.Reshape(
+            singa.AddFloat(singa.MultFloat(hit, -1.0), 1.0), shape)
+        if training:
+            self.untouched = untouched
+        return singa.__add__(singa.__mul__(x, untouched),
+                             singa.Reshape(placed, shape))
 
     def backward(self, dy):
-        mask = np.ones(dy.shape(), dtype=np.float32)
-        u_shape = self.updates.shape
-        for i in range(u_shape[0]):
-            for j in range(u_shape[1]):
-                idx = int(self.indices[i][j])
-                if self.axis == 1:
-                    mask[i][idx] = 0.
-                else:
-                    mask[idx][j] = 0.
-        mask = tensor.from_numpy(mask)
-        mask.to_device(dy.device())
-        return singa.__mul__(dy, mask.data)
+        return singa.__mul__(dy, self.untouched)
+
+
+def _device_ints(values, dev):
+    t = tensor.from_numpy(np.ascontiguousarray(values, dtype=np.int32))
+    t.to_device(dev)
+    return t.data
 
 
 def scatter_elements(x, indices, updates, axis=0):

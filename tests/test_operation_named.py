@@ -279,6 +279,30 @@ def test_scatter_elements(dev, axis):
     np.testing.assert_allclose(tensor.to_numpy(y), want, rtol=1e-6)
 
 
+def test_scatter_elements_rank3_repeats_and_gradient(dev):
+    """Any rank, negative indices, a cell written twice (the later update
+    stays), updates on the device; the input's gradient is zero exactly where
+    a value was replaced."""
+    x = RS.randn(3, 4, 5).astype(np.float32)
+    idx = RS.randint(-4, 4, (2, 4, 3))
+    idx[1, 2, 1] = idx[0, 2, 1]                 # no clash: different rows
+    idx[0, 1, :] = [2, -2, 2]                   # axis 1: cells written twice
+    upd = RS.randn(2, 4, 3).astype(np.float32)
+    want, touched = x.copy(), np.zeros(x.shape, bool)
+    for i in range(2):
+        for j in range(4):
+            for k in range(3):
+                want[i, idx[i, j, k] % 4, k] = upd[i, j, k]
+                touched[i, idx[i, j, k] % 4, k] = True
+    tx = to_t(x, dev)
+    y = autograd.scatter_elements(tx, idx, to_t(upd, dev, False), 1)
+    np.testing.assert_allclose(tensor.to_numpy(y), want, rtol=1e-6)
+    w = to_t(RS.uniform(0.5, 1.5, x.shape).astype(np.float32), dev, False)
+    grads = {id(p): g for p, g in autograd.backward(scalar_loss(y, w))}
+    g = tensor.to_numpy(grads[id(tx)])
+    assert (g[touched] == 0).all() and (g[~touched] != 0).all()
+
+
 def test_nonzero(dev):
     x = np.array([[1, 0, 2], [0, 0, 3]], np.float32)
     autograd.training = False

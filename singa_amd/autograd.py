@@ -2179,11 +2179,12 @@ class _Conv2d(Operator):
             self, "inputs"), "Please set training as True before do BP. "
         dx = None
         if self.x_needs_grad[0]:
-            dx = singa.ConvBackwardx(dy, self.inputs[1], self.inputs[0],
-                                     self.handle, self.dx_addend)
+            dx, dW = singa.ConvBackwardxW(dy, self.inputs[1], self.inputs[0],
+                                          self.handle, self.dx_addend)
             self.dx_addend = None
-        dW = singa.ConvBackwardW(dy, self.inputs[0], self.inputs[1],
-                                 self.handle)
+        else:
+            dW = singa.ConvBackwardW(dy, self.inputs[0], self.inputs[1],
+                                     self.handle)
         db = singa.ConvBackwardb(dy, self.inputs[2], self.handle) \
             if self.handle.bias_term else None
         if dx is not None and self.odd_padding != (0, 0, 0, 0):

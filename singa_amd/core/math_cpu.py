@@ -230,12 +230,14 @@ class CpuMath(object):
             stats[:K] += d.sum(dim=(0, 2, 3))
             stats[K:2 * K] += (d * d).sum(dim=(0, 2, 3))
 
-    def conv_bwd_data(self, dy, w, dx, stride, pad, groups, addend=None):
+    def conv_bwd_data(self, dy, w, dx, stride, pad, groups, addend=None,
+                      side_zero=None):
         r = torch.nn.grad.conv2d_input(dx.shape, w, dy, stride=stride,
                                        padding=pad, groups=groups)
         dx.copy_(r if addend is None else r + addend)
+        return False
 
-    def conv_bwd_weight(self, dy, x, dw, stride, pad, groups):
+    def conv_bwd_weight(self, dy, x, dw, stride, pad, groups, zeroed=False):
         r = torch.nn.grad.conv2d_weight(x, dw.shape, dy, stride=stride,
                                         padding=pad, groups=groups)
         dw.copy_(r)

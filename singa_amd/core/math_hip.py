@@ -94,6 +94,8 @@ _CONV_FLAT_MAX_HW = int(os.environ.get("SINGA_CONV_FLAT_MAX_HW", "399"))
 _CONV_FLAT_MIN_HW_3X3 = int(os.environ.get("SINGA_CONV_FLAT_MIN_HW_3X3", "64"))
 _CONV_S2_GATHER = os.environ.get("SINGA_CONV_S2_GATHER", "1") != "0"
 _CONV_WGRAD_GEMM = os.environ.get("SINGA_CONV_WGRAD_GEMM", "1") != "0"
+# the backward-data launch of a layer also clears the layer's weight gradient
+_CONV_SIDE_ZERO = os.environ.get("SINGA_CONV_SIDE_ZERO", "1") != "0"
 _CONV3X3_GEMM_MIN_HW = int(os.environ.get("SINGA_CONV3X3_GEMM_MIN_HW", "2000"))
 
 def _raw_stream(index):
@@ -821,10 +823,13 @@ class HipMath(object):
             return True
         return self._flat16(0, x, w, None, y, stride, pad, groups)
 
-    def conv_bwd_data(self, dy, w, dx, stride, pad, groups, addend=None):
+    def conv_bwd_data(self, dy, w, dx, stride, pad, groups, addend=None,
+                      side_zero=None):
         """dx = backward-data(dy, w) [+ addend]: the sum with a gradient that
         reached the same input along another path happens in the kernel's
-        epilogue instead of in a separate pass over dx."""
+        epilogue instead of in a separate pass over dx.  ``side_zero`` is a
+        float tensor (the layer's weight gradient) that the launch may clear
+        on the side; returns True when it did."""
         w = self._contig(w)
         if addend is not None:
             assert addend.shape == dx.shape and addend.dtype == dx.dtype \
@@ -874,6 +879,11 @@ class HipMath(object):
         self._tuned(1, g, key,
                     lambda gg: self.k.conv_bwd_data(code, gg, *args,
                                                     self._s()))
+        cleared = False
+        if side_zero is not None and side_zero.dtype == torch.float32 and \
+                side_zero.is_contiguous() and _CONV_SIDE_ZERO:
+            g.set_side_zero(side_zero.data_ptr(), side_zero.numel())
+            cleared = True
         if addend is None:
             self.k.conv_bwd_data(code, g, *args, self._s())
         else:
@@ -882,6 +892,7 @@ class HipMath(object):
             addend = self._contig(addend)
             self.k.conv_bwd_data_acc(code, g, args[0], args[1],
                                      addend.data_ptr(), args[2], self._s())
+        return cleared
 
     def _wgrad16(self, dy, x, dw, stride, pad, groups):
         """16-bit weight gradient of a 1x1 or 3x3 / pad 1 stride-1 convolution
@@ -908,7 +919,9 @@ class HipMath(object):
             _code(x), N, C, K, H, W, taps, dy.data_ptr(), x.data_ptr(),
             part.data_ptr(), splits, dw.data_ptr(), self._s())
 
-    def conv_bwd_weight(self, dy, x, dw, stride, pad, groups):
+    def conv_bwd_weight(self, dy, x, dw, stride, pad, groups, zeroed=False):
+        """``zeroed``: dw already holds zeros (cleared by the backward-data
+        launch of the same layer)."""
         if self._strided_pointwise16(x, dw, stride, pad, groups) and \
                 _CONV_WGRAD_GEMM and dw.dtype == x.dtype and \
                 self.k.conv_wgrad_h16_splits(
@@ -931,6 +944,7 @@ class HipMath(object):
         self._tuned(2, g, key,
                     lambda gg: self.k.conv_bwd_weight(code, gg, *args,
                                                       self._s()))
+        g.out_zeroed = bool(zeroed) and acc is dw
         self.k.conv_bwd_weight(code, g, *args, self._s())
         if dw.dtype != torch.float32:
             self.copy(acc, dw)

@@ -191,6 +191,33 @@ def ConvBackwardx(dy, W, x, ch, addend=None):
     return dx
 
 
+def ConvBackwardxW(dy, W, x, ch, addend=None):
+    """(dx, dW) of one layer as one recorded operation: the data-gradient
+    launch clears dW on the side where the backend supports it, so the
+    weight-gradient launch accumulates its partial sums without a zero-fill
+    pass of its own."""
+    d = dy if dy.is_contiguous() else Contiguous(dy)
+    xs = x if x.is_contiguous() else Contiguous(x)
+    dx = Tensor(x.shape(), x.device(), x.data_type())
+    dW = Tensor(W.shape(), W.device(), W.data_type())
+    st, pd, g = (ch.stride_h, ch.stride_w), (ch.pad_h, ch.pad_w), ch.group
+    reads = [d, W, xs]
+    if addend is not None:
+        reads.append(addend if addend.is_contiguous() else Contiguous(addend))
+
+    def body(a, w, xx, *rest):
+        p, odx, odw = (rest[0], rest[1], rest[2]) if len(rest) == 3 else \
+            (None, rest[0], rest[1])
+        m = a._dev.math
+        cleared = m.conv_bwd_data(a.view(), w.view(), odx.view(), st, pd, g,
+                                  None if p is None else p.view(),
+                                  side_zero=odw.view())
+        m.conv_bwd_weight(a.view(), xx.view(), odw.view(), st, pd, g,
+                          zeroed=bool(cleared))
+    _submit(x.device(), "ConvBackwardxW", body, reads, [dx, dW])
+    return dx, dW
+
+
 def ConvBackwardW(dy, x, W, ch):
     d = dy if dy.is_contiguous() else Contiguous(dy)
     xs = x if x.is_contiguous() else Contiguous(x)
@@ -215,6 +242,7 @@ def ConvBackwardb(dy, b, ch):
 CpuConvForward = GpuConvForward = ConvForward
 CpuConvBackwardx = GpuConvBackwardx = ConvBackwardx
 CpuConvBackwardW = GpuConvBackwardW = ConvBackwardW
+CpuConvBackwardxW = GpuConvBackwardxW = ConvBackwardxW
 CpuConvBackwardb = GpuConvBackwardb = ConvBackwardb
 
 

@@ -252,6 +252,11 @@ PYBIND11_MODULE(_hip, m) {
         g.scratch = reinterpret_cast<float *>(p);
         g.scratch_elems = elems;
       })
+      .def("set_side_zero", [](ConvGeom &g, uintptr_t p, int64_t words) {
+        g.side_zero = reinterpret_cast<uint32_t *>(p);
+        g.side_zero_words = words;
+      })
+      .def_readwrite("out_zeroed", &ConvGeom::out_zeroed)
       .def("set_stats", [](ConvGeom &g, uintptr_t stats, uintptr_t shift) {
         g.stats = reinterpret_cast<float *>(stats);
         g.stats_shift = reinterpret_cast<const float *>(shift);

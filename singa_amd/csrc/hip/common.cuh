@@ -117,6 +117,27 @@ __global__ static void zero_words_kernel(uint32_t *__restrict__ p, int64_t words
   }
 }
 
+// The whole grid clears `words` 32-bit words at p as a side job of a kernel
+// whose own work is unrelated; every workgroup takes a strided share.
+__device__ __forceinline__ void grid_zero_words(uint32_t *__restrict__ p,
+                                                int64_t words) {
+  const int64_t blocks = (int64_t)gridDim.x * gridDim.y * gridDim.z;
+  const int64_t block =
+      blockIdx.x + (int64_t)gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z);
+  const int threads = blockDim.x * blockDim.y * blockDim.z;
+  const int t = threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z);
+  const int64_t step = blocks * threads;
+  const int64_t first = block * threads + t;
+  if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    uint4 *p4 = reinterpret_cast<uint4 *>(p);
+    const int64_t n4 = words >> 2;
+    for (int64_t j = first; j < n4; j += step) p4[j] = make_uint4(0, 0, 0, 0);
+    for (int64_t j = (n4 << 2) + first; j < words; j += step) p[j] = 0;
+  } else {
+    for (int64_t j = first; j < words; j += step) p[j] = 0;
+  }
+}
+
 __global__ static void copy_words_kernel(uint32_t *__restrict__ d,
                                          const uint32_t *__restrict__ s,
                                          int64_t words,

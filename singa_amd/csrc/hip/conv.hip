@@ -236,6 +236,9 @@ conv_igemm_kernel(ConvArgs a) {
   const ConvGeom &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
+  if constexpr (MODE == CONV_BWD_DATA) {
+    if (g.side_zero) grid_zero_words(g.side_zero, g.side_zero_words);
+  }
 #ifdef SA_CONV_PROF
   unsigned long long pf_plan = 0, pf_mma = 0, pf_store = 0, pf_bar = 0;
 #endif
@@ -1011,7 +1014,7 @@ void launch_conv(ConvArgs &a, int64_t out_elems, bool clear, hipStream_t s,
     const size_t bytes = (size_t)out_elems * sizeof(float);
     if (MODE == CONV_BWD_DATA && a.addend && a.addend != a.out)
       copy_async(a.out, a.addend, bytes, s);
-    else
+    else if (!(MODE == CONV_BWD_WEIGHT && g.out_zeroed))
       zero_async(a.out, bytes, s);
   }
   bool v1 = false;
@@ -1150,8 +1153,10 @@ int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
                          hipStream_t s) {
   if (!geom_ok(g)) return -2;
   if (addend == dx) return -2;
-  if (sa_dwconv_applies(g))
+  if (sa_dwconv_applies(g)) {
+    if (g->side_zero) zero_async(g->side_zero, (size_t)g->side_zero_words * 4, s);
     return sa_dwconv_bwd_data(dtype, g, dy, w, addend, dx, s);
+  }
   if (sa_conv3x3_applies(dtype, g, g->K))
     return sa_conv3x3_bwd_data(g, dy, w, addend, dx, s);
   ConvArgs base = make_args(*g, CONV_BWD_DATA);
@@ -1201,8 +1206,11 @@ int sa_conv_bwd_data_acc(int dtype, const ConvGeom *g, const void *dy,
       zero_async(dx, bytes, s);
     zeroed = true;
   }
+  if (classes.empty() && g->side_zero)
+    zero_async(g->side_zero, (size_t)g->side_zero_words * 4, s);
   for (size_t first = 0; first < classes.size(); first += 4) {
     ConvArgs a = base;
+    if (first > 0) a.g.side_zero = nullptr;   // the first launch clears it
     a.ncls = (int)std::min<size_t>(4, classes.size() - first);
     a.Ngemm = a.Kgemm = 0;
     for (int i = 0; i < a.ncls; ++i) {

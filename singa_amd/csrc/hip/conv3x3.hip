@@ -39,6 +39,9 @@ struct Halo3Args {
   // forward: batch-norm statistics of the output (see ConvGeom::stats)
   float *stats;
   const float *shift;
+  // backward-data: words the grid clears on the side (ConvGeom::side_zero)
+  uint32_t *side_zero;
+  int64_t side_zero_words;
 };
 
 constexpr int kH3Chunk = 8;     // input channels per LDS stage
@@ -94,6 +97,9 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(Halo3Args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n31 = lane & 31, kh = lane >> 5;
+  if constexpr (MODE == 1) {
+    if (a.side_zero) grid_zero_words(a.side_zero, a.side_zero_words);
+  }
   const int per_m = a.tiles_h * a.N;
   const int mt = blockIdx.x / per_m;
   const int rem = blockIdx.x - mt * per_m;
@@ -362,5 +368,6 @@ int sa_conv3x3_bwd_data(const ConvGeom *g, const void *dy, const void *w,
   a.in = (const float *)dy; a.w = (const float *)w; a.bias = nullptr;
   a.addend = (const float *)addend; a.out = (float *)dx;
   a.N = g->N; a.Cin = g->K; a.Cout = g->C; a.H = g->H;
+  a.side_zero = g->side_zero; a.side_zero_words = g->side_zero_words;
   return run_halo3(g, a, 1, s);
 }

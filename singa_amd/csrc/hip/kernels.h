@@ -187,6 +187,14 @@ struct ConvGeom {
   // copies of [0][k] and [1][k]; shift is float[K].
   float *stats = nullptr;
   const float *stats_shift = nullptr;
+  // backward-data only: a buffer of 32-bit words that the launch also clears
+  // (the weight gradient of the same layer, which the weight-gradient launch
+  // that follows accumulates into with atomics): saves that launch a
+  // zero-fill pass of its own.  Cleared whenever the call returns 0.
+  uint32_t *side_zero = nullptr;
+  int64_t side_zero_words = 0;
+  // backward-weight only: dw is known to hold zeros already
+  bool out_zeroed = false;
 };
 // copies of the statistics rows (spreads same-address atomics; one per XCD)
 constexpr int kStatCopies = 8;

@@ -239,6 +239,41 @@ __global__ void bn_infer_kernel(const T *__restrict__ x,
   }
 }
 
+// VEC consecutive elements per thread (HW % VEC == 0, so they share a channel
+// and the per-channel factors are formed once per vector); one load and one
+// store of VEC * sizeof(T) bytes per tensor.
+template <typename T, int VEC>
+__global__ void bn_infer_vec_kernel(const T *__restrict__ x,
+                                    const float *__restrict__ scale,
+                                    const float *__restrict__ bias,
+                                    const float *__restrict__ rmean,
+                                    const float *__restrict__ rvar, float eps,
+                                    T *__restrict__ y, int64_t units, int C,
+                                    Div32 div_per, Div32 div_c, int act,
+                                    const T *__restrict__ res) {
+  struct alignas(sizeof(T) * VEC) Pack { T v[VEC]; };
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < units;
+       u += step) {
+    uint32_t nc, in_plane, n, c;
+    div_per.divmod((uint32_t)u, nc, in_plane);
+    div_c.divmod(nc, n, c);
+    const float g = scale[c] * rsqrtf(rvar[c] + eps);
+    const float b = fmaf(-rmean[c], g, bias[c]);
+    const Pack xv = reinterpret_cast<const Pack *>(x)[u];
+    Pack rv, out;
+    if (act == 2) rv = reinterpret_cast<const Pack *>(res)[u];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float z = fmaf(to_f<T>(xv.v[j]), g, b);
+      if (act == 2) z += to_f<T>(rv.v[j]);
+      if (act >= 1) z = fmaxf(z, 0.f);
+      out.v[j] = from_f<T>(z);
+    }
+    reinterpret_cast<Pack *>(y)[u] = out;
+  }
+}
+
 // pass 1 of backward: sum(dy), sum(dy * xhat).  With an activation the
 // incoming gradient is first masked by (output > 0): for ACT 1 the output sign
 // is recomputed from x (no extra tensor is read), for ACT 2 the saved output y
@@ -673,6 +708,37 @@ int sa_bn_fwd_infer_act(int dtype, const void *x, const float *scale,
   if (total <= 0) return 0;
   if (total >= ((int64_t)1 << 31)) return -2;
   if (act == 2 && residual == nullptr) return -5;
+  {
+    // widest vector (16 bytes at most) that divides the plane and keeps
+    // every access aligned
+    const int es = dtype == kF32 ? 4 : 2;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(x) |
+                           reinterpret_cast<uintptr_t>(y) |
+                           reinterpret_cast<uintptr_t>(residual);
+    int vec = 16 / es;
+    while (vec > 1 && (HW % vec != 0 || (bits & (uintptr_t)(vec * es - 1))))
+      vec >>= 1;
+    if (vec >= 4) {
+      const int64_t units = total / vec;
+      SA_DISPATCH_FLOAT(dtype, T, {
+        if (vec == 8) {
+          if constexpr (sizeof(T) == 2)
+            hipLaunchKernelGGL((bn_infer_vec_kernel<T, 8>),
+                               dim3(grid_for(units, 256, 2)), dim3(256), 0, s,
+                               (const T *)x, scale, bias, rmean, rvar, eps,
+                               (T *)y, units, C, Div32(HW / 8), Div32(C), act,
+                               (const T *)residual);
+        } else {
+          hipLaunchKernelGGL((bn_infer_vec_kernel<T, 4>),
+                             dim3(grid_for(units, 256, 2)), dim3(256), 0, s,
+                             (const T *)x, scale, bias, rmean, rvar, eps,
+                             (T *)y, units, C, Div32(HW / 4), Div32(C), act,
+                             (const T *)residual);
+        }
+      });
+      return 0;
+    }
+  }
   SA_DISPATCH_FLOAT(dtype, T, {
     hipLaunchKernelGGL((bn_infer_kernel<T>), dim3(grid_for(total, 256, 4)),
                        dim3(256), 0, s, (const T *)x, scale, bias, rmean, rvar,

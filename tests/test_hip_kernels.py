@@ -749,6 +749,38 @@ def test_batchnorm(maths, shape):
                                rtol=1e-4)
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(3, 16, 56, 56), (2, 24, 14, 14),
+                                   (4, 32, 7, 7), (2, 5, 6, 6)])
+def test_batchnorm_inference_vector_paths(maths, shape, act, dt):
+    """Running-statistics normalisation with the fused ReLU / residual:
+    planes of 3136 elements move 16 bytes per access, 196 move four elements,
+    49 and 36 (odd / unaligned in 16 bits) take the scalar kernel."""
+    hm, cm, dev = maths
+    C = shape[1]
+    d = dev.torch_device
+    x = rnd(*shape, seed=140, lo=-2, hi=3)
+    res = rnd(*shape, seed=141)
+    scale, bias = rnd(C, seed=142, lo=0.5, hi=1.5), rnd(C, seed=143)
+    rm, rv = rnd(C, seed=144), rnd(C, seed=145, lo=0.5, hi=2.0)
+    xq, rq = x.to(dt), res.to(dt)
+    want = (xq.float() - rm[None, :, None, None]) * (
+        scale / torch.sqrt(rv + 1e-5))[None, :, None, None] + \
+        bias[None, :, None, None]
+    if act == 2:
+        want = want + rq.float()
+    if act >= 1:
+        want = want.clamp_min(0)
+    y = torch.empty(shape, dtype=dt, device=d)
+    hm.bn_fwd_infer(xq.to(d), g(scale, dev), g(bias, dev), g(rm, dev),
+                    g(rv, dev), 1e-5, y, act=act,
+                    residual=rq.to(d) if act == 2 else None)
+    tol = {torch.float32: 2e-5, torch.float16: 4e-3, torch.bfloat16: 3e-2}[dt]
+    np.testing.assert_allclose(y.float().cpu().numpy(), want.numpy(),
+                               atol=tol, rtol=tol)
+
+
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(8, 16, 14, 14), (4, 3, 33, 17),
                                    (40, 6, 56, 56), (9, 5, 61, 67)])

@@ -94,6 +94,10 @@ _CONV_FLAT_MAX_HW = int(os.environ.get("SINGA_CONV_FLAT_MAX_HW", "399"))
 _CONV_FLAT_MIN_HW_3X3 = int(os.environ.get("SINGA_CONV_FLAT_MIN_HW_3X3", "64"))
 _CONV_S2_GATHER = os.environ.get("SINGA_CONV_S2_GATHER", "1") != "0"
 _CONV_WGRAD_GEMM = os.environ.get("SINGA_CONV_WGRAD_GEMM", "1") != "0"
+# column sums (bias gradients) in one launch instead of fill + sum + convert
+_REDUCE_COLS_ONE_LAUNCH = os.environ.get("SINGA_REDUCE_COLS_ONE_LAUNCH",
+                                         "1") != "0"
+_COLS_SCRATCH = 1 << 16
 # the backward-data launch of a layer also clears the layer's weight gradient
 _CONV_SIDE_ZERO = os.environ.get("SINGA_CONV_SIDE_ZERO", "1") != "0"
 _CONV3X3_GEMM_MIN_HW = int(os.environ.get("SINGA_CONV3X3_GEMM_MIN_HW", "2000"))
@@ -111,6 +115,31 @@ class HipMath(object):
         self.k = dev.kernels
         HipMath._kernel_file = getattr(self.k, "__file__", "") or ""
         self.conv_prof = None
+        # zero-filled scratch of the one-launch column sums, per stream
+        self._cols_scratch = {}
+
+    def _column_sums(self, x, out, rows, cols):
+        """out[c] = sum over rows of x[r, c]; x contiguous float / 16-bit,
+        out contiguous float32 or of x's type.  One launch: partial sums of
+        the row slices meet in a scratch buffer that the kernel leaves
+        zeroed.  False when the shape exceeds the scratch."""
+        if not _REDUCE_COLS_ONE_LAUNCH:
+            return False
+        stream = self._s()
+        scratch = self._cols_scratch.get(stream)
+        if scratch is None:
+            d = self.dev.torch_device
+            scratch = (torch.zeros(_COLS_SCRATCH, dtype=torch.float32,
+                                   device=d),
+                       torch.zeros(_COLS_SCRATCH // 16, dtype=torch.int32,
+                                   device=d))
+            self._cols_scratch[stream] = scratch
+        sums, tickets = scratch
+        return self.k.reduce_cols_fin(
+            _code(x), x.data_ptr(), out.data_ptr(),
+            0 if out.dtype == torch.float32 else 1, rows, cols,
+            sums.data_ptr(), sums.numel(), tickets.data_ptr(),
+            tickets.numel(), stream)
 
     # ---- plumbing -----------------------------------------------------------
     def _s(self):
@@ -305,6 +334,9 @@ class HipMath(object):
             return
         # 16-bit input is read as it is; sums are accumulated in float32
         xf = x if x.dtype in _FLOATS else self._f32c(x)
+        if o.is_contiguous() and o.dtype in (torch.float32, xf.dtype) and \
+                self._column_sums(xf, o, rows, cols):
+            return
         if o.dtype == torch.float32 and o.is_contiguous():
             self.k.reduce_cols(_code(xf), xf.data_ptr(), o.data_ptr(), rows,
                                cols, self._s())
@@ -335,6 +367,10 @@ class HipMath(object):
             # leading axes: column sums of the (cols, rows) matrix
             x2 = (x if x.dtype in _FLOATS and x.is_contiguous()
                   else self._f32c(x)).reshape(cols, rows)
+            if op == "sum" and o.is_contiguous() and \
+                    o.dtype in (torch.float32, x2.dtype) and \
+                    self._column_sums(x2, o, cols, rows):
+                return
             tmp = o if (o.dtype == torch.float32 and o.is_contiguous()) \
                 else self._tmp(rows)
             self.k.reduce_cols(_code(x2), x2.data_ptr(), tmp.data_ptr(), cols,

@@ -98,6 +98,18 @@ PYBIND11_MODULE(_hip, m) {
                           int64_t cols, uintptr_t s) {
     check(sa_reduce_cols(dt, CP(x), P(out), rows, cols, S(s)), "reduce_cols");
   });
+  m.def("reduce_cols_fin", [](int dt, uintptr_t x, uintptr_t out, int out_typed,
+                              int64_t rows, int64_t cols, uintptr_t sums,
+                              int64_t sums_cap, uintptr_t tickets,
+                              int64_t tickets_cap, uintptr_t s) {
+    const int rc = sa_reduce_cols_fin(
+        dt, CP(x), P(out), out_typed, rows, cols,
+        reinterpret_cast<float *>(sums), sums_cap,
+        reinterpret_cast<unsigned *>(tickets), tickets_cap, S(s));
+    if (rc == -3) return false;   // shape beyond the scratch: caller falls back
+    check(rc, "reduce_cols_fin");
+    return true;
+  });
   m.def("reduce_all", [](int op, int dt, uintptr_t x, uintptr_t out, int64_t n,
                          uintptr_t s) {
     check(sa_reduce_all(op, dt, CP(x), P(out), n, S(s)), "reduce_all");

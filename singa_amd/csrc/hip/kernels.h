@@ -53,6 +53,15 @@ int sa_reduce_rows(int op, int dtype, const void *x, void *out, int64_t rows,
 // sa_reduce_cols_workspace).
 int sa_reduce_cols(int dtype, const void *x, void *out, int64_t rows,
                    int64_t cols, hipStream_t s);
+// The same in ONE launch for any number of row slices, with the result in
+// float (out_typed 0) or in x's type: partial sums meet in `sums` (floats,
+// zero on entry and on exit; `tickets` likewise), the last slice to arrive
+// writes the output.  The scratch serves one stream at a time.  -3: scratch
+// too small.
+int sa_reduce_cols_fin(int dtype, const void *x, void *out, int out_typed,
+                       int64_t rows, int64_t cols, float *sums,
+                       int64_t sums_cap, unsigned *tickets,
+                       int64_t tickets_cap, hipStream_t s);
 // whole-tensor reduction to one element (op: R_SUM, R_ASUM, R_SUMSQ, R_MAX,
 // R_MIN); `out` is written in the tensor's dtype, zero-initialised by the
 // launcher.

@@ -82,6 +82,56 @@ __global__ void reduce_rows_block_kernel(const T *__restrict__ x,
   }
 }
 
+// Where a workgroup's column sums go.  One row slice: straight to the typed
+// output.  Several: atomically into `sums` (float, all zero on entry); the
+// slice that arrives last at a column block (ticket counter) rounds the
+// totals into the output and puts zeros back, so the scratch is clean for the
+// next launch on the stream without a fill pass, and a 16-bit result needs no
+// conversion pass.
+struct ColsOut {
+  void *out;            // cols elements of type float (typed == 0) or T
+  float *sums;          // scratch, >= cols floats
+  unsigned *tickets;    // scratch, >= gridDim.x counters
+  int typed;
+};
+
+template <typename T>
+__device__ __forceinline__ void cols_store(const ColsOut &o, int64_t col,
+                                           float v) {
+  if (o.typed) static_cast<T *>(o.out)[col] = from_f<T>(v);
+  else static_cast<float *>(o.out)[col] = v;
+}
+
+// called by every thread of the workgroup; `mine` threads hold the sum `v` of
+// column `col`.  The scratch is only ever touched with device-scope atomics,
+// which execute at the point where the chip's eight L2 caches meet, so no
+// device-wide fence (a write-back of the whole L2 here) is needed: a thread
+// waits for the value its add returns, i.e. for the add to have been
+// performed, before the workgroup takes its ticket; the holder of the last
+// ticket therefore swaps complete totals out (and zeros in).
+template <typename T>
+__device__ __forceinline__ void cols_finish(const ColsOut &o, bool mine,
+                                            int64_t col, float v) {
+  if (gridDim.y == 1) {
+    if (mine) cols_store<T>(o, col, v);
+    return;
+  }
+  __shared__ int is_last;
+  if (mine) {
+    const float before = atomicAdd(o.sums + col, v);
+    asm volatile("" ::"v"(before) : "memory");
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(o.tickets + blockIdx.x, 1u);
+    is_last = t == gridDim.y - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  if (mine) cols_store<T>(o, col, atomicExch(o.sums + col, 0.f));
+  if (threadIdx.x == 0) atomicExch(o.tickets + blockIdx.x, 0u);
+}
+
 // column sums: block = 256 threads = 4 row-lanes x 64 columns
 template <typename T>
 __global__ void reduce_cols_kernel(const T *__restrict__ x,
@@ -162,6 +212,75 @@ reduce_cols_vec_kernel(const T *__restrict__ x, float *__restrict__ out,
         atomicAdd(out + col, v);
     }
   }
+}
+
+template <typename T>
+__global__ void reduce_cols_fin_kernel(const T *__restrict__ x, ColsOut o,
+                                       int64_t rows, int64_t cols,
+                                       int64_t rows_per_block) {
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int64_t c = (int64_t)blockIdx.x * 64 + cx;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  float acc = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + ry; r < r1; r += 4) acc += to_f<T>(x[r * cols + c]);
+  part[ry][cx] = acc;
+  __syncthreads();
+  const bool mine = ry == 0 && c < cols;
+  if (mine) acc = part[0][cx] + part[1][cx] + part[2][cx] + part[3][cx];
+  cols_finish<T>(o, mine, c, acc);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+reduce_cols_vec_fin_kernel(const T *__restrict__ x, ColsOut o, int64_t rows,
+                           int64_t cols, int64_t rows_per_block) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int W = 16 * VEC;
+  __shared__ float part[16][W + 1];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int64_t c = ((int64_t)blockIdx.x * 16 + cx) * VEC;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = min(rows, r0 + rows_per_block);
+  float acc[VEC];
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) acc[k] = 0.f;
+  if (c < cols) {
+    int64_t r = r0 + ry;
+    for (; r + 16 * 7 < r1; r += 16 * 8) {
+      uint4 w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        w[u] = *reinterpret_cast<const uint4 *>(x + (r + 16 * u) * cols + c);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        T e[VEC];
+        __builtin_memcpy(e, &w[u], 16);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) acc[k] += to_f<T>(e[k]);
+      }
+    }
+    for (; r < r1; r += 16) {
+      const uint4 w = *reinterpret_cast<const uint4 *>(x + r * cols + c);
+      T e[VEC];
+      __builtin_memcpy(e, &w, 16);
+#pragma unroll
+      for (int k = 0; k < VEC; ++k) acc[k] += to_f<T>(e[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < VEC; ++k) part[ry][cx * VEC + k] = acc[k];
+  __syncthreads();
+  const int64_t col = (int64_t)blockIdx.x * W + threadIdx.x;
+  const bool mine = threadIdx.x < W && col < cols;
+  float v = 0.f;
+  if (mine) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += part[k][threadIdx.x];
+  }
+  cols_finish<T>(o, mine, col, v);
 }
 
 template <typename T>
@@ -289,6 +408,50 @@ int sa_reduce_cols(int dtype, const void *x, void *out, int64_t rows,
     }
   });
   return 0;
+}
+
+// Column sums in one launch whatever the number of row slices: out is float
+// (out_typed == 0) or of x's type; sums / tickets are scratch buffers that
+// hold zeros on entry and again on exit, used by one stream at a time.
+// -3 when the scratch is too small for this shape.
+int sa_reduce_cols_fin(int dtype, const void *x, void *out, int out_typed,
+                       int64_t rows, int64_t cols, float *sums,
+                       int64_t sums_cap, unsigned *tickets,
+                       int64_t tickets_cap, hipStream_t s) {
+  if (cols <= 0) return 0;
+  if (cols > sums_cap) return -3;
+  int rc = 0;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    constexpr int VEC = 16 / (int)sizeof(T);
+    ColsOut o{out, sums, tickets, out_typed};
+    const bool vec = cols % VEC == 0 &&
+                     (reinterpret_cast<uintptr_t>(x) & 15) == 0;
+    if (vec) {
+      const int64_t col_blocks = (cols + 16 * VEC - 1) / (16 * VEC);
+      int64_t splits = i64min((rows + 127) / 128,
+                              i64max(1, 2048 / col_blocks));
+      const int64_t rpb = (rows + splits - 1) / splits;
+      splits = (rows + rpb - 1) / rpb;
+      if (col_blocks > tickets_cap) rc = -3;
+      else
+        hipLaunchKernelGGL((reduce_cols_vec_fin_kernel<T>),
+                           dim3((unsigned)col_blocks, (unsigned)splits),
+                           dim3(256), 0, s, (const T *)x, o, rows, cols, rpb);
+    } else {
+      const int64_t col_blocks = (cols + 63) / 64;
+      int64_t splits = 1;
+      if (rows > 256)
+        splits = i64min((rows + 255) / 256, i64max(1, 1024 / col_blocks));
+      const int64_t rpb = (rows + splits - 1) / splits;
+      splits = (rows + rpb - 1) / rpb;
+      if (col_blocks > tickets_cap) rc = -3;
+      else
+        hipLaunchKernelGGL((reduce_cols_fin_kernel<T>),
+                           dim3((unsigned)col_blocks, (unsigned)splits),
+                           dim3(256), 0, s, (const T *)x, o, rows, cols, rpb);
+    }
+  });
+  return rc;
 }
 
 int sa_reduce_all(int op, int dtype, const void *x, void *out, int64_t n,

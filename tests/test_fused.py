@@ -385,17 +385,23 @@ def test_linear_bias_forward_backward(dev, dtype_name, tol, shape):
 
 @pytest.mark.parametrize("dtype_name", ["float32", "float16", "bfloat16"])
 @pytest.mark.parametrize("rows,cols", [(1, 8), (300, 768), (1025, 36),
-                                       (700, 13)])
+                                       (700, 13), (8192, 768), (2048, 3072),
+                                       (600, 70001)])
 def test_column_sums_read_the_input_type(dev, dtype_name, rows, cols):
     """Sum over axis 0 of a matrix of any float type (float accumulation;
-    16-byte loads when the row length allows, single elements otherwise)."""
+    16-byte loads when the row length allows, single elements otherwise).
+    On the GPU the row slices of one launch meet in a scratch buffer that the
+    launch must leave clean: the sum is taken three times in a row.  70001
+    columns exceed that scratch (separate fill / sum / convert passes)."""
     from singa_amd import singa_wrap as singa
     from singa_amd import tensor
     dt = getattr(tensor, dtype_name)
     a = np.random.RandomState(1).randn(rows, cols).astype(np.float32)
     t = tensor.from_numpy(a, dev).as_type(dt)
     ref = tensor.to_numpy(t.as_type(tensor.float32)).astype(np.float64).sum(0)
-    got = tensor.to_numpy(tensor.from_raw_tensor(
-        singa.Sum(t.data, 0)).as_type(tensor.float32))
     tol = {"float32": 1e-4, "float16": 4e-3, "bfloat16": 3e-2}[dtype_name]
-    np.testing.assert_allclose(got, ref, atol=tol * max(1.0, np.abs(ref).max()))
+    for _ in range(3):
+        got = tensor.to_numpy(tensor.from_raw_tensor(
+            singa.Sum(t.data, 0)).as_type(tensor.float32))
+        np.testing.assert_allclose(got, ref,
+                                   atol=tol * max(1.0, np.abs(ref).max()))

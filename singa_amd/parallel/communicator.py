@@ -668,6 +668,8 @@ class Communicator(object):
         blocks = self._blocks
         self._blocks = []
         self._slot = 0
+        if not self._active:
+            return          # a lone rank put nothing in flight
 
         def join():
             if self._skip_body(dev):

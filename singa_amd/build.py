@@ -112,8 +112,31 @@ def build_hip(force=False, verbose=True):
     if jobs or not os.path.exists(target):
         _run(["g++", "-shared", "-o", target] + objs +
              ["-L" + os.path.join(ROCM, "lib"), "-lamdhip64",
-              "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+              "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread", "-ldl"])
     return target
+
+
+def _embed_opencl_sources(cl_dir):
+    """Write the directory's .cl files as one C string literal sequence into
+    ``cl_sources.inc`` (included by opencl/runtime.cc, which hands the text to
+    the OpenCL compiler at run time).  Role of the reference's
+    tool/opencl/clsrc_to_str.py.  Returns the .cl paths."""
+    files = sorted(os.path.join(cl_dir, f) for f in os.listdir(cl_dir)
+                   if f.endswith(".cl"))
+    lines = []
+    for path in files:
+        lines.append('"// ---- %s\\n"' % os.path.basename(path))
+        with open(path) as f:
+            for line in f.read().splitlines():
+                lines.append('"%s\\n"' % line.replace("\\", "\\\\")
+                             .replace('"', '\\"'))
+    text = "\n".join(lines) + "\n"
+    out = os.path.join(cl_dir, "cl_sources.inc")
+    old = open(out).read() if os.path.exists(out) else None
+    if old != text:
+        with open(out, "w") as f:
+            f.write(text)
+    return files
 
 
 def build_cpp(force=False, verbose=True):
@@ -126,7 +149,9 @@ def build_cpp(force=False, verbose=True):
     inc = os.path.join(cpp, "include")
     rt = os.path.join(CSRC, "runtime")
     hd = os.path.join(CSRC, "hip")
-    hdrs = _headers(inc, rt, hd)
+    cl_sources = _embed_opencl_sources(os.path.join(cpp, "src", "core", "opencl"))
+    hdrs = _headers(inc, rt, hd) + cl_sources + [
+        os.path.join(cpp, "src", "core", "opencl", "runtime.h")]
     flags = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-parameter",
              "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
              "-I" + inc]

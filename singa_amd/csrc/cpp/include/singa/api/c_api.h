@@ -27,6 +27,13 @@ const char *singa_version(void);
 int singa_num_gpus(void);
 singa_device singa_device_host(void);
 singa_device singa_device_gpu(int id);
+/* OpenCL devices (the GPUs as seen by the OpenCL runtime; 0 without one) */
+int singa_num_opencl_devices(void);
+singa_device singa_device_opencl(int id);
+/* 0 = host, 1 = HIP GPU, 2 = OpenCL */
+int singa_device_lang(singa_device d);
+/* writes a NUL-terminated description (at most n bytes), returns its length */
+int singa_device_description(singa_device d, char *buf, int n);
 void singa_device_sync(singa_device d);
 void singa_device_free(singa_device d);
 

@@ -60,6 +60,7 @@ struct Context {
   int device_id = -1;
   uint64_t seed = 0;
   int64_t *rng_state = nullptr;  // device int64[2] {seed, offset} (HIP)
+  void *cl = nullptr;            // ocl::Runtime of an OpenclDevice, else null
 };
 
 }  // namespace singa

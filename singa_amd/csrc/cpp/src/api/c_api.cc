@@ -77,6 +77,44 @@ singa_device singa_device_gpu(int id) {
       (singa_device) nullptr);
 }
 
+int singa_num_opencl_devices(void) {
+  return guarded([&] { return singa::OpenclDevice::GetNumDevices(); }, 0);
+}
+
+singa_device singa_device_opencl(int id) {
+  return guarded(
+      [&] {
+        if (id < 0 || id >= singa::OpenclDevice::GetNumDevices())
+          throw std::runtime_error("no such OpenCL device");
+        return new singa_device_s{std::make_shared<singa::OpenclDevice>(id)};
+      },
+      (singa_device) nullptr);
+}
+
+int singa_device_lang(singa_device d) {
+  return guarded([&] { return static_cast<int>(d->d->lang()); }, -1);
+}
+
+int singa_device_description(singa_device d, char *buf, int n) {
+  return guarded(
+      [&] {
+        std::string text;
+        if (d->d->lang() == singa::kOpencl)
+          text = static_cast<singa::OpenclDevice *>(d->d.get())->Description();
+        else if (d->d->lang() == singa::kCpp)
+          text = "host";
+        else
+          text = singa::Platform::DeviceQuery(d->d->id());
+        if (buf && n > 0) {
+          const int len = std::min<int>(n - 1, static_cast<int>(text.size()));
+          std::memcpy(buf, text.data(), len);
+          buf[len] = 0;
+        }
+        return static_cast<int>(text.size());
+      },
+      -1);
+}
+
 void singa_device_sync(singa_device d) {
   guarded([&] { if (d) d->d->Sync(); return 0; }, 0);
 }

@@ -7,13 +7,19 @@
 
 #include "../../../hip/kernels.h"
 #include "../../../runtime/snapshot.h"
+#include "opencl/runtime.h"
 
 namespace singa {
 
 namespace {
 
 inline hipStream_t S(Context *ctx) { return static_cast<hipStream_t>(ctx->stream); }
-#define SA_OK(expr) CHECK_EQ((expr), 0) << "kernel launcher rejected arguments"
+#define SA_OK(expr)                                                     \
+  do {                                                                  \
+    CHECK_EQ((expr), 0) << "kernel launcher rejected arguments";        \
+  } while (0)
+// the OpenCL runtime of the executing device, or null on a HIP device
+inline ocl::Runtime *CL(Context *ctx) { return static_cast<ocl::Runtime *>(ctx->cl); }
 
 float cpu_unary(int op, float x, float a, float b) {
   using namespace sa;
@@ -97,8 +103,12 @@ void Unary(int op, const Tensor &in, Tensor *out, float a = 0.f, float b = 0.f,
     }, {ib}, {ob}, name);
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_unary(op, ti, to, ib->data(), ob->mutable_data(), nullptr,
-                     static_cast<int64_t>(n), a, b, S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::unary(CL(ctx), op, ti, to, ib->data(), ob->mutable_data(),
+                         nullptr, static_cast<int64_t>(n), a, b));
+      else
+        SA_OK(sa_unary(op, ti, to, ib->data(), ob->mutable_data(), nullptr,
+                       static_cast<int64_t>(n), a, b, S(ctx)));
     }, {ib}, {ob}, name);
   }
 }
@@ -142,9 +152,14 @@ void BinaryDesc(int op, const Tensor &x, const Tensor &y, Tensor *z,
     }, {xb, yb}, {zb}, name);
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_binary(op, t, xb->data(), yb->data(), zb->mutable_data(),
-                      has_desc ? &desc : nullptr, static_cast<int64_t>(n),
-                      S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::binary(CL(ctx), op, t, xb->data(), yb->data(),
+                          zb->mutable_data(), has_desc ? &desc : nullptr,
+                          static_cast<int64_t>(n)));
+      else
+        SA_OK(sa_binary(op, t, xb->data(), yb->data(), zb->mutable_data(),
+                        has_desc ? &desc : nullptr, static_cast<int64_t>(n),
+                        S(ctx)));
     }, {xb, yb}, {zb}, name);
   }
 }
@@ -195,11 +210,15 @@ void Copy3(const Tensor &src, size_t src_off, size_t src_pitch, Tensor *dst,
     d.s1[0] = 0; d.s1[1] = 0;
     d.s2[0] = dst_pitch; d.s2[1] = 1;
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_unary(sa::U_COPY, t, t,
-                     static_cast<const char *>(sb->data()) + src_off * es,
-                     static_cast<char *>(db->mutable_data()) + dst_off * es,
-                     &d, static_cast<int64_t>(outer * len * inner), 0.f, 0.f,
-                     S(ctx)));
+      const char *from = static_cast<const char *>(sb->data()) + src_off * es;
+      char *to = static_cast<char *>(db->mutable_data()) + dst_off * es;
+      const int64_t count = static_cast<int64_t>(outer * len * inner);
+      if (CL(ctx))
+        SA_OK(ocl::unary(CL(ctx), sa::U_COPY, t, t, from, to, &d, count, 0.f,
+                         0.f));
+      else
+        SA_OK(sa_unary(sa::U_COPY, t, t, from, to, &d, count, 0.f, 0.f,
+                       S(ctx)));
     }, {sb}, {db}, name);
   }
 }
@@ -223,8 +242,12 @@ float ReduceAll(int op, const Tensor &in) {
   Tensor tmp(Shape{1}, dev, kFloat32);
   Block *tb = tmp.block();
   dev->Exec([=](Context *ctx) {
-    SA_OK(sa_reduce_all(op, kFloat32, ib->data(), tb->mutable_data(),
-                        static_cast<int64_t>(n), S(ctx)));
+    if (CL(ctx))
+      SA_OK(ocl::reduce_all(CL(ctx), op, kFloat32, ib->data(),
+                            tb->mutable_data(), static_cast<int64_t>(n)));
+    else
+      SA_OK(sa_reduce_all(op, kFloat32, ib->data(), tb->mutable_data(),
+                          static_cast<int64_t>(n), S(ctx)));
   }, {ib}, {tb}, "ReduceAll");
   float v = 0;
   tmp.GetValue(&v, 1);
@@ -378,8 +401,13 @@ Tensor Tensor::Contiguous() const {
     }, {ib}, {ob}, "Contiguous");
   } else {
     device_->Exec([=](Context *ctx) {
-      SA_OK(sa_unary(sa::U_COPY, t, t, ib->data(), ob->mutable_data(), &d,
-                     static_cast<int64_t>(n), 0, 0, S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::unary(CL(ctx), sa::U_COPY, t, t, ib->data(),
+                         ob->mutable_data(), &d, static_cast<int64_t>(n), 0,
+                         0));
+      else
+        SA_OK(sa_unary(sa::U_COPY, t, t, ib->data(), ob->mutable_data(), &d,
+                       static_cast<int64_t>(n), 0, 0, S(ctx)));
     }, {ib}, {ob}, "Contiguous");
   }
   return out;
@@ -402,7 +430,12 @@ void Tensor::SetValue(SType x) {
     }, {}, {b}, "SetValue");
   } else {
     device_->Exec([=](Context *ctx) {
-      SA_OK(sa_fill(t, b->mutable_data(), static_cast<int64_t>(n), v, S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::fill(CL(ctx), t, b->mutable_data(), static_cast<int64_t>(n),
+                        v));
+      else
+        SA_OK(sa_fill(t, b->mutable_data(), static_cast<int64_t>(n), v,
+                      S(ctx)));
     }, {}, {b}, "SetValue");
   }
 }
@@ -619,8 +652,12 @@ void SumRows(const Tensor &M, Tensor *v) {
     }, {mb}, {vb}, "SumRows");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_reduce_cols(kFloat32, mb->data(), vb->mutable_data(), nr, nc,
-                           S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::reduce_cols(CL(ctx), kFloat32, mb->data(),
+                               vb->mutable_data(), nr, nc));
+      else
+        SA_OK(sa_reduce_cols(kFloat32, mb->data(), vb->mutable_data(), nr, nc,
+                             S(ctx)));
     }, {mb}, {vb}, "SumRows");
   }
 }
@@ -646,8 +683,12 @@ static void ReduceRowsOp(int op, const Tensor &M, Tensor *v, const char *name) {
     }, {mb}, {vb}, name);
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_reduce_rows(op, kFloat32, mb->data(), vb->mutable_data(), nr,
-                           nc, S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::reduce_rows(CL(ctx), op, kFloat32, mb->data(),
+                               vb->mutable_data(), nr, nc));
+      else
+        SA_OK(sa_reduce_rows(op, kFloat32, mb->data(), vb->mutable_data(), nr,
+                             nc, S(ctx)));
     }, {mb}, {vb}, name);
   }
 }
@@ -701,8 +742,12 @@ void SoftMax(const Tensor &in, Tensor *out) {
     }, {ib}, {ob}, "SoftMax");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_softmax_fwd(kFloat32, ib->data(), ob->mutable_data(), rows,
-                           cols, S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::softmax_fwd(CL(ctx), kFloat32, ib->data(),
+                               ob->mutable_data(), rows, cols));
+      else
+        SA_OK(sa_softmax_fwd(kFloat32, ib->data(), ob->mutable_data(), rows,
+                             cols, S(ctx)));
     }, {ib}, {ob}, "SoftMax");
   }
 }
@@ -733,8 +778,12 @@ Tensor SoftMaxBackward(const Tensor &dy, const Tensor &y) {
     }, {gb, yb}, {xb}, "SoftMaxBackward");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_softmax_bwd(kFloat32, gb->data(), yb->data(),
-                           xb->mutable_data(), rows, cols, S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::softmax_bwd(CL(ctx), kFloat32, gb->data(), yb->data(),
+                               xb->mutable_data(), rows, cols));
+      else
+        SA_OK(sa_softmax_bwd(kFloat32, gb->data(), yb->data(),
+                             xb->mutable_data(), rows, cols, S(ctx)));
     }, {gb, yb}, {xb}, "SoftMaxBackward");
   }
   return dx;
@@ -785,9 +834,13 @@ void Mult(SType alpha_, const Tensor &A, const Tensor &B, SType beta_,
     }, reads, {cb}, "Mult");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_gemm(t, M, N, K, alpha, ab->data(), ars, acs, 0, bb->data(),
-                    brs, bcs, 0, beta, cb->mutable_data(), N, 0, 1, nullptr, 0,
-                    S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::gemm(CL(ctx), t, M, N, K, alpha, ab->data(), ars, acs,
+                        bb->data(), brs, bcs, beta, cb->mutable_data(), N));
+      else
+        SA_OK(sa_gemm(t, M, N, K, alpha, ab->data(), ars, acs, 0, bb->data(),
+                      brs, bcs, 0, beta, cb->mutable_data(), N, 0, 1, nullptr,
+                      0, S(ctx)));
     }, reads, {cb}, "Mult");
   }
 }
@@ -820,8 +873,12 @@ void Axpy(SType alpha_, const Tensor &in, Tensor *out) {
     }, {ib, ob}, {ob}, "Axpy");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_axpy(t, nullptr, alpha, ib->data(), ob->mutable_data(),
-                    static_cast<int64_t>(n), S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::axpy(CL(ctx), t, alpha, ib->data(), ob->mutable_data(),
+                        static_cast<int64_t>(n)));
+      else
+        SA_OK(sa_axpy(t, nullptr, alpha, ib->data(), ob->mutable_data(),
+                      static_cast<int64_t>(n), S(ctx)));
     }, {ib, ob}, {ob}, "Axpy");
   }
 }
@@ -857,8 +914,12 @@ void Bernoulli(SType p_, Tensor *out) {
   const size_t n = out->Size();
   DataType t = out->data_type();
   out->device()->Exec([=](Context *ctx) {
-    SA_OK(sa_rng_bernoulli(t, ob->mutable_data(), static_cast<int64_t>(n), p,
-                           ctx->rng_state, S(ctx)));
+    if (CL(ctx))
+      SA_OK(ocl::rng_bernoulli(CL(ctx), t, ob->mutable_data(),
+                               static_cast<int64_t>(n), p));
+    else
+      SA_OK(sa_rng_bernoulli(t, ob->mutable_data(), static_cast<int64_t>(n), p,
+                             ctx->rng_state, S(ctx)));
   }, {}, {ob}, "Bernoulli");
 }
 template void Bernoulli<float>(float, Tensor *);
@@ -876,8 +937,12 @@ void Gaussian(SType mean_, SType std_, Tensor *out) {
   const size_t n = out->Size();
   DataType t = out->data_type();
   out->device()->Exec([=](Context *ctx) {
-    SA_OK(sa_rng_normal(t, ob->mutable_data(), static_cast<int64_t>(n), mean,
-                        sd, ctx->rng_state, S(ctx)));
+    if (CL(ctx))
+      SA_OK(ocl::rng_normal(CL(ctx), t, ob->mutable_data(),
+                            static_cast<int64_t>(n), mean, sd));
+    else
+      SA_OK(sa_rng_normal(t, ob->mutable_data(), static_cast<int64_t>(n), mean,
+                          sd, ctx->rng_state, S(ctx)));
   }, {}, {ob}, "Gaussian");
 }
 template void Gaussian<float>(float, float, Tensor *);
@@ -895,8 +960,12 @@ void Uniform(SType low_, SType high_, Tensor *out) {
   const size_t n = out->Size();
   DataType t = out->data_type();
   out->device()->Exec([=](Context *ctx) {
-    SA_OK(sa_rng_uniform(t, ob->mutable_data(), static_cast<int64_t>(n), lo,
-                         hi, ctx->rng_state, S(ctx)));
+    if (CL(ctx))
+      SA_OK(ocl::rng_uniform(CL(ctx), t, ob->mutable_data(),
+                             static_cast<int64_t>(n), lo, hi));
+    else
+      SA_OK(sa_rng_uniform(t, ob->mutable_data(), static_cast<int64_t>(n), lo,
+                           hi, ctx->rng_state, S(ctx)));
   }, {}, {ob}, "Uniform");
 }
 template void Uniform<float>(float, float, Tensor *);
@@ -923,8 +992,12 @@ void ComputeCrossEntropy(const Tensor &p, const Tensor &t, Tensor *loss) {
     }, {pb, tb}, {lb}, "ComputeCrossEntropy");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_cross_entropy_fwd(kFloat32, pb->data(), tb->data(), 1, kInt,
-                                 lb->mutable_data(), rows, cols, S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::cross_entropy_fwd(CL(ctx), pb->data(), tb->data(),
+                                     lb->mutable_data(), rows, cols));
+      else
+        SA_OK(sa_cross_entropy_fwd(kFloat32, pb->data(), tb->data(), 1, kInt,
+                                   lb->mutable_data(), rows, cols, S(ctx)));
     }, {pb, tb}, {lb}, "ComputeCrossEntropy");
   }
 }
@@ -943,8 +1016,12 @@ void SoftmaxCrossEntropyBwd(const Tensor &t, Tensor *p) {
     }, {pb, tb}, {pb}, "SoftmaxCrossEntropyBwd");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_softmax_ce_bwd(kFloat32, pb->mutable_data(), tb->data(), 1,
-                              kInt, rows, cols, S(ctx)));
+      if (CL(ctx))
+        SA_OK(ocl::softmax_ce_bwd(CL(ctx), pb->mutable_data(), tb->data(),
+                                  rows, cols));
+      else
+        SA_OK(sa_softmax_ce_bwd(kFloat32, pb->mutable_data(), tb->data(), 1,
+                                kInt, rows, cols, S(ctx)));
     }, {pb, tb}, {pb}, "SoftmaxCrossEntropyBwd");
   }
 }

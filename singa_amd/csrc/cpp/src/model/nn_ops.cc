@@ -6,12 +6,19 @@
 #include <limits>
 
 #include "../../../hip/kernels.h"
+#include "../core/opencl/runtime.h"
 
 namespace singa {
 
 namespace {
 inline hipStream_t S(Context *ctx) { return static_cast<hipStream_t>(ctx->stream); }
-#define SA_OK(expr) CHECK_EQ((expr), 0) << "kernel launcher rejected arguments"
+inline ocl::Runtime *CL(Context *ctx) { return static_cast<ocl::Runtime *>(ctx->cl); }
+#define SA_OK(expr)                                                     \
+  do {                                                                  \
+    CHECK_EQ((expr), 0) << "kernel launcher rejected arguments";        \
+  } while (0)
+// the OpenCL device computes in float32 only
+#define CL_F32(t) CHECK_EQ((t), kFloat32) << "the OpenCL device computes in float32"
 constexpr float kBnEps = 1e-5f;
 
 ConvGeom MakeGeom(const Shape &x, const ConvParams &p) {
@@ -91,8 +98,15 @@ Tensor ConvForward(const Tensor &x, const Tensor &w, const Tensor *b,
     }, reads, {yb}, "ConvForward");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_conv_fwd(t, &g, xb->data(), wb->data(),
-                        bb ? bb->data() : nullptr, yb->mutable_data(), S(ctx)));
+      if (CL(ctx)) {
+        CL_F32(t);
+        SA_OK(ocl::conv_fwd(CL(ctx), &g, xb->data(), wb->data(),
+                            bb ? bb->data() : nullptr, yb->mutable_data()));
+      } else {
+        SA_OK(sa_conv_fwd(t, &g, xb->data(), wb->data(),
+                          bb ? bb->data() : nullptr, yb->mutable_data(),
+                          S(ctx)));
+      }
     }, reads, {yb}, "ConvForward");
   }
   return y;
@@ -118,8 +132,14 @@ Tensor ConvBackwardData(const Tensor &dy, const Tensor &w, const Shape &x_shape,
     }, {gb, wb}, {xb}, "ConvBackwardData");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_conv_bwd_data(t, &g, gb->data(), wb->data(),
-                             xb->mutable_data(), S(ctx)));
+      if (CL(ctx)) {
+        CL_F32(t);
+        SA_OK(ocl::conv_bwd_data(CL(ctx), &g, gb->data(), wb->data(),
+                                 xb->mutable_data()));
+      } else {
+        SA_OK(sa_conv_bwd_data(t, &g, gb->data(), wb->data(),
+                               xb->mutable_data(), S(ctx)));
+      }
     }, {gb, wb}, {xb}, "ConvBackwardData");
   }
   return dx;
@@ -145,8 +165,14 @@ Tensor ConvBackwardWeight(const Tensor &dy, const Tensor &x,
     }, {gb, xb}, {wb}, "ConvBackwardWeight");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_conv_bwd_weight(t, &g, gb->data(), xb->data(),
-                               wb->mutable_data(), S(ctx)));
+      if (CL(ctx)) {
+        CL_F32(t);
+        SA_OK(ocl::conv_bwd_weight(CL(ctx), &g, gb->data(), xb->data(),
+                                   wb->mutable_data()));
+      } else {
+        SA_OK(sa_conv_bwd_weight(t, &g, gb->data(), xb->data(),
+                                 wb->mutable_data(), S(ctx)));
+      }
     }, {gb, xb}, {wb}, "ConvBackwardWeight");
   }
   return dw;
@@ -172,8 +198,14 @@ Tensor ConvBackwardBias(const Tensor &dy) {
     }, {gb}, {bb}, "ConvBackwardBias");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_conv_bwd_bias(t, gb->data(), bb->mutable_data(), N, K, PQ,
-                             S(ctx)));
+      if (CL(ctx)) {
+        CL_F32(t);
+        SA_OK(ocl::conv_bwd_bias(CL(ctx), gb->data(), bb->mutable_data(), N, K,
+                                 PQ));
+      } else {
+        SA_OK(sa_conv_bwd_bias(t, gb->data(), bb->mutable_data(), N, K, PQ,
+                               S(ctx)));
+      }
     }, {gb}, {bb}, "ConvBackwardBias");
   }
   return db;
@@ -228,7 +260,12 @@ Tensor PoolForward(const Tensor &x, const PoolParams &p) {
     }, {xb}, {yb}, "PoolForward");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_pool_fwd(t, &g, xb->data(), yb->mutable_data(), S(ctx)));
+      if (CL(ctx)) {
+        CL_F32(t);
+        SA_OK(ocl::pool_fwd(CL(ctx), &g, xb->data(), yb->mutable_data()));
+      } else {
+        SA_OK(sa_pool_fwd(t, &g, xb->data(), yb->mutable_data(), S(ctx)));
+      }
     }, {xb}, {yb}, "PoolForward");
   }
   return y;
@@ -286,8 +323,14 @@ Tensor PoolBackward(const Tensor &dy, const Tensor &x, const Tensor &y,
     }, {gb, xb, yb}, {db}, "PoolBackward");
   } else {
     dev->Exec([=](Context *ctx) {
-      SA_OK(sa_pool_bwd(t, &g, gb->data(), xb->data(), yb->data(),
-                        db->mutable_data(), S(ctx)));
+      if (CL(ctx)) {
+        CL_F32(t);
+        SA_OK(ocl::pool_bwd(CL(ctx), &g, gb->data(), xb->data(), yb->data(),
+                            db->mutable_data()));
+      } else {
+        SA_OK(sa_pool_bwd(t, &g, gb->data(), xb->data(), yb->data(),
+                          db->mutable_data(), S(ctx)));
+      }
     }, {gb, xb, yb}, {db}, "PoolBackward");
   }
   return dx;
@@ -349,6 +392,8 @@ Tensor BatchNormForwardTrain(const Tensor &x, const Tensor &scale,
       }
     }, {xb, sb, bb, rm, rv}, {yb, mb, ib, rm, rv}, "BatchNormForwardTrain");
   } else {
+    CHECK(dev->lang() != kOpencl)
+        << "batch normalisation is not provided on the OpenCL device";
     Tensor work(Shape{size_t(std::max<int64_t>(sa_bn_workspace(N, C, HW), 1))},
                 dev, kFloat32);
     Block *wk = work.block();
@@ -394,6 +439,8 @@ Tensor BatchNormForwardInfer(const Tensor &x, const Tensor &scale,
         }
     }, {xb, sb, bb, rm, rv}, {yb}, "BatchNormForwardInfer");
   } else {
+    CHECK(dev->lang() != kOpencl)
+        << "batch normalisation is not provided on the OpenCL device";
     dev->Exec([=](Context *ctx) {
       SA_OK(sa_bn_fwd_infer(t, xb->data(),
                             static_cast<const float *>(sb->data()),
@@ -449,6 +496,8 @@ Tensor BatchNormBackward(const Tensor &dy, const Tensor &x, const Tensor &scale,
       }
     }, {gb, xb, sb, mb, ib}, {db, dsb, dbb}, "BatchNormBackward");
   } else {
+    CHECK(dev->lang() != kOpencl)
+        << "batch normalisation is not provided on the OpenCL device";
     Tensor work(Shape{size_t(std::max<int64_t>(sa_bn_workspace(N, C, HW), 1))},
                 dev, kFloat32);
     Block *wk = work.block();

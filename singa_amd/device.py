@@ -50,19 +50,23 @@ create_hip_gpus_on = create_cuda_gpus_on
 
 
 def get_num_opencl_platforms():
-    """No OpenCL target exists in this build (reference
-    python/singa/device.py:44-51 asserts USE_OPENCL)."""
-    assert False, 'singa_amd is built for HIP devices only (USE_OPENCL is False).'
-    return 0
+    """1 when the machine's OpenCL runtime exposes a GPU, else 0 (reference
+    python/singa/device.py:44-51)."""
+    return 1 if get_num_opencl_devices() > 0 else 0
 
 
 def get_num_opencl_devices():
-    assert False, 'singa_amd is built for HIP devices only (USE_OPENCL is False).'
-    return 0
+    from . import native
+    return native.num_opencl_devices()
 
 
-def create_opencl_device():
-    raise NotImplementedError("OpenCL devices are not part of the MI355X build")
+def create_opencl_device(index=0):
+    """The GPU as an OpenCL device of the native C++ library
+    (``singa::OpenclDevice``).  The returned ``native.Device`` creates
+    ``native.Tensor`` objects; the autograd / layer / model stack of this
+    package runs on the HIP devices (``create_cuda_gpu``)."""
+    from . import native
+    return native.Device.opencl(index)
 
 
 def create_cpu_device():

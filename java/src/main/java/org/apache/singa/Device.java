@@ -33,6 +33,18 @@ public final class Device implements AutoCloseable {
         }
     }
 
+    /** The GPU as seen by the machine's OpenCL runtime (see {@link Singa#numOpenclDevices()}). */
+    public static Device opencl(int id) {
+        try {
+            return new Device(Singa.checked((MemorySegment) Singa.fn("singa_device_opencl",
+                    FunctionDescriptor.of(Singa.PTR, Singa.I32)).invokeExact(id)));
+        } catch (IllegalStateException e) {
+            throw e;
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
     /** Wait until the device has finished the work issued so far. */
     public void sync() {
         try {

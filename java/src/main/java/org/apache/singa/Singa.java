@@ -75,6 +75,14 @@ public final class Singa {
         }
     }
 
+    public static int numOpenclDevices() {
+        try {
+            return (int) fn("singa_num_opencl_devices", FunctionDescriptor.of(I32)).invokeExact();
+        } catch (Throwable t) {
+            throw new IllegalStateException(t);
+        }
+    }
+
     /** Element-wise function of one tensor: abs exp log relu sigmoid sign sqrt square tanh. */
     public static Tensor unary(String op, Tensor x) {
         try (Arena a = Arena.ofConfined()) {

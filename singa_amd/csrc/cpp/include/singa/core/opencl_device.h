@@ -11,7 +11,8 @@
 //     a plain pointer, as on the other devices, so Tensor offsets, sub-block
 //     views and the lazy Block work unchanged, and kernels take pointers
 //     (clSetKernelArgSVMPointer) rather than buffer handles.
-//   * one in-order queue per device; Sync() is clFinish.
+//   * one in-order queue per device; Sync() is clFinish.  Freed blocks are
+//     cached and recycled (releasing SVM needs an idle queue, reuse does not).
 //   * kernel sources (src/core/opencl/*.cl) are embedded in the library at
 //     build time and compiled once per device on first use.
 // Like the reference's, this device computes in float32 (int32 labels) and
@@ -46,9 +47,15 @@ class OpenclDevice : public Device {
   static int GetNumDevices();
 
  private:
+  void ReleaseCache();
+  static constexpr size_t kCacheLimit = size_t(8) << 30;  // bytes kept for reuse
+
   std::unique_ptr<ocl::Runtime> rt_;
-  size_t allocated_ = 0;
-  std::map<void *, size_t> sizes_;
+  size_t allocated_ = 0;                  // bytes in use, as requested
+  size_t cached_ = 0;                     // bytes in free_
+  std::map<void *, size_t> sizes_;        // live block -> its capacity
+  std::map<void *, size_t> requested_;    // live block -> bytes asked for
+  std::multimap<size_t, void *> free_;    // capacity -> block kept for reuse
 };
 
 }  // namespace singa

@@ -16,7 +16,7 @@
 //   * kernel sources (src/core/opencl/*.cl) are embedded in the library at
 //     build time and compiled once per device on first use.
 // Like the reference's, this device computes in float32 (int32 labels) and
-// has no graph buffering.
+// has no graph buffering.  Every layer of the C++ API runs on it.
 #pragma once
 #include <map>
 #include <memory>

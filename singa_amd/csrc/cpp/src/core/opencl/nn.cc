@@ -110,5 +110,71 @@ int pool_bwd(Runtime *rt, const PoolGeom *g, const void *dy, const void *x,
   return 0;
 }
 
+int bn_fwd_train(Runtime *rt, const void *x, const float *scale,
+                 const float *bias, float *rmean, float *rvar, float factor,
+                 float eps, void *y, float *mean, float *invstd, int N, int C,
+                 int HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  cl_kernel k = rt->Kernel("k_bn_fwd_train");
+  int i = 0;
+  rt->ArgPtr(k, i++, x);
+  rt->ArgPtr(k, i++, scale);
+  rt->ArgPtr(k, i++, bias);
+  rt->ArgPtr(k, i++, rmean);
+  rt->ArgPtr(k, i++, rvar);
+  rt->Arg(k, i++, factor);
+  rt->Arg(k, i++, eps);
+  rt->ArgPtr(k, i++, y);
+  rt->ArgPtr(k, i++, mean);
+  rt->ArgPtr(k, i++, invstd);
+  rt->Arg(k, i++, static_cast<cl_int>(N));
+  rt->Arg(k, i++, static_cast<cl_int>(C));
+  rt->Arg(k, i++, static_cast<cl_int>(HW));
+  rt->Launch(k, Groups(rt, C), kGroup);
+  return 0;
+}
+
+int bn_fwd_infer(Runtime *rt, const void *x, const float *scale,
+                 const float *bias, const float *rmean, const float *rvar,
+                 float eps, void *y, int N, int C, int HW) {
+  const int64_t total = (int64_t)N * C * HW;
+  if (total <= 0) return 0;
+  cl_kernel k = rt->Kernel("k_bn_fwd_infer");
+  int i = 0;
+  rt->ArgPtr(k, i++, x);
+  rt->ArgPtr(k, i++, scale);
+  rt->ArgPtr(k, i++, bias);
+  rt->ArgPtr(k, i++, rmean);
+  rt->ArgPtr(k, i++, rvar);
+  rt->Arg(k, i++, eps);
+  rt->ArgPtr(k, i++, y);
+  rt->Arg(k, i++, static_cast<cl_long>(total));
+  rt->Arg(k, i++, static_cast<cl_int>(C));
+  rt->Arg(k, i++, static_cast<cl_int>(HW));
+  rt->Launch(k, Items(rt, total), kGroup);
+  return 0;
+}
+
+int bn_bwd(Runtime *rt, const void *dy, const void *x, const float *scale,
+           const float *mean, const float *invstd, void *dx, float *dscale,
+           float *dbias, int N, int C, int HW) {
+  if (N <= 0 || C <= 0 || HW <= 0) return 0;
+  cl_kernel k = rt->Kernel("k_bn_bwd");
+  int i = 0;
+  rt->ArgPtr(k, i++, dy);
+  rt->ArgPtr(k, i++, x);
+  rt->ArgPtr(k, i++, scale);
+  rt->ArgPtr(k, i++, mean);
+  rt->ArgPtr(k, i++, invstd);
+  rt->ArgPtr(k, i++, dx);
+  rt->ArgPtr(k, i++, dscale);
+  rt->ArgPtr(k, i++, dbias);
+  rt->Arg(k, i++, static_cast<cl_int>(N));
+  rt->Arg(k, i++, static_cast<cl_int>(C));
+  rt->Arg(k, i++, static_cast<cl_int>(HW));
+  rt->Launch(k, Groups(rt, C), kGroup);
+  return 0;
+}
+
 }  // namespace ocl
 }  // namespace singa

@@ -215,3 +215,101 @@ __kernel void k_pool_bwd(PoolShape g, __global const float *dy,
     dx[i] = acc;
   }
 }
+
+// ---- batch normalisation ---------------------------------------------------------
+// One work-group per channel: two-pass statistics (mean first, then the
+// centred second moment), so the variance does not suffer from cancellation.
+inline float group_sum(float v, __local float *buf) {
+  const int l = get_local_id(0);
+  buf[l] = v;
+  barrier(CLK_LOCAL_MEM_FENCE);
+  for (int span = get_local_size(0) / 2; span > 0; span >>= 1) {
+    if (l < span) buf[l] += buf[l + span];
+    barrier(CLK_LOCAL_MEM_FENCE);
+  }
+  const float r = buf[0];
+  barrier(CLK_LOCAL_MEM_FENCE);
+  return r;
+}
+
+__kernel void k_bn_fwd_train(__global const float *x,
+                             __global const float *scale,
+                             __global const float *bias,
+                             __global float *rmean, __global float *rvar,
+                             float factor, float eps, __global float *y,
+                             __global float *mean_out,
+                             __global float *invstd_out, int N, int C,
+                             int HW) {
+  __local float buf[256];
+  const long count = (long)N * HW;
+  for (int c = get_group_id(0); c < C; c += get_num_groups(0)) {
+    float s = 0.f;
+    for (long j = get_local_id(0); j < count; j += get_local_size(0))
+      s += x[((j / HW) * C + c) * HW + j % HW];
+    const float mean = group_sum(s, buf) / (float)count;
+    float ss = 0.f;
+    for (long j = get_local_id(0); j < count; j += get_local_size(0)) {
+      const float d = x[((j / HW) * C + c) * HW + j % HW] - mean;
+      ss += d * d;
+    }
+    const float var = group_sum(ss, buf) / (float)count;
+    const float invstd = rsqrt(var + eps);
+    if (get_local_id(0) == 0) {
+      mean_out[c] = mean;
+      invstd_out[c] = invstd;
+      const float unbiased =
+          count > 1 ? var * (float)count / (float)(count - 1) : var;
+      rmean[c] = (1.f - factor) * rmean[c] + factor * mean;
+      rvar[c] = (1.f - factor) * rvar[c] + factor * unbiased;
+    }
+    const float g = scale[c] * invstd, b = bias[c] - mean * g;
+    for (long j = get_local_id(0); j < count; j += get_local_size(0)) {
+      const long o = ((j / HW) * C + c) * HW + j % HW;
+      y[o] = fma(x[o], g, b);
+    }
+  }
+}
+
+__kernel void k_bn_fwd_infer(__global const float *x,
+                             __global const float *scale,
+                             __global const float *bias,
+                             __global const float *rmean,
+                             __global const float *rvar, float eps,
+                             __global float *y, long total, int C, int HW) {
+  for (long i = get_global_id(0); i < total; i += get_global_size(0)) {
+    const int c = (i / HW) % C;
+    const float g = scale[c] * rsqrt(rvar[c] + eps);
+    y[i] = fma(x[i] - rmean[c], g, bias[c]);
+  }
+}
+
+__kernel void k_bn_bwd(__global const float *dy, __global const float *x,
+                       __global const float *scale,
+                       __global const float *mean,
+                       __global const float *invstd, __global float *dx,
+                       __global float *dscale, __global float *dbias, int N,
+                       int C, int HW) {
+  __local float buf[256];
+  const long count = (long)N * HW;
+  for (int c = get_group_id(0); c < C; c += get_num_groups(0)) {
+    const float m = mean[c], is = invstd[c];
+    float sg = 0.f, sgx = 0.f;
+    for (long j = get_local_id(0); j < count; j += get_local_size(0)) {
+      const long o = ((j / HW) * C + c) * HW + j % HW;
+      sg += dy[o];
+      sgx += dy[o] * (x[o] - m) * is;
+    }
+    sg = group_sum(sg, buf);
+    sgx = group_sum(sgx, buf);
+    if (get_local_id(0) == 0) {
+      dbias[c] = sg;
+      dscale[c] = sgx;
+    }
+    const float k = scale[c] * is, inv = 1.f / (float)count;
+    for (long j = get_local_id(0); j < count; j += get_local_size(0)) {
+      const long o = ((j / HW) * C + c) * HW + j % HW;
+      const float xh = (x[o] - m) * is;
+      dx[o] = k * (dy[o] - sg * inv - xh * sgx * inv);
+    }
+  }
+}

@@ -135,6 +135,17 @@ int conv_bwd_bias(Runtime *rt, const void *dy, void *db, int N, int K, int PQ);
 int pool_fwd(Runtime *rt, const PoolGeom *g, const void *x, void *y);
 int pool_bwd(Runtime *rt, const PoolGeom *g, const void *dy, const void *x,
              const void *y, void *dx);
+// batch normalisation over (N, C, HW), float32; statistics as the HIP side
+int bn_fwd_train(Runtime *rt, const void *x, const float *scale,
+                 const float *bias, float *rmean, float *rvar, float factor,
+                 float eps, void *y, float *mean, float *invstd, int N, int C,
+                 int HW);
+int bn_fwd_infer(Runtime *rt, const void *x, const float *scale,
+                 const float *bias, const float *rmean, const float *rvar,
+                 float eps, void *y, int N, int C, int HW);
+int bn_bwd(Runtime *rt, const void *dy, const void *x, const float *scale,
+           const float *mean, const float *invstd, void *dx, float *dscale,
+           float *dbias, int N, int C, int HW);
 
 }  // namespace ocl
 }  // namespace singa

@@ -392,8 +392,19 @@ Tensor BatchNormForwardTrain(const Tensor &x, const Tensor &scale,
       }
     }, {xb, sb, bb, rm, rv}, {yb, mb, ib, rm, rv}, "BatchNormForwardTrain");
   } else {
-    CHECK(dev->lang() != kOpencl)
-        << "batch normalisation is not provided on the OpenCL device";
+    if (dev->lang() == kOpencl) {
+      CL_F32(t);
+      dev->Exec([=](Context *ctx) {
+        SA_OK(ocl::bn_fwd_train(
+            CL(ctx), xb->data(), static_cast<const float *>(sb->data()),
+            static_cast<const float *>(bb->data()),
+            static_cast<float *>(rm->mutable_data()),
+            static_cast<float *>(rv->mutable_data()), factor, kBnEps,
+            yb->mutable_data(), static_cast<float *>(mb->mutable_data()),
+            static_cast<float *>(ib->mutable_data()), N, C, HW));
+      }, {xb, sb, bb, rm, rv}, {yb, mb, ib, rm, rv}, "BatchNormForwardTrain");
+      return y;
+    }
     Tensor work(Shape{size_t(std::max<int64_t>(sa_bn_workspace(N, C, HW), 1))},
                 dev, kFloat32);
     Block *wk = work.block();
@@ -439,8 +450,18 @@ Tensor BatchNormForwardInfer(const Tensor &x, const Tensor &scale,
         }
     }, {xb, sb, bb, rm, rv}, {yb}, "BatchNormForwardInfer");
   } else {
-    CHECK(dev->lang() != kOpencl)
-        << "batch normalisation is not provided on the OpenCL device";
+    if (dev->lang() == kOpencl) {
+      CL_F32(t);
+      dev->Exec([=](Context *ctx) {
+        SA_OK(ocl::bn_fwd_infer(CL(ctx), xb->data(),
+                                static_cast<const float *>(sb->data()),
+                                static_cast<const float *>(bb->data()),
+                                static_cast<const float *>(rm->data()),
+                                static_cast<const float *>(rv->data()), kBnEps,
+                                yb->mutable_data(), N, C, HW));
+      }, {xb, sb, bb, rm, rv}, {yb}, "BatchNormForwardInfer");
+      return y;
+    }
     dev->Exec([=](Context *ctx) {
       SA_OK(sa_bn_fwd_infer(t, xb->data(),
                             static_cast<const float *>(sb->data()),
@@ -496,8 +517,19 @@ Tensor BatchNormBackward(const Tensor &dy, const Tensor &x, const Tensor &scale,
       }
     }, {gb, xb, sb, mb, ib}, {db, dsb, dbb}, "BatchNormBackward");
   } else {
-    CHECK(dev->lang() != kOpencl)
-        << "batch normalisation is not provided on the OpenCL device";
+    if (dev->lang() == kOpencl) {
+      CL_F32(t);
+      dev->Exec([=](Context *ctx) {
+        SA_OK(ocl::bn_bwd(CL(ctx), gb->data(), xb->data(),
+                          static_cast<const float *>(sb->data()),
+                          static_cast<const float *>(mb->data()),
+                          static_cast<const float *>(ib->data()),
+                          db->mutable_data(),
+                          static_cast<float *>(dsb->mutable_data()),
+                          static_cast<float *>(dbb->mutable_data()), N, C, HW));
+      }, {gb, xb, sb, mb, ib}, {db, dsb, dbb}, "BatchNormBackward");
+      return dx;
+    }
     Tensor work(Shape{size_t(std::max<int64_t>(sa_bn_workspace(N, C, HW), 1))},
                 dev, kFloat32);
     Block *wk = work.block();

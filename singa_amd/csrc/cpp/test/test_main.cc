@@ -2,8 +2,7 @@
 //   singa_cpp_test            host device only
 //   singa_cpp_test --gpu      every numeric test also on HipGPU 0, compared
 //                             with the host result of the same operation
-//   singa_cpp_test --opencl   the same on OpenclDevice 0 (batch-norm layers
-//                             left out: that device has none)
+//   singa_cpp_test --opencl   the same on OpenclDevice 0
 // Modelled on the reference's test/singa/test_*.cc suites (tensor math,
 // layers, optimizers, loss, metric, snapshot, feed-forward net, endpoint).
 #include <unistd.h>
@@ -445,9 +444,6 @@ static void TestLayersGpuVsCpu() {
   unsigned seed = 40;
   for (auto &lc : LayerCases()) {
     ++seed;
-    if (g_dev->lang() == kOpencl &&
-        lc.type.find("batchnorm") != std::string::npos)
-      continue;
     LayerResult c = RunLayer(lc.type, lc.conf, lc.sample, lc.batch,
                              defaultDevice, seed);
     LayerResult g = RunLayer(lc.type, lc.conf, lc.sample, lc.batch, g_dev, seed);
@@ -1243,6 +1239,7 @@ int main(int argc, char **argv) {
     Run("LayersOpenclVsCpu", TestLayersGpuVsCpu);
     Run("Optimizers/opencl", [&] { TestOptimizers(g_dev); });
     Run("LossMetric/opencl", [&] { TestLossMetric(g_dev); });
+    Run("DropoutAndMulti/opencl", [&] { TestDropoutAndMulti(g_dev); });
     Run("FeedForwardNet/opencl", [&] { TestFeedForwardNet(g_dev, false); });
     g_dev->Sync();
     std::printf("%d checks, %d failed\n", g_checks, g_failed);

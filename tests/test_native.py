@@ -92,5 +92,5 @@ def test_opencl_device_cpp_suite():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     for name in ("Opencl/device", "TensorMath/opencl", "LayersOpenclVsCpu",
                  "Optimizers/opencl", "LossMetric/opencl",
-                 "FeedForwardNet/opencl"):
+                 "DropoutAndMulti/opencl", "FeedForwardNet/opencl"):
         assert "[  OK  ] " + name in r.stdout

@@ -1,6 +1,6 @@
 // CIFAR-10 convolutional network (3 x conv-pool-relu-lrn, one dense layer)
 // trained with the C++ API on one device.
-//   singa_cnn [-epoch N] [-lr X] [-data DIR] [-cpu] [-batch B]
+//   singa_cnn [-epoch N] [-lr X] [-data DIR] [-cpu | -opencl] [-batch B]
 // Counterpart of the reference's examples/cpp/cifar10/cnn.cc; the
 // configuration records are plain structs here.
 #include <cstdio>
@@ -109,7 +109,7 @@ FeedForwardNet CreateNet() {
 }
 
 void Train(int num_epoch, float lr, const std::string &data_dir, bool use_cpu,
-           size_t batch) {
+           size_t batch, bool use_opencl) {
   Cifar10 data(data_dir);
   auto train = data.ReadTrainData();
   auto test = data.ReadTestData();
@@ -135,8 +135,16 @@ void Train(int num_epoch, float lr, const std::string &data_dir, bool use_cpu,
   net.Compile(true, &sgd, &loss, &acc);
 
   std::shared_ptr<Device> dev = defaultDevice;
-  if (!use_cpu && Platform::GetNumGPUs() > 0) dev = Platform::CreateCudaGPUs(1)[0];
-  std::printf("training on %s\n", dev->lang() == kCpp ? "CppCPU" : "HipGPU");
+  if (use_opencl) {
+    CHECK_GT(OpenclDevice::GetNumDevices(), 0) << "no OpenCL GPU device";
+    dev = std::make_shared<OpenclDevice>(0);
+  } else if (!use_cpu && Platform::GetNumGPUs() > 0) {
+    dev = Platform::CreateCudaGPUs(1)[0];
+  }
+  std::printf("training on %s\n",
+              dev->lang() == kCpp ? "CppCPU"
+                                  : (dev->lang() == kOpencl ? "OpenclDevice"
+                                                            : "HipGPU"));
   net.ToDevice(dev);
   train_x.ToDevice(dev);
   train_y.ToDevice(dev);
@@ -157,10 +165,13 @@ int main(int argc, char **argv) {
   std::string data = pos != -1 ? argv[pos + 1] : "cifar-10-batches-bin";
   pos = singa::ArgPos(argc, argv, "-batch");
   size_t batch = pos != -1 ? std::atoi(argv[pos + 1]) : 100;
-  bool cpu = false;
-  for (int i = 1; i < argc; ++i) cpu = cpu || std::string(argv[i]) == "-cpu";
+  bool cpu = false, opencl = false;
+  for (int i = 1; i < argc; ++i) {
+    cpu = cpu || std::string(argv[i]) == "-cpu";
+    opencl = opencl || std::string(argv[i]) == "-opencl";
+  }
   std::printf("Start training\n");
-  singa::Train(nEpoch, lr, data, cpu, batch);
+  singa::Train(nEpoch, lr, data, cpu, batch, opencl);
   std::printf("End training\n");
   return 0;
 }

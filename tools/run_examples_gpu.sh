@@ -32,6 +32,7 @@ run onnx_selftest python examples/onnx/text_models.py self-test
 run largedata python examples/largedataset_cnn/train_largedata.py cnn --synthetic -m 1 -b 16
 run hfl python examples/hfl/run_local.py
 run cpp_cnn singa_amd/bin/singa_cnn -epoch 1
+run cpp_cnn_opencl singa_amd/bin/singa_cnn -epoch 1 -opencl
 run cpp_cnn_parallel singa_amd/bin/singa_cnn_parallel -epoch 1 -replicas 1
 run cpp_vgg_parallel singa_amd/bin/singa_vgg_parallel -epoch 3 -replicas 1 -dropout 0.5
 run cpp_alexnet singa_amd/bin/singa_alexnet -synthetic -data /tmp/singa_alexnet_gpu

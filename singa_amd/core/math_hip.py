@@ -683,18 +683,20 @@ class HipMath(object):
 
     def _tuned(self, mode, g, key, launch):
         """Set g.tile / g.split_target for this launch.  ``launch(g)`` runs the
-        convolution once (it only overwrites the output)."""
+        convolution once (it only overwrites the output).  Returns True when
+        timing launches were issued, i.e. the output has been written."""
         if key[4] > 1 and key[4] == key[0][1] == key[1][0]:
-            return  # depthwise kernels have no launch plan to choose
+            return False  # depthwise kernels have no launch plan to choose
         full = (mode,) + key
+        measured = False
         plan = self._conv_plans.get(full)
         if plan is None:
             if not _CONV_AUTOTUNE:
-                return
+                return False
             capturing = torch.cuda.is_current_stream_capturing()
             ranks = _world_size()
             if ranks > 1 and capturing:
-                return        # no collective inside a capture: heuristic plan
+                return False  # no collective inside a capture: heuristic plan
             name = repr(full)
             if ranks <= 1 or _rank() == 0:
                 stored = self._plan_store()[1].get(name)
@@ -702,6 +704,7 @@ class HipMath(object):
                     plan = (int(stored[0]), int(stored[1]))
                 elif not capturing:
                     plan = self._measure_plan(g, launch)
+                    measured = True
                     self._persist_plan(name, plan)
             if ranks > 1:
                 word = torch.tensor(list(plan or (0, 0)), dtype=torch.int32,
@@ -709,9 +712,10 @@ class HipMath(object):
                 torch.distributed.broadcast(word, 0)
                 plan = tuple(int(v) for v in word.tolist())
             if plan is None:
-                return        # first met under capture, nothing stored
+                return False  # first met under capture, nothing stored
             self._conv_plans[full] = plan
         g.tile, g.split_target = plan
+        return measured
 
     def _split_scratch(self, g, out, rows, cols, groups):
         """16-bit outputs: lend the launcher a float buffer of the output's
@@ -977,10 +981,11 @@ class HipMath(object):
         acc = dw if dw.dtype == torch.float32 else torch.empty(
             dw.shape, dtype=torch.float32, device=dw.device)
         args = (dy.data_ptr(), x.data_ptr(), acc.data_ptr())
-        self._tuned(2, g, key,
-                    lambda gg: self.k.conv_bwd_weight(code, gg, *args,
-                                                      self._s()))
-        g.out_zeroed = bool(zeroed) and acc is dw
+        wrote = self._tuned(2, g, key,
+                            lambda gg: self.k.conv_bwd_weight(code, gg, *args,
+                                                              self._s()))
+        # timing launches leave a complete gradient in dw: not zero any more
+        g.out_zeroed = bool(zeroed) and acc is dw and not wrote
         self.k.conv_bwd_weight(code, g, *args, self._s())
         if dw.dtype != torch.float32:
             self.copy(acc, dw)

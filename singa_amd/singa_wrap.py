@@ -26,7 +26,7 @@ USE_CUDA = bool(_torch.cuda.is_available())
 USE_HIP = USE_CUDA
 USE_CUDNN = USE_CUDA      # conv / bn / pool / rnn handles are available
 USE_DNNL = True           # the host path implements conv / bn / pool as well
-USE_OPENCL = False
+USE_OPENCL = False   # Python tensors live on HIP; the OpenCL device is the C++ library's (singa_amd.native)
 USE_PYTHON = True
 USE_JAVA = False     # the Java classes (java/) bind the C interface at run time
 USE_DIST = True

@@ -749,6 +749,42 @@ def test_batchnorm(maths, shape):
                                rtol=1e-4)
 
 
+def test_conv_backward_pair_while_plans_are_measured(maths, monkeypatch):
+    """The data-gradient launch clears the weight gradient for the launch
+    that follows.  When the weight-gradient launch plan of a shape is still to
+    be chosen, timing launches run in between and leave a full gradient in
+    the buffer: the final launch must then start from zero again.  First call
+    = plans measured, second = plans known; both must match the host."""
+    from singa_amd.core import math_hip, nn_ops, tensor_core
+    hm, cm, dev = maths
+    monkeypatch.setattr(math_hip, "_CONV_AUTOTUNE", True)
+    monkeypatch.setattr(type(hm), "_plan_file", ("", {}))
+    saved = dict(hm._conv_plans)
+    hm._conv_plans.clear()
+    try:
+        N, C, K, H = 4, 24, 40, 13            # a shape no other test uses
+        x = rnd(N, C, H, H, seed=301)
+        w = rnd(K, C, 3, 3, seed=302)
+        dy = rnd(N, K, H, H, seed=303)
+        rdx, rdw = torch.empty_like(x), torch.empty_like(w)
+        cm.conv_bwd_data(dy, w, rdx, (1, 1), (1, 1), 1)
+        cm.conv_bwd_weight(dy, x, rdw, (1, 1), (1, 1), 1)
+        for attempt in ("measuring", "planned"):
+            dx = torch.empty_like(x, device=dev.torch_device)
+            dw = torch.full_like(w, 7.0, device=dev.torch_device)
+            cleared = hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (1, 1),
+                                       (1, 1), 1, side_zero=dw)
+            hm.conv_bwd_weight(g(dy, dev), g(x, dev), dw, (1, 1), (1, 1), 1,
+                               zeroed=bool(cleared))
+            np.testing.assert_allclose(dx.cpu().numpy(), rdx.numpy(),
+                                       atol=2e-3, rtol=1e-3, err_msg=attempt)
+            np.testing.assert_allclose(dw.cpu().numpy(), rdw.numpy(),
+                                       atol=5e-3, rtol=1e-3, err_msg=attempt)
+    finally:
+        hm._conv_plans.clear()
+        hm._conv_plans.update(saved)
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("act", [0, 1, 2])
 @pytest.mark.parametrize("shape", [(3, 16, 56, 56), (2, 24, 14, 14),

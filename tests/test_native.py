@@ -94,3 +94,40 @@ def test_opencl_device_cpp_suite():
                  "Optimizers/opencl", "LossMetric/opencl",
                  "DropoutAndMulti/opencl", "FeedForwardNet/opencl"):
         assert "[  OK  ] " + name in r.stdout
+
+
+def test_opencl_sources_compile_for_gfx950():
+    """The OpenCL C sources of the OpenCL device parse and type-check for
+    gfx950 with the operator codes of the C++ enums as -D options (what the
+    device does at run time with the runtime's own compiler); needs only the
+    ROCm clang, no GPU."""
+    import re
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    if not os.path.exists(clang):
+        pytest.skip("no ROCm clang")
+    csrc = os.path.join(ROOT, "singa_amd", "csrc")
+    header = open(os.path.join(csrc, "hip", "kernels.h")).read()
+    defines = []
+    for enum in ("UnaryOp", "BinaryOp", "ReduceOp"):
+        body = re.search(r"enum %s : int \{(.*?)\};" % enum, header,
+                         re.S).group(1)
+        names = [n.split("=")[0].strip() for n in body.replace("\n", " ")
+                 .split(",") if n.strip()]
+        defines += ["-D%s=%d" % (n, i) for i, n in enumerate(names)]
+    cl_dir = os.path.join(csrc, "cpp", "src", "core", "opencl")
+    sources = sorted(f for f in os.listdir(cl_dir) if f.endswith(".cl"))
+    assert sources == ["nn.cl", "tensor_math.cl"]
+    for f in sources:
+        r = subprocess.run(
+            [clang, "-x", "cl", "-cl-std=CL2.0", "-fsyntax-only", "-Werror",
+             "-Xclang", "-finclude-default-header", "-target",
+             "amdgcn-amd-amdhsa", "-mcpu=gfx950"] + defines +
+            [os.path.join(cl_dir, f)], capture_output=True, text=True,
+            timeout=120)
+        assert r.returncode == 0, f + "\n" + r.stderr[-3000:]
+    # the text embedded in the library is these files, line for line
+    from singa_amd import build
+    build._embed_opencl_sources(cl_dir)
+    inc = open(os.path.join(cl_dir, "cl_sources.inc")).read()
+    first = open(os.path.join(cl_dir, "nn.cl")).read().splitlines()[0]
+    assert first.replace("\\", "\\\\").replace('"', '\\"') in inc

@@ -103,8 +103,10 @@ def main():
     # one-time work that is not part of a training step -- convolution plan
     # selection on first use, recording the step, capturing it into hipGraphs
     # -- happens in the first three calls; they run before the warm-up steps
-    # so that even --warmup 0 times steady-state steps only
-    for _ in range(3):
+    # so that even --warmup 0 times steady-state steps only (reported as
+    # "setup_steps" in the JSON line)
+    SETUP_STEPS = 3
+    for _ in range(SETUP_STEPS):
         _, loss = model(tx, ty, 'plain', None)
     for _ in range(args.warmup):
         _, loss = model(tx, ty, 'plain', None)
@@ -115,8 +117,8 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist.is_initialized():
-        t = torch.tensor([elapsed], device=dev.torch_device,
-                         dtype=torch.float64)
+        # the host control group (gloo) carries the maximum over the ranks
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     loss_val = float(tensor.to_numpy(loss.as_type(tensor.float32))
@@ -131,6 +133,8 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "setup_steps": SETUP_STEPS,
+            "untimed_steps_total": SETUP_STEPS + args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 3),
             "higher_is_better": True,
             "scaling": "weak",
@@ -155,8 +159,7 @@ def main():
         }), flush=True)
         if args.verbosity > 0:
             dev.PrintTimeProfiling()
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    sgd.communicator.close()
 
 
 if __name__ == "__main__":

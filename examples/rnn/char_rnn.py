@@ -21,56 +21,75 @@ from singa_amd import autograd, device, layer, model, opt, tensor  # noqa: E402
 
 
 class CharRNN(model.Model):
+    """LSTM over one-hot characters followed by a linear read-out of every
+    time step.  The recurrent state lives in ``self.state`` (name -> tensor of
+    shape (batch, hidden)) and is carried from one call to the next; the fused
+    sequence operator behind ``layer.LSTM`` runs the whole unrolled recurrence
+    as one node of the recorded graph."""
+
+    STATE_NAMES = ("h", "c")
 
     def __init__(self, vocab_size, hidden_size=32, lr=0.01):
         super(CharRNN, self).__init__()
+        self.vocab_size, self.hidden_size = vocab_size, hidden_size
         self.rnn = layer.LSTM(vocab_size, hidden_size)
-        self.cat = layer.Cat()
-        self.reshape1 = layer.Reshape()
-        self.dense = layer.Linear(hidden_size, vocab_size)
-        self.reshape2 = layer.Reshape()
-        self.softmax_cross_entropy = layer.SoftMaxCrossEntropy()
-        self.optimizer = opt.SGD(lr)
-        self.hidden_size = hidden_size
-        self.vocab_size = vocab_size
+        self.readout = layer.Linear(hidden_size, vocab_size)
+        self.stack = layer.Cat()
+        self.fold_steps = layer.Reshape()
+        self.fold_labels = layer.Reshape()
+        self.loss_fn = layer.SoftMaxCrossEntropy()
+        self.set_optimizer(opt.SGD(lr))
+        self.state = {}
+
+    # the pair handed to layer.LSTM
+    @property
+    def hx(self):
+        return self.state["h"]
+
+    @property
+    def cx(self):
+        return self.state["c"]
+
+    def new_state(self, batch, dev):
+        """Zero state for sequences of ``batch`` rows on ``dev``."""
+        self.state = {}
+        for name in self.STATE_NAMES:
+            t = tensor.Tensor((batch, self.hidden_size), dev)
+            t.set_value(0.0)
+            t.name = "state." + name
+            self.state[name] = t
 
     def reset_states(self, dev):
-        self.hx.to_device(dev)
-        self.cx.to_device(dev)
-        self.hx.set_value(0.0)
-        self.cx.set_value(0.0)
+        """Start a new sequence: zero the carried state in place (the
+        recorded step keeps reading the same tensors)."""
+        for t in self.state.values():
+            t.to_device(dev)
+            t.set_value(0.0)
 
     def initialize(self, inputs):
-        batchsize = inputs[0].shape[0]
-        self.hx = tensor.Tensor((batchsize, self.hidden_size))
-        self.cx = tensor.Tensor((batchsize, self.hidden_size))
-        self.reset_states(inputs[0].device)
+        self.new_state(inputs[0].shape[0], inputs[0].device)
 
     def forward(self, inputs):
-        x, hx, cx = self.rnn(inputs, (self.hx, self.cx))
-        # carry the recurrent state over to the next call
-        self.hx.copy_data(hx)
-        self.cx.copy_data(cx)
-        x = self.cat(x)
-        x = self.reshape1(x, (-1, self.hidden_size))
-        return self.dense(x)
+        steps, h, c = self.rnn(inputs, (self.hx, self.cx))
+        for t, new in zip((self.hx, self.cx), (h, c)):
+            t.copy_data(new)
+        rows = self.fold_steps(self.stack(steps), (-1, self.hidden_size))
+        return self.readout(rows)
 
     def train_one_batch(self, x, y):
-        out = self.forward(x)
-        y = self.reshape2(y, (-1, 1))
-        loss = self.softmax_cross_entropy(out, y)
+        logits = self.forward(x)
+        loss = self.loss_fn(logits, self.fold_labels(y, (-1, 1)))
         self.optimizer(loss)
-        return out, loss
+        return logits, loss
 
     def get_states(self):
-        ret = super().get_states()
-        ret[self.hx.name] = self.hx
-        ret[self.cx.name] = self.cx
-        return ret
+        states = super().get_states()
+        states.update((t.name, t) for t in self.state.values())
+        return states
 
     def set_states(self, states):
-        self.hx.copy_from(states[self.hx.name])
-        self.cx.copy_from(states[self.cx.name])
+        for t in self.state.values():
+            t.copy_from(states[t.name])
         super().set_states(states)
 
 
@@ -131,9 +150,7 @@ def sample(model, data, dev, seed, nsamples=100, use_max=False):
     inputs = [tensor.from_numpy(one_hot(i, data.vocab_size), dev)
               for i in ids]
     # generation runs with batch 1: fresh state tensors of that shape
-    model.hx = tensor.Tensor((1, model.hidden_size), dev)
-    model.cx = tensor.Tensor((1, model.hidden_size), dev)
-    model.reset_states(dev)
+    model.new_state(1, dev)
     outputs = model(inputs)
     text = list(seed)
     prob = tensor.to_numpy(tensor.softmax(outputs))[-1]

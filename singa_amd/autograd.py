@@ -1013,44 +1013,55 @@ def add_bias(x, b, axis=0):
     return AddBias(axis)(x, b)[0]
 
 
+def _scaled_product(scale, X, Y, into=None, keep=0.0):
+    """``scale * X @ Y`` (+ ``keep * into``) as ONE product launch: the scale
+    and the accumulation are part of the GEMM kernel's epilogue."""
+    if into is None:
+        into = singa.Tensor([X.shape()[0], Y.shape()[1]], X.device(),
+                            X.data_type())
+    singa.MultWithScale(scale, X, Y, keep, into)
+    return into
+
+
 class Gemm(Operator):
-    """Y = alpha * A' * B' + beta * C."""
+    """Y = alpha * op(A) @ op(B) + beta * C, ``op`` an optional transposition
+    (ONNX Gemm).  alpha, beta and the addition of C ride on the product
+    kernel; the transpositions are stride views."""
 
     def __init__(self, alpha=1.0, beta=1.0, transA=0, transB=0):
         super(Gemm, self).__init__()
-        self.alpha = alpha
-        self.beta = beta
-        self.transA = transA
-        self.transB = transB
+        self.alpha, self.beta = float(alpha), float(beta)
+        self.transA, self.transB = int(transA), int(transB)
+
+    def _operands(self, A, B):
+        return (singa.DefaultTranspose(A) if self.transA else A,
+                singa.DefaultTranspose(B) if self.transB else B)
 
     def forward(self, A, B, C=None):
-        _A = singa.DefaultTranspose(A) if self.transA == 1 else A
-        _B = singa.DefaultTranspose(B) if self.transB == 1 else B
+        left, right = self._operands(A, B)
         if training:
-            self.inputs = (_A, _B, C)
-        tmpM = singa.Mult(_A, _B)
-        if self.alpha != 1.0:
-            tmpM = singa.MultFloat(tmpM, self.alpha)
-        if C is not None:
-            c = C if self.beta == 1.0 else singa.MultFloat(C, self.beta)
-            tmpM = singa.__add__(tmpM, c)
-        return tmpM
+            self.inputs = (left, right, C)
+        if C is None:
+            return _scaled_product(self.alpha, left, right)
+        rows, cols = left.shape()[0], right.shape()[1]
+        # start from C broadcast to the result's shape, accumulate onto it
+        y = singa.Contiguous(singa.Broadcast(C, [rows, cols]))
+        if y is C or y.block() is C.block():
+            y = y.Clone()
+        return _scaled_product(self.alpha, left, right, into=y, keep=self.beta)
 
     def backward(self, dy):
-        _A, _B, C = self.inputs
-        da = singa.MultFloat(singa.Mult(dy, singa.DefaultTranspose(_B)),
-                             self.alpha)
-        if self.transA:
-            da = singa.DefaultTranspose(da)
-        db = singa.MultFloat(singa.Mult(singa.DefaultTranspose(_A), dy),
-                             self.alpha)
-        if self.transB:
-            db = singa.DefaultTranspose(db)
+        left, right, C = self.inputs
+        # d op(A) = alpha * dy @ op(B)^T ; d op(B) = alpha * op(A)^T @ dy
+        grads = [_scaled_product(self.alpha, dy, singa.DefaultTranspose(right)),
+                 _scaled_product(self.alpha, singa.DefaultTranspose(left), dy)]
+        for i, flipped in enumerate((self.transA, self.transB)):
+            if flipped:
+                grads[i] = singa.DefaultTranspose(grads[i])
         if C is not None:
-            dc = back_broadcast(dy.shape(), C.shape(),
-                                singa.MultFloat(dy, self.beta))
-            return da, db, dc
-        return da, db
+            dc = dy if self.beta == 1.0 else singa.MultFloat(dy, self.beta)
+            grads.append(back_broadcast(dy.shape(), C.shape(), dc))
+        return tuple(grads)
 
 
 def gemm(A, B, C=None, alpha=1.0, beta=1.0, transA=0, transB=0):
@@ -1566,37 +1577,39 @@ def slice(x, starts, ends, axes=None, steps=None):
 
 
 class Split(Operator):
+    """Cut ``x`` along ``axis`` into pieces of the sizes ``parts`` (or into
+    ``num_output`` equal pieces) with one strided-copy launch per piece."""
 
     def __init__(self, axis, parts, num_output=None):
         super(Split, self).__init__()
-        self.axis = axis
-        self.parts = parts
-        self.num_output = num_output
-        if self.parts is None:
-            assert self.num_output is not None, \
-                "For (parts, num_output), it at least requires one."
+        if parts is None and num_output is None:
+            raise ValueError("Split needs the piece sizes or their number")
+        self.axis, self.parts, self.num_output = axis, parts, num_output
 
     def forward(self, x):
-        x_shape = list(x.shape())
-        self.axis = self.axis % len(x_shape)
+        shape = list(x.shape())
+        self.axis %= len(shape)
         if self.parts is None:
-            self.parts = [x_shape[self.axis] // self.num_output
-                          ] * self.num_output
-        self._like = (x_shape, x.device(), x.data_type())
+            each, rest = divmod(shape[self.axis], self.num_output)
+            assert rest == 0, "Split: %d is not divisible into %d pieces" % (
+                shape[self.axis], self.num_output)
+            self.parts = [each] * self.num_output
+        self._like = (shape, x.device(), x.data_type())
         return tuple(singa.SplitOn(x, self.parts, self.axis))
 
     def backward(self, *dys):
-        # outputs that nothing consumed have no gradient: they contribute zeros
-        x_shape, dev, dtype = self._like
-        dys = list(dys)
-        for i, (dy, part) in enumerate(zip(dys, self.parts)):
-            if dy is None:
-                shape = list(x_shape)
-                shape[self.axis] = part
-                z = singa.Tensor(shape, dev, dtype)
-                z.SetFloatValue(0.0)
-                dys[i] = z
-        return singa.ConcatOn(singa.VecTensor(dys), self.axis)
+        # a piece nothing consumed has no gradient: it contributes zeros
+        shape, dev, dtype = self._like
+
+        def zeros(extent):
+            z = singa.Tensor(shape[:self.axis] + [extent] +
+                             shape[self.axis + 1:], dev, dtype)
+            z.SetFloatValue(0.0)
+            return z
+
+        pieces = [dy if dy is not None else zeros(extent)
+                  for dy, extent in zip(dys, self.parts)]
+        return singa.ConcatOn(singa.VecTensor(pieces), self.axis)
 
 
 def split(x, axis, parts, num_output=None):
@@ -1766,34 +1779,36 @@ def pad(x, mode, pads, constant=0.):
 
 
 class UpSample(Operator):
-    """Nearest-neighbour up-sampling by integer scales."""
+    """Nearest-neighbour up-sampling by an integer factor per dimension
+    (ONNX Upsample): y[..., i * s + j, ...] = x[..., i, ...]."""
 
     def __init__(self, mode, scales):
         super(UpSample, self).__init__()
+        if str(mode).lower() != "nearest":
+            raise ValueError("UpSample: only mode 'nearest' is implemented, "
+                             "got %r" % (mode,))
+        self.mode = "nearest"
         self.scales = scales
-        self.mode = mode.lower()
-        if self.mode != "nearest":
-            assert False, "only support nearest mode."
+
+    def _factors(self, rank):
+        f = [int(v) for v in np.asarray(self.scales).reshape(-1)]
+        assert len(f) == rank, "UpSample: one scale per dimension"
+        self.scales = f
+        return f
 
     def forward(self, x):
-        if isinstance(self.scales, np.ndarray):
-            self.scales = self.scales.tolist()
-        self.scales = [int(s) for s in self.scales]
         self.x_shape = list(x.shape())
-        for axis, s in enumerate(self.scales):
-            if s != 1:
-                x = x.Repeat([s], axis)
+        for axis, f in enumerate(self._factors(len(self.x_shape))):
+            if f > 1:
+                x = x.Repeat([f], axis)
         return x
 
     def backward(self, dy):
-        # y[..., i * s + j, ...] = x[..., i, ...]  ->  sum over j
-        inter, axes = [], []
-        for i, (n, s) in enumerate(zip(self.x_shape, self.scales)):
-            inter += [n, s]
-            axes.append(2 * i + 1)
-        d = singa.Reshape(dy, inter)
-        dx = singa.ReduceND(d, axes, "sum")
-        return singa.Reshape(dx, self.x_shape)
+        # view dy as (n0, s0, n1, s1, ...) and sum the s axes in one reduction
+        split = [v for pair in zip(self.x_shape, self.scales) for v in pair]
+        summed = singa.ReduceND(singa.Reshape(dy, split),
+                                list(range(1, len(split), 2)), "sum")
+        return singa.Reshape(summed, self.x_shape)
 
 
 def upsample(x, mode, scales):

@@ -199,12 +199,80 @@ def build_cpp(force=False, verbose=True):
     return outs
 
 
+SANITIZE_FLAGS = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                  "-fno-omit-frame-pointer", "-O1", "-g"]
+
+
+def build_sanitized(outdir, verbose=True):
+    """Host-side code under AddressSanitizer + UndefinedBehaviorSanitizer:
+    the runtime extension (``<outdir>/_rt<suffix>``), the C++ API library
+    (``<outdir>/lib``) and its test program (``<outdir>/bin/singa_cpp_test``).
+    Only host translation units are instrumented; the HIP kernel objects are
+    linked as built by ``build_hip`` (device code cannot be sanitized here).
+    The reference has no sanitizer configuration (CMakeLists.txt:48-66)."""
+    build_hip(False, verbose)
+    obj = os.path.join(outdir, "obj")
+    for d in (obj, os.path.join(outdir, "lib"), os.path.join(outdir, "bin")):
+        os.makedirs(d, exist_ok=True)
+    rt = os.path.join(CSRC, "runtime")
+    cpp = os.path.join(CSRC, "cpp")
+    inc = os.path.join(cpp, "include")
+    hd = os.path.join(CSRC, "hip")
+    _embed_opencl_sources(os.path.join(cpp, "src", "core", "opencl"))
+    base = ["g++", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-parameter"] + \
+        SANITIZE_FLAGS
+    # ---- _rt
+    rt_srcs = [os.path.join(rt, f) for f in sorted(os.listdir(rt)) if f.endswith(".cc")]
+    rt_srcs.append(os.path.join(CSRC, "bindings", "rt_bind.cc"))
+    jobs, rt_objs = [], []
+    for s in rt_srcs:
+        o = os.path.join(obj, "rt_" + os.path.basename(s) + ".o")
+        rt_objs.append(o)
+        if _newer(o, [s] + _headers(rt)):
+            jobs.append(base + ["-fvisibility=hidden", "-c", s, "-o", o] + _py_includes())
+    # ---- C++ API
+    flags = base + ["-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROCM, "include"),
+                    "-I" + inc]
+    srcs = []
+    for root, _, files in os.walk(os.path.join(cpp, "src")):
+        srcs += [os.path.join(root, f) for f in sorted(files) if f.endswith(".cc")]
+    srcs += [os.path.join(rt, f) for f in ("graph.cc", "logging.cc", "snapshot.cc")]
+    hdrs = _headers(inc, rt, hd)
+    cpp_objs = []
+    for s in srcs:
+        o = os.path.join(obj, "cpp_" + os.path.relpath(s, CSRC).replace(os.sep, "_") + ".o")
+        cpp_objs.append(o)
+        if _newer(o, [s] + hdrs):
+            jobs.append(flags + ["-c", s, "-o", o])
+    if jobs and verbose:
+        print("[singa_amd.build] compiling %d sources with %s" % (
+            len(jobs), SANITIZE_FLAGS[0]))
+    _compile_many(jobs, 8)
+    target = os.path.join(outdir, "_rt" + EXT_SUFFIX)
+    _run(["g++", "-shared", "-o", target] + rt_objs + SANITIZE_FLAGS[:1] + ["-lpthread"])
+    hip_objs = [os.path.join(OBJ, "hip_" + f + ".o")
+                for f in sorted(os.listdir(hd)) if f.endswith(".hip")]
+    lib = os.path.join(outdir, "lib", "libsinga_amd_cpp.so")
+    _run(["g++", "-shared", "-o", lib] + cpp_objs + hip_objs + SANITIZE_FLAGS[:1] +
+         ["-L" + os.path.join(ROCM, "lib"), "-lamdhip64",
+          "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+    exe = os.path.join(outdir, "bin", "singa_cpp_test")
+    _run(flags + [os.path.join(cpp, "test", "test_main.cc"), "-o", exe,
+                  "-L" + os.path.join(outdir, "lib"), "-lsinga_amd_cpp",
+                  "-Wl,-rpath,$ORIGIN/../lib",
+                  "-Wl,-rpath," + os.path.join(ROCM, "lib"), "-lpthread"])
+    return [target, lib, exe]
+
+
 def build_all(force=False, verbose=True):
     return [build_rt(force, verbose), build_hip(force, verbose)] + \
         build_cpp(force, verbose)
 
 
 if __name__ == "__main__":
-    outs = build_all(force="--force" in sys.argv)
+    if "--sanitize" in sys.argv:
+        outs = build_sanitized(sys.argv[sys.argv.index("--sanitize") + 1])
+    else:
+        outs = build_all(force="--force" in sys.argv)
     for o in outs:
         print("built", o)

@@ -220,7 +220,12 @@ class HipGPU(Device):
         from .math_hip import HipMath
         self.math = HipMath(self)
         with torch.cuda.device(gpu_id):
-            self.stream_comm = torch.cuda.Stream(device=gpu_id)   # "s"
+            # The collective's stream has high priority: its kernels are few
+            # and short, and the backward pass on the compute stream would
+            # otherwise keep every CU busy with queued convolution workgroups
+            # while a bucket waits to go out.
+            self.stream_comm = torch.cuda.Stream(device=gpu_id,
+                                                 priority=-1)     # "s"
             self.stream_pack = torch.cuda.Stream(device=gpu_id)   # "c1"
             self.stream_unpack = torch.cuda.Stream(device=gpu_id)  # "c2"
             # philox state: [seed, offset]; the offset is advanced on the device
@@ -236,6 +241,8 @@ class HipGPU(Device):
         # set by the communicator: its collectives are stream ordered (RCCL)
         # and may be captured into the step's hipGraph
         self.collectives_capturable = False
+        self.communicator = None   # set with the flag above
+        self._watched = []         # (device word, message): see watch_flag
         self._stamps = None   # device-side profile of the captured graph
 
     def _new_storage(self, n, tdtype):
@@ -254,6 +261,24 @@ class HipGPU(Device):
 
     def stream_handle(self):
         return torch.cuda.current_stream(self.torch_device).cuda_stream
+
+    # -- device-side error words -------------------------------------------------
+    def watch_flag(self, word, message):
+        """Register a one-element device tensor that kernels set non-zero when
+        they detect that their result is invalid (e.g. a bounded grid barrier
+        that timed out).  ``check_flags`` raises for it."""
+        self._watched.append((word, message))
+
+    def check_flags(self):
+        """Called where the host reads device memory (the natural
+        synchronisation points of a training loop): raise if a watched word
+        has been set since the last check, and clear it."""
+        if not self._watched or torch.cuda.is_current_stream_capturing():
+            return
+        for word, message in self._watched:
+            if int(word.item()) != 0:
+                word.zero_()
+                raise RuntimeError(message)
 
     def side_streams(self):
         return (self.stream_pack, self.stream_comm, self.stream_unpack)
@@ -328,19 +353,7 @@ class HipGPU(Device):
                         finally:
                             g.set_verbosity(self._verbosity)
                         return
-                    try:
-                        self._replay = _HipGraphReplay(self, serial)
-                    except Exception as e:      # noqa: BLE001
-                        if not self.collectives_capturable:
-                            raise
-                        # the step could not be captured with its collectives
-                        # inside: keep them between captured segments instead
-                        print("capture of the step with its collectives "
-                              "failed (%s); capturing around them" % (e,),
-                              file=sys.stderr, flush=True)
-                        self.collectives_capturable = False
-                        torch.cuda.synchronize(self.torch_device)
-                        self._replay = _HipGraphReplay(self, serial)
+                    self._replay = self._capture(serial)
                 if self._stamps is not None:
                     self._stamps.before_replay(g.iteration(),
                                                self._skip_iteration)
@@ -348,6 +361,37 @@ class HipGPU(Device):
                 g.FinishIteration()
         finally:
             self._graph_enabled = prev
+
+    def _capture(self, serial):
+        """Capture the recorded step.  With collectives inside the capture
+        every rank must end up with the same kind of step: the ranks agree on
+        the outcome over the host control group, and if the capture failed
+        anywhere, all of them capture again with the collectives between the
+        hipGraph segments (a rank replaying a graph with the collective inside
+        against one issuing it eagerly would pair different sequences)."""
+        self.math.sync_conv_plans(self.communicator)
+        if not self.collectives_capturable:
+            return _HipGraphReplay(self, serial)
+        replay, err = None, None
+        try:
+            replay = _HipGraphReplay(self, serial)
+        except Exception as e:      # noqa: BLE001
+            err = e
+        comm = self.communicator
+        agreed = comm.agree(replay is not None) if comm is not None \
+            else replay is not None
+        if agreed:
+            return replay
+        print("capture of the step with its collectives failed%s; "
+              "capturing around them" % (
+                  " (%s)" % (err,) if err is not None else " on another rank"),
+              file=sys.stderr, flush=True)
+        del replay
+        self.collectives_capturable = False
+        if comm is not None:
+            comm.capturable = False
+        torch.cuda.synchronize(self.torch_device)
+        return _HipGraphReplay(self, serial)
 
     def PrintTimeProfiling(self):
         if self._stamps is not None:
@@ -487,22 +531,6 @@ class _GraphStamps(object):
         g.AddTimeElapsed(vals[self.n])
 
 
-def _drain_collective_watchdog(dev):
-    """Let the process group's watchdog thread retire every collective issued
-    so far before a capture starts.
-
-    The watchdog polls the completion event of each outstanding collective.
-    On ROCm an event query fails with "operation not permitted on an event
-    last recorded in a capturing stream" as soon as the stream the event was
-    recorded on is capturing -- also for events recorded *before* the capture
-    began -- and the watchdog then aborts the process.  Collectives issued
-    inside the capture are never handed to the watchdog; the ones from the
-    eager warm-up iteration are: wait until they have finished on the GPU and
-    give the watchdog (which wakes every 100 ms) time to drop them."""
-    torch.cuda.synchronize(dev.torch_device)
-    time.sleep(float(os.environ.get("SINGA_CAPTURE_DRAIN_MS", "350")) / 1e3)
-
-
 class _HipGraphReplay(object):
     """Captured form of one device graph.  With stream-ordered collectives
     (RCCL) the whole plan is ONE hipGraph: the communication nodes fork the
@@ -510,6 +538,9 @@ class _HipGraphReplay(object):
     so the collectives are graph nodes like the kernels around them.  With a
     host-side collective backend the plan is cut at the communication nodes,
     which then run eagerly between the captured segments."""
+
+    # tests set this to make the next capture with collectives inside fail
+    fail_next = False
 
     def __init__(self, dev, serial):
         self.serial = serial
@@ -549,8 +580,9 @@ class _HipGraphReplay(object):
                 not any(r[0] == "eager" for r in ranges):
             stamps = _GraphStamps(dev, len(names), self.verbosity, names)
         dev._stamps = stamps
-        if dev.collectives_capturable:
-            _drain_collective_watchdog(dev)
+        if dev.collectives_capturable and _HipGraphReplay.fail_next:
+            _HipGraphReplay.fail_next = False
+            raise RuntimeError("capture failure requested by a test")
         pool = torch.cuda.graph_pool_handle()
         cap_stream = torch.cuda.Stream(device=dev.torch_device)
         dev.phase = "capture"

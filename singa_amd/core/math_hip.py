@@ -603,9 +603,12 @@ class HipMath(object):
     # Plans persist in a JSON file keyed by GPU architecture and kernel build
     # (SINGA_CONV_PLAN_CACHE: path, or 0 for no file), so later processes --
     # and shapes first met under stream capture -- start from measured plans.
-    # With several ranks only rank 0 consults the file or measures; every
-    # rank takes rank 0's choice through a broadcast, so all ranks launch
-    # identical kernels.  SINGA_CONV_AUTOTUNE=0 keeps the heuristic.
+    # With several ranks only rank 0 consults the file or measures; the other
+    # ranks run the eager first iteration on the heuristic and take rank 0's
+    # whole table in ONE broadcast over the host control group before the step
+    # is captured (``sync_conv_plans``), so all ranks replay identical kernels
+    # and no collective is issued per geometry.  SINGA_CONV_AUTOTUNE=0 keeps
+    # the heuristic.
     _conv_plans = {}
     _CONV_CANDIDATES = ((64, 512), (64, 1024), (64, 2048), (128, 256),
                         (128, 512), (128, 1024), (128, 2048))
@@ -694,28 +697,35 @@ class HipMath(object):
             if not _CONV_AUTOTUNE:
                 return False
             capturing = torch.cuda.is_current_stream_capturing()
-            ranks = _world_size()
-            if ranks > 1 and capturing:
-                return False  # no collective inside a capture: heuristic plan
+            if _world_size() > 1 and _rank() != 0:
+                return False  # rank 0's table arrives before the capture
             name = repr(full)
-            if ranks <= 1 or _rank() == 0:
-                stored = self._plan_store()[1].get(name)
-                if stored is not None:
-                    plan = (int(stored[0]), int(stored[1]))
-                elif not capturing:
-                    plan = self._measure_plan(g, launch)
-                    measured = True
-                    self._persist_plan(name, plan)
-            if ranks > 1:
-                word = torch.tensor(list(plan or (0, 0)), dtype=torch.int32,
-                                    device=self.dev.torch_device)
-                torch.distributed.broadcast(word, 0)
-                plan = tuple(int(v) for v in word.tolist())
+            stored = self._plan_store()[1].get(name)
+            if stored is not None:
+                plan = (int(stored[0]), int(stored[1]))
+            elif not capturing:
+                plan = self._measure_plan(g, launch)
+                measured = True
+                self._persist_plan(name, plan)
             if plan is None:
                 return False  # first met under capture, nothing stored
             self._conv_plans[full] = plan
         g.tile, g.split_target = plan
         return measured
+
+    def sync_conv_plans(self, comm):
+        """Every rank adopts rank 0's launch plans (one host-side broadcast
+        of the table; a no-op for a lone rank)."""
+        if comm is None or _world_size() <= 1 or not _CONV_AUTOTUNE:
+            return
+        table = comm.broadcast_object(
+            {repr(k): list(v) for k, v in self._conv_plans.items()}
+            if _rank() == 0 else None)
+        if _rank() != 0 and table:
+            import ast
+            for name, plan in table.items():
+                type(self)._conv_plans[ast.literal_eval(name)] = (
+                    int(plan[0]), int(plan[1]))
 
     def _split_scratch(self, g, out, rows, cols, groups):
         """16-bit outputs: lend the launcher a float buffer of the output's

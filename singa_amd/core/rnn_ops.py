@@ -420,9 +420,20 @@ def _run_forward(x, hx, cx, W, h, lens, training):
     cy = Tensor(shape, dev, x.data_type())
     reads = [x, hx, cx, W] + ([lens] if lens is not None else [])
     if getattr(h, "_bar", None) is None:
-        # barrier words of the single-launch LSTM kernels: arrival counter and
-        # give-up flag (non-zero after a launch = a wait hit its bound)
-        h._bar = torch.zeros(2, dtype=torch.int32, device=dev.torch_device)
+        # barrier words of the single-launch LSTM kernels: arrival counter,
+        # give-up flag of the last launch, and a sticky give-up flag that no
+        # launch clears.  A wait that hit its bound means the workgroups were
+        # not all resident (e.g. another process shares the GPU) and the
+        # sequence was computed from incomplete data: the device raises at the
+        # next read of device memory by the host.
+        h._bar = torch.zeros(4, dtype=torch.int32, device=dev.torch_device)
+        if hasattr(dev, "watch_flag"):
+            dev.watch_flag(
+                h._bar[2:3],
+                "a persistent LSTM kernel gave up waiting at its grid barrier "
+                "(its workgroups were not all resident); results since the "
+                "last check are invalid.  SINGA_LSTM_SEQ=0 selects the "
+                "per-step kernels.")
     if lens is not None and getattr(h, "_steps", None) is None:
         h._steps = torch.arange(h.seq_length, dtype=torch.float32).view(
             h.seq_length, 1).to(dev.torch_device)

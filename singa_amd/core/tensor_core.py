@@ -283,6 +283,9 @@ class Tensor(object):
         if v.dtype == torch.bfloat16:
             v = v.float()
         arr = v.to("cpu").contiguous().numpy().reshape(-1)
+        check = getattr(self._dev, "check_flags", None)
+        if check is not None:
+            check()
         if n is not None:
             arr = arr[:n]
         return arr.astype(np_dtype, copy=True)
@@ -319,6 +322,7 @@ class Tensor(object):
 
     # ---- norms (host results, unsafe inside a recorded graph) ----------------------------------
     def L1(self):
+        _no_host_result_while_recording(self._dev, "L1")
         n = max(self.Size(), 1)
         return self._dev.math.asum(self.view()) / n
 
@@ -326,6 +330,7 @@ class Tensor(object):
         return self.L1()
 
     def L2(self):
+        _no_host_result_while_recording(self._dev, "L2")
         n = max(self.Size(), 1)
         return self._dev.math.nrm2(self.view()) / n
 
@@ -664,7 +669,22 @@ def SumAll(x):
     return out
 
 
+def _no_host_result_while_recording(dev, what):
+    """Reductions that hand a Python float back read the operand at call
+    time.  While a step is being recorded the operand's producers have not
+    run (and never run in program order under replay), so the value would be
+    garbage -- the reference documents the same hazard for ``Sum<float>`` and
+    the norms (src/core/tensor/tensor.cc:815-843, 1211-1227) and returns it
+    silently.  Here the call fails."""
+    if dev.graph_enabled():
+        raise RuntimeError(
+            "%s returns a host value and cannot be part of a recorded graph: "
+            "call it outside train_one_batch / with graph mode off, or use "
+            "the tensor-valued form (SumAll, autograd.reduce_sum)" % what)
+
+
 def SumAsFloat(x):
+    _no_host_result_while_recording(x._dev, "SumAsFloat")
     return x._dev.math.sum_float(x.view())
 
 

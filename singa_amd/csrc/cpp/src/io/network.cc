@@ -318,6 +318,9 @@ bool NetworkThread::Parse(Conn *c) {
     uint32_t id = GetU32(c->rbuf.data() + 1);
     uint32_t ms = GetU32(c->rbuf.data() + 5), ps = GetU32(c->rbuf.data() + 9);
     size_t total = kHeader + size_t(ms) + ps;
+    // lengths come from the peer: a frame nobody sends (over 1 GiB) is a
+    // protocol violation, not a reason to buffer until memory runs out
+    if (total > (size_t(1) << 30)) return false;
     if (c->rbuf.size() < total) break;
     std::string meta = c->rbuf.substr(kHeader, ms);
     std::string payload = c->rbuf.substr(kHeader + ms, ps);

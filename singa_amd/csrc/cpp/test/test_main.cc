@@ -1220,8 +1220,16 @@ static int JpegTool(int argc, char **argv) {
 }
 
 int main(int argc, char **argv) {
-  if (argc > 1 && std::string(argv[1]).rfind("--jpeg-", 0) == 0)
-    return JpegTool(argc, argv);
+  if (argc > 1 && std::string(argv[1]).rfind("--jpeg-", 0) == 0) {
+    // a file the codec rejects (a failed CHECK throws) is exit status 1; only a
+    // fault inside the codec ends the tool by a signal
+    try {
+      return JpegTool(argc, argv);
+    } catch (const std::exception &e) {
+      std::fprintf(stderr, "rejected: %s\n", e.what());
+      return 1;
+    }
+  }
   bool opencl = false;
   for (int i = 1; i < argc; ++i) {
     if (std::string(argv[i]) == "--gpu") g_gpu = true;

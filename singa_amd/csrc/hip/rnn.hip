@@ -167,9 +167,14 @@ __device__ __forceinline__ void st_agent(float *p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// bar[0]: arrivals so far; bar[1]: non-zero once any wait has given up.
+// bar[0]: arrivals so far; bar[1]: non-zero once any wait of this launch has
+// given up; bar[2]: the same, but never cleared by a launch (the host reads
+// it at its next synchronisation point).
 __device__ __forceinline__ void grid_arrive(unsigned *bar) {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // stores complete
+  // every wave drains its own write-through stores before the workgroup
+  // signals: neither a workgroup-scope fence nor s_barrier waits for vector
+  // memory operations
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
     __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -185,6 +190,8 @@ __device__ __forceinline__ void grid_wait(unsigned *bar, unsigned target) {
         break;
       if (++spins > kSpinLimit) {
         __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(bar + 2, 1u, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -496,9 +503,10 @@ int sa_lstm_seq_supported(int64_t batch, int64_t hidden) {
 int sa_lstm_seq(const LstmSeqArgs *args, int backward, hipStream_t s) {
   const LstmSeqArgs &a = *args;
   if (!sa_lstm_seq_supported(a.batch, a.hidden) || a.steps < 1) return -3;
-  // barrier counter and give-up flag start at zero for every launch (an
-  // ordinary kernel: a memset node is not reliably ordered against the
-  // kernel nodes of a captured graph)
+  // barrier counter and this launch's give-up flag start at zero for every
+  // launch (an ordinary kernel: a memset node is not reliably ordered against
+  // the kernel nodes of a captured graph); the sticky word bar[2] is left
+  // alone
   zero_async(a.bar, 2 * sizeof(unsigned), s);
   switch (a.hidden / 32) {
     case 1: launch_lstm_seq<1>(a, backward != 0, s); break;

@@ -81,7 +81,11 @@ class BinFileReader {
   bool Open(const std::string &path, int /*capacity*/ = 10485760) {
     path_ = path;
     f_.open(path, std::ios::binary | std::ios::in);
-    return f_.is_open();
+    if (!f_.is_open()) return false;
+    f_.seekg(0, std::ios::end);
+    size_ = static_cast<uint64_t>(f_.tellg());
+    f_.seekg(0);
+    return true;
   }
   void Close() {
     if (f_.is_open()) f_.close();
@@ -104,20 +108,26 @@ class BinFileReader {
     std::ifstream fin(path_, std::ios::binary | std::ios::in);
     SA_CHECK(fin.is_open()) << "Cannot open file " << path_;
     int count = 0;
-    while (true) {
-      char magic[4];
+    fin.seekg(0, std::ios::end);
+    const uint64_t size = static_cast<uint64_t>(fin.tellg());
+    fin.seekg(0);
+    uint64_t at = 0;
+    // a length field that points beyond the end of the file ends the count
+    auto skip_field = [&]() {
       uint64_t len = 0;
-      fin.read(magic, 4);
-      if (!fin.good()) break;
-      if (magic[2] == 1) {
-        fin.read(reinterpret_cast<char *>(&len), 8);
-        if (!fin.good()) break;
-        fin.seekg(static_cast<std::streamoff>(len), std::ios::cur);
-      }
       fin.read(reinterpret_cast<char *>(&len), 8);
-      if (!fin.good()) break;
-      fin.seekg(static_cast<std::streamoff>(len), std::ios::cur);
-      if (!fin.good()) break;
+      if (!fin.good() || len > size - (at + 8)) return false;
+      at += 8 + len;
+      fin.seekg(static_cast<std::streamoff>(at));
+      return fin.good();
+    };
+    while (at + 4 <= size) {
+      char magic[4];
+      fin.read(magic, 4);
+      if (!fin.good() || magic[0] != 's' || magic[1] != 'g') break;
+      at += 4;
+      if (magic[2] == 1 && !skip_field()) break;
+      if (!skip_field()) break;
       ++count;
     }
     return count;
@@ -134,12 +144,17 @@ class BinFileReader {
     uint64_t len = 0;
     f_.read(reinterpret_cast<char *>(&len), 8);
     if (f_.gcount() < 8) return false;
+    // a damaged length must not size an allocation: the field has to fit in
+    // what is left of the file
+    const uint64_t at = static_cast<uint64_t>(f_.tellg());
+    if (at > size_ || len > size_ - at) return false;
     out->resize(len);
     f_.read(&(*out)[0], static_cast<std::streamsize>(len));
     return static_cast<uint64_t>(f_.gcount()) == len;
   }
   std::string path_;
   std::ifstream f_;
+  uint64_t size_ = 0;
 };
 
 }  // namespace singa_amd

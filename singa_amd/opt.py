@@ -625,6 +625,11 @@ class DistOpt(object):
         self.wait()
         for p in chosen:
             p /= self.world_size
+        # 16-bit parameters are stepped from float32 master copies: the
+        # averaged values must reach those, or the next step overwrites them
+        refresh = getattr(self.opt, "sync_masters", None)
+        if refresh is not None and chosen:
+            refresh(dict(enumerate(chosen)))
         self.partial = 0 if index == turn else turn
         self.opt.step()
 

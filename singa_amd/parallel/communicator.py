@@ -1,8 +1,12 @@
 """Collective communication for synchronous data-parallel training.
 
-One process drives one GPU; the collectives are RCCL's (``torch.distributed``
-backend ``"nccl"`` on ROCm) over xGMI, or gloo between CPU ranks.  The
-interface is the reference's ``Communicator`` (include/singa/io/communicator.h
+One process drives one GPU.  Device collectives are RCCL's over xGMI, on a
+communicator this module creates itself (``ncclCommInitRank``, the unique id
+travelling over the host control group); host-side control traffic (rendezvous,
+agreement on fallbacks, the convolution plan table) and CPU ranks use a gloo
+group of ``torch.distributed``.  No NCCL process group of ``torch.distributed``
+exists, hence no watchdog thread that polls events of the streams a hipGraph
+capture runs on.  The interface is the reference's ``Communicator`` (include/singa/io/communicator.h
 :76-152, src/io/communicator.cc) so that ``opt.DistOpt`` and user code carry
 over, but the data path is laid out for MI355X:
 
@@ -28,9 +32,9 @@ Ring collectives over xGMI are bound by the per-link rate, not by a switch:
 fewer, larger buckets amortise the ring's latency better than many small ones.
 """
 import atexit
+import ctypes
 import math
 import os
-import time
 import socket
 
 import torch
@@ -72,8 +76,9 @@ _STRICT = int(os.environ.get("SINGA_DIST_STRICT", "0"))
 _CAPTURE = os.environ.get("SINGA_DIST_CAPTURE", "1") != "0"
 
 
-# SINGA_RCCL_DIRECT=0 routes device collectives through torch.distributed's
-# work objects instead of calling RCCL on the communicator's stream directly
+# SINGA_RCCL_DIRECT=0 keeps RCCL out of the picture: device tensors are then
+# exchanged through host memory over the gloo control group (slow; a debugging
+# aid and the path of rehearsals that put several ranks on one GPU)
 _DIRECT = os.environ.get("SINGA_RCCL_DIRECT", "1") != "0"
 # SINGA_ALLREDUCE_TWO_PHASE=<elements>: buckets of at least that many elements
 # are summed as reduce-scatter + all-gather instead of one all-reduce (0 = off,
@@ -82,47 +87,71 @@ _DIRECT = os.environ.get("SINGA_RCCL_DIRECT", "1") != "0"
 _TWO_PHASE = int(os.environ.get("SINGA_ALLREDUCE_TWO_PHASE", "0"))
 
 
-class _Rccl(object):
-    """RCCL entry points called directly on the process group's communicator.
+class _UniqueId(ctypes.Structure):
+    """``ncclUniqueId``: 128 opaque bytes, passed to RCCL by value."""
+    _fields_ = [("internal", ctypes.c_char * 128)]
 
-    ``torch.distributed`` wraps every collective in a work object whose
-    completion event a watchdog thread polls.  A collective issued while a
-    hipGraph is being captured must never reach that thread (querying an event
-    recorded in a capturing stream aborts the process), and each wrapped call
-    also hops through the group's internal stream with two event syncs.  Here
-    the collective is enqueued on the caller's current stream with the
-    communicator the process group has already built (rendezvous, topology
-    and xGMI ring set-up stay torch's job): nothing to poll, one kernel per
-    collective, capturable like any other kernel launch."""
+
+class _Rccl(object):
+    """An RCCL communicator owned by this process, driven through ctypes.
+
+    Rank 0 draws the unique id (``ncclGetUniqueId``), the host control group
+    carries it to the other ranks, and every rank joins with
+    ``ncclCommInitRank`` on its own GPU (the role of reference
+    src/io/communicator.cc:73-114, with the id broadcast over gloo instead of
+    MPI).  A collective is one C call that enqueues one kernel on the
+    caller's current HIP stream: nothing wraps it in a work object, no thread
+    polls its completion, and it is captured into a hipGraph like any other
+    kernel launch."""
 
     _DTYPES = {torch.int8: 0, torch.uint8: 1, torch.int32: 2, torch.int64: 4,
                torch.float16: 6, torch.float32: 7, torch.float64: 8,
                torch.bfloat16: 9}
     _SUM = 0
 
-    def __init__(self, device):
-        import ctypes
-        path = os.path.join(os.path.dirname(torch.__file__), "lib",
-                            "librccl.so")
-        self.lib = ctypes.CDLL(path)
+    def __init__(self, device, rank, world, ctl_group):
+        path = os.environ.get("SINGA_RCCL_LIB") or os.path.join(
+            os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.lib = lib = ctypes.CDLL(path)
         vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
-        self.lib.ncclAllReduce.argtypes = [vp, vp, sz, ci, ci, vp, vp]
-        self.lib.ncclAllReduce.restype = ci
-        self.lib.ncclAllGather.argtypes = [vp, vp, sz, ci, vp, vp]
-        self.lib.ncclAllGather.restype = ci
-        self.lib.ncclReduceScatter.argtypes = [vp, vp, sz, ci, ci, vp, vp]
-        self.lib.ncclReduceScatter.restype = ci
-        self.lib.ncclGetErrorString.argtypes = [ci]
-        self.lib.ncclGetErrorString.restype = ctypes.c_char_p
-        group = dist.distributed_c10d._get_default_group()
-        backend = group._get_backend(device)
-        # the communicator exists once the group has run a collective
-        warm = torch.zeros(1, dtype=torch.float32, device=device)
-        dist.all_reduce(warm)
-        torch.cuda.synchronize(device)
-        self.comm = int(backend._comm_ptr())
+        lib.ncclGetUniqueId.argtypes = [ctypes.POINTER(_UniqueId)]
+        lib.ncclGetUniqueId.restype = ci
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(vp), ci, _UniqueId, ci]
+        lib.ncclCommInitRank.restype = ci
+        lib.ncclCommDestroy.argtypes = [vp]
+        lib.ncclCommDestroy.restype = ci
+        lib.ncclAllReduce.argtypes = [vp, vp, sz, ci, ci, vp, vp]
+        lib.ncclAllReduce.restype = ci
+        lib.ncclAllGather.argtypes = [vp, vp, sz, ci, vp, vp]
+        lib.ncclAllGather.restype = ci
+        lib.ncclReduceScatter.argtypes = [vp, vp, sz, ci, ci, vp, vp]
+        lib.ncclReduceScatter.restype = ci
+        lib.ncclGetErrorString.argtypes = [ci]
+        lib.ncclGetErrorString.restype = ctypes.c_char_p
+        self.comm = None
+        self.rank, self.world = rank, world
+        uid = _UniqueId()
+        blob = [None]
+        if rank == 0:
+            self._check(lib.ncclGetUniqueId(ctypes.byref(uid)),
+                        "ncclGetUniqueId")
+            blob[0] = bytes(bytearray(uid.internal))
+        if world > 1:
+            dist.broadcast_object_list(blob, src=0, group=ctl_group)
+        ctypes.memmove(ctypes.byref(uid), blob[0], 128)
+        torch.cuda.set_device(device)
+        torch.cuda.current_stream(device).synchronize()   # HIP context exists
+        comm = vp()
+        self._check(lib.ncclCommInitRank(ctypes.byref(comm), world, uid, rank),
+                    "ncclCommInitRank")
+        self.comm = comm.value
         if not self.comm:
-            raise RuntimeError("the process group has no RCCL communicator")
+            raise RuntimeError("ncclCommInitRank returned no communicator")
+
+    def close(self):
+        if self.comm:
+            comm, self.comm = self.comm, None
+            self.lib.ncclCommDestroy(comm)
 
     def _check(self, rc, what):
         if rc != 0:
@@ -199,52 +228,40 @@ class Communicator(object):
                             "local_rank, world_size, nccl_id, buffSize)")
         self._gpu = torch.cuda.is_available()
         self._owns_group = False
-        # SINGA_DIST_FORCE=1 builds the process group even for a single rank
+        # SINGA_DIST_FORCE=1 builds the groups even for a single rank
         # (exercises the RCCL path on a one-GPU machine)
         force = os.environ.get("SINGA_DIST_FORCE", "0") == "1"
+        want_host = os.environ.get("SINGA_DIST_BACKEND", "") == "gloo"
         if (self.world_size > 1 or force) and not dist.is_initialized():
             if self._gpu:
                 # more ranks than devices only happens in rehearsals with
                 # SINGA_DIST_BACKEND=gloo (RCCL refuses two ranks per GPU)
                 torch.cuda.set_device(
                     self.local_rank % torch.cuda.device_count())
-            backend = os.environ.get("SINGA_DIST_BACKEND") or (
-                "nccl" if self._gpu else "gloo")
+            # the host control group; device collectives never go through it
+            # unless RCCL is unavailable or switched off
             dist.init_process_group(
-                backend=backend,
-                init_method=init_method, rank=self.global_rank,
-                world_size=self.world_size)
+                backend="gloo", init_method=init_method,
+                rank=self.global_rank, world_size=self.world_size)
             self._owns_group = True
             atexit.register(self.close)
         # without a process group a lone rank's all-reduce is the identity
         self._active = dist.is_initialized()
-        self._host_backend = self._active and dist.get_backend() != "nccl"
-        # stream-ordered collectives can be part of a captured hipGraph
-        self.capturable = (self._active and not self._host_backend and
-                           _CAPTURE and not _DEBUG and not _STRICT)
         # fraction of a bucket a threshold-sparsified payload can carry when
         # the entries held back are kept in an accumulation tensor (entries
         # beyond the capacity stay in the accumulator and go out later);
         # without accumulation the capacity is the whole bucket
         self.spars_cap = float(os.environ.get("SINGA_SPARS_CAP", "1.0"))
-        self._rccl = None         # direct RCCL calls
-        self._no_direct = False   # set when the communicator handle is out of reach
-        if _DIRECT and self._active and not self._host_backend and self._gpu:
-            try:
-                self._rccl = _Rccl(torch.device(
-                    "cuda", torch.cuda.current_device()))
-            except (OSError, AttributeError, RuntimeError) as e:
-                # no direct handle on the communicator: collectives go through
-                # torch.distributed's work objects, which must stay outside
-                # captured graphs (its watchdog polls their events)
-                print("[rank %d] direct RCCL calls unavailable (%s); using "
-                      "torch.distributed collectives outside the captured "
-                      "step" % (self.global_rank, e), flush=True)
-                self._rccl = None
-                self._no_direct = True
-                self.capturable = False
+        self._rccl = None         # this process's RCCL communicator
+        if _DIRECT and self._active and self._gpu and not want_host:
+            self._rccl = self._join_rccl()
+        # device tensors travel through host memory when there is no RCCL
+        self._host_backend = self._active and self._rccl is None
+        # stream-ordered collectives can be part of a captured hipGraph
+        self.capturable = (self._rccl is not None and _CAPTURE and
+                           not _DEBUG and not _STRICT)
         probe = os.environ.get("SINGA_DIST_CAPTURE_PROBE", "1")
-        if self.capturable and self._rccl is not None and probe != "0" and \
+        if self.capturable and probe != "0" and \
                 (self.world_size > 1 or probe == "force"):
             self.capturable = self._probe_capture()
         self._dev = None          # device of the last synchronised tensors
@@ -254,14 +271,56 @@ class Communicator(object):
         self._warmed = False
 
     # ------------------------------------------------------------------ helpers
+    def _join_rccl(self):
+        """Create this rank's RCCL communicator; every rank learns whether all
+        of them succeeded (one that could not load or initialise RCCL makes
+        the whole job exchange through host memory instead of hanging the
+        others in their first collective)."""
+        device = torch.device("cuda", torch.cuda.current_device())
+        rccl, err = None, None
+        try:
+            rccl = _Rccl(device, self.global_rank, self.world_size, None)
+        except (OSError, AttributeError, RuntimeError) as e:
+            err = e
+        if not self.agree(rccl is not None):
+            if err is not None:
+                print("[rank %d] no RCCL communicator (%s); device tensors "
+                      "are exchanged through host memory" % (
+                          self.global_rank, err), flush=True)
+            if rccl is not None:
+                rccl.close()
+            return None
+        return rccl
+
+    def agree(self, ok):
+        """True when ``ok`` holds on every rank.  The exchange runs over the
+        host control group, so it never pairs with (or waits behind) a device
+        collective."""
+        if not self._active or self.world_size <= 1:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(int(flag[0]) == 1)
+
+    def broadcast_object(self, obj, src=0):
+        """``obj`` of rank ``src`` on every rank (host control group)."""
+        if not self._active or self.world_size <= 1:
+            return obj
+        box = [obj if self.global_rank == src else None]
+        dist.broadcast_object_list(box, src=src)
+        return box[0]
+
     def close(self):
-        """Leave the process group this communicator created (also run at
+        """Leave the groups this communicator created (also run at
         interpreter exit: a process that ends with the group's worker threads
         alive aborts in their destructors)."""
         try:
+            if self._gpu and (self._rccl is not None or self._owns_group):
+                torch.cuda.synchronize()
+            if self._rccl is not None:
+                self._rccl.close()
+                self._rccl = None
             if self._owns_group and dist.is_initialized():
-                if self._gpu:
-                    torch.cuda.synchronize()
                 dist.destroy_process_group()
             self._owns_group = False
         except Exception:       # noqa: BLE001 (best effort at shutdown)
@@ -288,9 +347,11 @@ class Communicator(object):
         return s
 
     def _remember(self, dev, tensors):
-        self._dev = dev
-        if dev.lang() != 0:
-            dev.collectives_capturable = self.capturable
+        if self._dev is not dev:
+            self._dev = dev
+            if dev.lang() != 0:
+                dev.collectives_capturable = self.capturable
+                dev.communicator = self
         seen = set(id(b) for b in self._blocks)
         for t in tensors:
             if id(t.block()) not in seen:
@@ -298,52 +359,36 @@ class Communicator(object):
                 seen.add(id(t.block()))
 
     def _staged(self, t):
-        """Device tensors with a host backend (gloo; used to rehearse the
-        multi-rank path on machines where RCCL cannot run, e.g. several ranks
-        on one GPU) go through host memory explicitly: the device is drained,
-        the collective runs on a host copy, the result is copied back on the
-        current stream.  (gloo's own device-tensor path waits for the device
-        from its worker thread, which was seen to stall with two ranks on one
-        GPU.)  RCCL collectives are stream ordered and take the tensor as is."""
-        return t.is_cuda and self._host_backend
+        """Device tensors without an RCCL communicator (rehearsals of the
+        multi-rank path with several ranks on one GPU, RCCL switched off or
+        unavailable) go through host memory explicitly: the device is drained,
+        the collective runs on a host copy over gloo, the result is copied
+        back on the current stream.  RCCL collectives are stream ordered and
+        take the tensor as is."""
+        return t.is_cuda and self._rccl is None
 
     def _direct(self, t):
-        """True when the collective on ``t`` is a direct RCCL call."""
-        if not (_DIRECT and t.is_cuda and self._active and
-                not self._host_backend and t.is_contiguous() and
-                t.dtype in _Rccl._DTYPES):
-            return False
-        if self._rccl is None:
-            if self._no_direct:
-                return False
-            # first use is in the eager iteration that precedes any capture
-            assert not torch.cuda.is_current_stream_capturing(), \
-                "the first collective of a process must not be captured"
-            try:
-                self._rccl = _Rccl(t.device)
-            except (OSError, AttributeError, RuntimeError):
-                self._no_direct = True
-                self.capturable = False
-                return False
-        return True
+        """True when the collective on ``t`` is an RCCL call."""
+        return (self._rccl is not None and t.is_cuda and t.is_contiguous()
+                and t.dtype in _Rccl._DTYPES)
 
     def _probe_capture(self):
         """Capture one small all-reduce on a side stream into a hipGraph,
         replay it and check the sum: the training step relies on exactly this
         (a collective as a graph node, forked from and joined to the capturing
-        stream).  Any failure, on any rank, makes every rank keep its
-        collectives outside the captured graphs (the step is then cut into
-        several hipGraphs around them)."""
+        stream).  Capture and replay are separate phases with an agreement
+        over the host group in between, so a rank whose capture failed never
+        leaves the others waiting inside a replayed collective.  Any failure,
+        on any rank, makes every rank keep its collectives outside the
+        captured graphs (the step is then cut into several hipGraphs around
+        them)."""
         device = torch.device("cuda", torch.cuda.current_device())
-        ok = 1.0
+        g = x = None
+        ok = True
         try:
             x = torch.ones(4096, dtype=torch.float32, device=device)
             self._rccl.all_reduce(x)
             torch.cuda.synchronize(device)
-            # nothing from this group may still be with the watchdog thread
-            # when a capture starts (its event queries fail during capture)
-            time.sleep(float(os.environ.get("SINGA_CAPTURE_DRAIN_MS",
-                                            "350")) / 1e3)
             g = torch.cuda.CUDAGraph()
             cap = torch.cuda.Stream(device=device)
             side = torch.cuda.Stream(device=device)
@@ -355,22 +400,25 @@ class Communicator(object):
                     self._rccl.all_reduce(x)
                 torch.cuda.current_stream(device).wait_stream(side)
                 x.mul_(1.0)
-            x.fill_(1.0)
-            g.replay()
-            g.replay()
-            torch.cuda.synchronize(device)
-            want = float(self.world_size) ** 2
-            if abs(float(x[0].item()) - want) > 1e-3 * want or \
-                    abs(float(x[-1].item()) - want) > 1e-3 * want:
-                ok = 0.0
         except Exception as e:          # noqa: BLE001 (capability probe)
-            print("[rank %d] captured all-reduce probe failed: %s" % (
+            print("[rank %d] capture of an all-reduce failed: %s" % (
                 self.global_rank, e), flush=True)
-            ok = 0.0
-        flag = torch.tensor([ok], dtype=torch.float32, device=device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        torch.cuda.synchronize(device)
-        agreed = bool(flag.item() > 0.5)
+            ok = False
+        agreed = self.agree(ok)
+        if agreed:
+            try:
+                x.fill_(1.0)
+                g.replay()
+                g.replay()
+                torch.cuda.synchronize(device)
+                want = float(self.world_size) ** 2
+                ok = abs(float(x[0].item()) - want) <= 1e-3 * want and \
+                    abs(float(x[-1].item()) - want) <= 1e-3 * want
+            except Exception as e:      # noqa: BLE001
+                print("[rank %d] replay of a captured all-reduce failed: %s"
+                      % (self.global_rank, e), flush=True)
+                ok = False
+            agreed = self.agree(ok)
         if not agreed and self.global_rank == 0:
             print("collectives stay outside the captured step "
                   "(SINGA_DIST_CAPTURE_PROBE=0 skips this check)", flush=True)
@@ -440,8 +488,11 @@ class Communicator(object):
 
     def _skip_body(self, dev):
         """While the step is captured into hipGraph segments around eagerly
-        executed collectives, a collective's body only binds its operands."""
-        return dev.phase == "capture" and not self.capturable
+        executed collectives, a collective's body only binds its operands.
+        The device's flag decides: it also drops to False when the capture of
+        a step with its collectives inside failed on some rank."""
+        return dev.phase == "capture" and not (
+            self.capturable and getattr(dev, "collectives_capturable", True))
 
     @staticmethod
     def _operand_views(dev, state, ts):

@@ -267,6 +267,61 @@ def test_distopt_partial_update_runs_and_syncs():
         assert np.all(np.isfinite(res[0][k]))
 
 
+def _partial_fp16(rank, world, holder):
+    from singa_amd import opt, tensor, device
+    dev = device.get_default_device()
+    sgd = opt.DistOpt(opt.SGD(lr=0.1, momentum=0.9), nccl_id=holder,
+                      local_rank=rank, world_size=world)
+    x, y = _data()
+    n = x.shape[0] // world
+    tx = tensor.Tensor(device=dev,
+                       data=x[rank * n:(rank + 1) * n].astype(np.float16))
+    ty = tensor.Tensor(device=dev, data=y[rank * n:(rank + 1) * n])
+    m = _make_model()
+    m.set_optimizer(sgd)
+    m.compile([tx], is_train=True, use_graph=False, sequential=True)
+    rs = np.random.RandomState(1)
+    for k, v in sorted(m.get_params().items()):
+        assert v.dtype == tensor.float16
+        v.copy_from_numpy((rs.randn(*v.shape) * 0.3).astype(np.float16))
+    m(tx, ty, "partialUpdate", None)
+    params = {k: tensor.to_numpy(v) for k, v in m.get_params().items()}
+    masters = [tensor.to_numpy(t) for t in sgd.opt.masters.values()]
+    return params, masters
+
+
+def test_partial_update_reaches_fp16_master_weights():
+    """The MLP's parameters form one partition, so the first iteration
+    averages all of them: they must agree across the ranks, and the float32
+    master copies the next step starts from must hold the averaged values."""
+    res = _spawn(_partial_fp16)
+    p0, m0 = res[0]
+    p1, _ = res[1]
+    assert len(m0) == len(p0) > 0
+    for k in p0:
+        np.testing.assert_array_equal(p0[k], p1[k])
+    have = sorted(v.astype(np.float32).reshape(-1).tolist() for v in p0.values())
+    want = sorted(v.reshape(-1).tolist() for v in m0)
+    assert have == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("option", ["plain", "partialUpdate", "sparseTopK"])
+def test_failed_capture_falls_back_without_extra_collectives(option):
+    """The first capture of the step (collectives inside) is made to fail:
+    the step is captured again around eagerly issued collectives, and the
+    loss trajectory stays the eager one (no collective ran twice, no
+    parameter was averaged twice, no residual was consumed)."""
+    import subprocess
+    out = subprocess.run(
+        [sys.executable, "-u",
+         os.path.join(ROOT, "tools", "check_rccl_captured.py"), option, "fp32",
+         "0", "failcapture"],
+        capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "RCCL-CAPTURED-OK" in out.stdout, (
+        out.stdout[-3000:] + out.stderr[-3000:])
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("option,dtype,verbosity", [
     ("plain", "fp32", 0), ("plain", "fp16", 0), ("half", "fp32", 0),

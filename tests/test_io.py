@@ -102,6 +102,80 @@ def test_tensor_proto_wire_format():
     assert back.data == st.data
 
 
+def _reference_tensor_proto():
+    """The TensorProto message of reference src/proto/core.proto:26-34, 70-79
+    (proto2) as a dynamic google.protobuf class: an encoder / decoder that
+    shares no code with the runtime's hand-written wire codec."""
+    from google.protobuf import descriptor_pb2, descriptor_pool
+    try:
+        from google.protobuf.message_factory import GetMessageClass
+    except ImportError:                     # older protobuf
+        from google.protobuf import message_factory
+        GetMessageClass = message_factory.MessageFactory().GetPrototype
+    F = descriptor_pb2.FieldDescriptorProto
+    fd = descriptor_pb2.FileDescriptorProto(
+        name="singa_core_test.proto", package="singa_test", syntax="proto2")
+    en = fd.enum_type.add(name="DataType")
+    for i, nm in enumerate(["kFloat32", "kFloat16", "kInt", "kChar", "kDouble",
+                            "kUChar", "kNumDataType"]):
+        en.value.add(name=nm, number=i)
+    msg = fd.message_type.add(name="TensorProto")
+    rep, opt = F.LABEL_REPEATED, F.LABEL_OPTIONAL
+    for name, num, label, typ, packed in [
+            ("shape", 1, rep, F.TYPE_UINT32, False),
+            ("data_type", 2, opt, F.TYPE_ENUM, False),
+            ("stride", 3, rep, F.TYPE_INT32, False),
+            ("float_data", 4, rep, F.TYPE_FLOAT, True),
+            ("double_data", 5, rep, F.TYPE_DOUBLE, True),
+            ("int_data", 6, rep, F.TYPE_INT32, True),
+            ("bytes_data", 7, rep, F.TYPE_BYTES, False)]:
+        f = msg.field.add(name=name, number=num, label=label, type=typ)
+        if typ == F.TYPE_ENUM:
+            f.type_name = ".singa_test.DataType"
+        if packed:
+            f.options.packed = True
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    return GetMessageClass(pool.FindMessageTypeByName("singa_test.TensorProto"))
+
+
+@pytest.mark.parametrize("dtype,np_dtype,field", [
+    (0, np.float32, "float_data"), (2, np.int32, "int_data"),
+    (4, np.float64, "double_data")])
+def test_tensor_proto_against_protobuf_library(dtype, np_dtype, field):
+    """Bytes written by the runtime parse with google.protobuf into the
+    reference's message (same shape / type / values, nothing unknown left
+    over), and bytes serialised by google.protobuf decode with the runtime."""
+    TensorProto = _reference_tensor_proto()
+    vals = (np.arange(24).reshape(2, 3, 4) * 3 - 7).astype(np_dtype)
+    st = _rt.SnapshotTensor()
+    st.shape = list(vals.shape)
+    st.dtype = dtype
+    st.data = vals.tobytes()
+    blob = _rt.EncodeTensorProto(st)
+    msg = TensorProto()
+    msg.ParseFromString(blob)
+    assert list(msg.shape) == [2, 3, 4]
+    assert msg.data_type == dtype
+    np.testing.assert_array_equal(
+        np.array(getattr(msg, field), np_dtype), vals.reshape(-1))
+    for other in ("float_data", "double_data", "int_data", "bytes_data"):
+        if other != field:
+            assert len(getattr(msg, other)) == 0
+    # nothing the message does not know: re-serialising gives the same bytes
+    assert msg.SerializeToString() == blob
+    # the other direction, with strides present as the reference writes them
+    ref = TensorProto()
+    ref.shape.extend([4, 6])
+    ref.data_type = dtype
+    ref.stride.extend([6, 1])
+    getattr(ref, field).extend(vals.reshape(-1).tolist())
+    back = _rt.DecodeTensorProto(ref.SerializeToString())
+    assert list(back.shape) == [4, 6] and back.dtype == dtype
+    np.testing.assert_array_equal(np.frombuffer(back.data, np_dtype),
+                                  vals.reshape(-1))
+
+
 def test_channel(tmp_path):
     _rt.InitChannel("")
     _rt.SetChannelDirectory(str(tmp_path))

@@ -5,11 +5,12 @@
     SINGA_DIST_FORCE=1 python tools/bench_allreduce.py      # one rank: the
                                                             # launch floor
 
-For every size three ways of summing a float32 buffer over the ranks are
-timed: ``torch.distributed.all_reduce`` (work object, process-group stream),
-the direct RCCL call on the caller's stream that the communicator uses, and
-reduce-scatter + all-gather on the same communicator; the direct call is also
-timed as a captured hipGraph replay (the way a training step issues it).
+For every size the ways of summing a float32 buffer over the ranks are timed:
+the RCCL call on the caller's stream that the communicator uses,
+reduce-scatter + all-gather on the same communicator, the RCCL call as a
+captured hipGraph replay (the way a training step issues it), and -- for
+reference -- the host-staged exchange over the gloo control group that serves
+when RCCL is switched off.
 Reported: microseconds per call, algorithm bandwidth (bytes / time) and bus
 bandwidth (algorithm bandwidth x 2 (N - 1) / N, the per-link load of a ring).
 xGMI gives every GPU 7 links of about 153 GB/s peer to peer."""
@@ -61,9 +62,13 @@ def main():
         buf = torch.ones(n, dtype=torch.float32, device=td)
         res = {"bytes": n * 4}
 
-        def torch_call():
-            dist.all_reduce(buf)
-        res["torch_us"] = timed(torch_call, args.iters, td) * 1e6
+        if rccl is None or lg <= 20:
+            def staged_call():
+                host = buf.cpu()
+                if dist.is_initialized():
+                    dist.all_reduce(host)
+                buf.copy_(host)
+            res["host_staged_us"] = timed(staged_call, 3, td) * 1e6
         if rccl is not None:
             res["direct_us"] = timed(lambda: rccl.all_reduce(buf),
                                      args.iters, td) * 1e6

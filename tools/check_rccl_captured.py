@@ -8,8 +8,14 @@ trajectory of a plain eager single-process run (a one-rank sum is the
 identity).  With a verbosity the per-node device time stamps are captured too
 and the communication profile is printed from the same production replay.
 
-    python tools/check_rccl_captured.py [option] [dtype] [verbosity]
-    option: plain | half | sparseTopK | sparseThreshold   dtype: fp32 | fp16
+    python tools/check_rccl_captured.py [option] [dtype] [verbosity] [failcapture]
+    option: plain | half | partialUpdate | sparseTopK | sparseThreshold
+    dtype: fp32 | fp16
+
+With ``failcapture`` the first capture of the step is made to fail: the device
+must fall back to hipGraph segments around eagerly issued collectives without
+running any collective twice (parameters averaged twice, residuals consumed),
+i.e. the loss trajectory must still be the eager one.
 """
 import os
 import sys
@@ -26,6 +32,7 @@ sys.path.insert(0, ROOT)
 OPTION = sys.argv[1] if len(sys.argv) > 1 else "plain"
 DTYPE = sys.argv[2] if len(sys.argv) > 2 else "fp32"
 VERBOSITY = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+FAIL_CAPTURE = len(sys.argv) > 4 and sys.argv[4] == "failcapture"
 
 
 def train(dist, graph, steps=7):
@@ -46,6 +53,9 @@ def train(dist, graph, steps=7):
     if dist:
         sgd = opt.DistOpt(sgd)
         sgd.threshold = 1 << 20          # several buckets
+    if dist and FAIL_CAPTURE:
+        from singa_amd.core import device as core_device
+        core_device._HipGraphReplay.fail_next = True
     np.random.seed(7)
     m = models.resnet.resnet18(num_classes=10)
     m.set_optimizer(sgd)
@@ -70,7 +80,10 @@ def main():
     from singa_amd import tensor
     got, info = train(True, True)
     print("captured", " ".join("%.5f" % v for v in got), info, flush=True)
-    assert info["segments"] == 1 and info["steps"] == 1, info
+    if FAIL_CAPTURE:
+        assert info["segments"] > 1 and info["steps"] > info["segments"], info
+    else:
+        assert info["segments"] == 1 and info["steps"] == 1, info
     ref, _ = train(False, False)
     print("eager   ", " ".join("%.5f" % v for v in ref), flush=True)
     if OPTION == "half" or DTYPE == "fp16":

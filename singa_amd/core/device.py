@@ -220,12 +220,18 @@ class HipGPU(Device):
         from .math_hip import HipMath
         self.math = HipMath(self)
         with torch.cuda.device(gpu_id):
-            # The collective's stream has high priority: its kernels are few
-            # and short, and the backward pass on the compute stream would
-            # otherwise keep every CU busy with queued convolution workgroups
-            # while a bucket waits to go out.
-            self.stream_comm = torch.cuda.Stream(device=gpu_id,
-                                                 priority=-1)     # "s"
+            # SINGA_COMM_STREAM_PRIORITY=-1 puts the collectives on a
+            # high-priority HIP stream, so that their few short kernels are
+            # scheduled ahead of the convolution workgroups queued by the
+            # backward pass.  Off by default: on ROCm 7.0 / MI355X the first
+            # cross-stream event wait between the compute stream and a
+            # high-priority stream never completed (host blocked in
+            # hipEventSynchronize, the step's kernels never ran), with and
+            # without an RCCL kernel on that stream.
+            self.stream_comm = torch.cuda.Stream(
+                device=gpu_id,
+                priority=int(os.environ.get("SINGA_COMM_STREAM_PRIORITY",
+                                            "0")))                # "s"
             self.stream_pack = torch.cuda.Stream(device=gpu_id)   # "c1"
             self.stream_unpack = torch.cuda.Stream(device=gpu_id)  # "c2"
             # philox state: [seed, offset]; the offset is advanced on the device

@@ -89,7 +89,7 @@ _TWO_PHASE = int(os.environ.get("SINGA_ALLREDUCE_TWO_PHASE", "0"))
 
 class _UniqueId(ctypes.Structure):
     """``ncclUniqueId``: 128 opaque bytes, passed to RCCL by value."""
-    _fields_ = [("internal", ctypes.c_char * 128)]
+    _fields_ = [("internal", ctypes.c_ubyte * 128)]
 
 
 class _Rccl(object):
@@ -135,9 +135,10 @@ class _Rccl(object):
         if rank == 0:
             self._check(lib.ncclGetUniqueId(ctypes.byref(uid)),
                         "ncclGetUniqueId")
-            blob[0] = bytes(bytearray(uid.internal))
+            blob[0] = ctypes.string_at(ctypes.byref(uid), 128)
         if world > 1:
             dist.broadcast_object_list(blob, src=0, group=ctl_group)
+        assert len(blob[0]) == 128
         ctypes.memmove(ctypes.byref(uid), blob[0], 128)
         torch.cuda.set_device(device)
         torch.cuda.current_stream(device).synchronize()   # HIP context exists
@@ -265,7 +266,7 @@ class Communicator(object):
                 (self.world_size > 1 or probe == "force"):
             self.capturable = self._probe_capture()
         self._dev = None          # device of the last synchronised tensors
-        self._blocks = []         # their blocks: what wait() orders against
+        self._blocks = []         # one tensor per block: what wait() orders against
         self._buffers = {}        # (slot, kind, dtype) -> persistent buffer
         self._slot = 0            # bucket index within the iteration
         self._warmed = False
@@ -352,10 +353,10 @@ class Communicator(object):
             if dev.lang() != 0:
                 dev.collectives_capturable = self.capturable
                 dev.communicator = self
-        seen = set(id(b) for b in self._blocks)
+        seen = set(id(t.block()) for t in self._blocks)
         for t in tensors:
             if id(t.block()) not in seen:
-                self._blocks.append(t.block())
+                self._blocks.append(t)
                 seen.add(id(t.block()))
 
     def _staged(self, t):
@@ -716,13 +717,13 @@ class Communicator(object):
         if self._dev is None:
             return
         dev = self._dev
-        blocks = self._blocks
+        tensors = self._blocks
         self._blocks = []
         self._slot = 0
         if not self._active:
             return          # a lone rank put nothing in flight
 
-        def join():
+        def join(*_):
             if self._skip_body(dev):
                 return
             st = self._streams(dev)
@@ -732,4 +733,9 @@ class Communicator(object):
             if _STRICT & 2:
                 torch.cuda.synchronize(dev.torch_device)
 
-        dev.Exec(join, blocks, blocks, "Dist_wait")
+        # submitted like every other operation: the recorded node keeps a
+        # tensor copy per use, so the scheduler's count of graph references
+        # matches the blocks' reference counts (a bare block list would make a
+        # tensor the user still holds, e.g. a residual accumulator, look like
+        # a graph-internal buffer that may be released after the wait)
+        tc._submit(dev, "Dist_wait", join, tensors, tensors)

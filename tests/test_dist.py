@@ -261,6 +261,18 @@ def test_distopt_sparse_full_density_matches(option, spars):
         np.testing.assert_allclose(res[0][k], ref[k], rtol=1e-4, atol=1e-5)
 
 
+def test_sparse_residuals_survive_graph_replay():
+    """Top-30 % exchange with error feedback: what is held back must be added
+    the next iteration, also when the step is a replayed graph (the residual
+    tensors are only touched by communication nodes; the scheduler must not
+    take them for graph-internal buffers and release them)."""
+    eager = _spawn(_dist_train, args=("sparseTopK", False, 0.3))
+    graph = _spawn(_dist_train, args=("sparseTopK", True, 0.3))
+    for k in eager[0]:
+        np.testing.assert_allclose(graph[0][k], eager[0][k], rtol=1e-5,
+                                   atol=1e-6)
+
+
 def test_distopt_partial_update_runs_and_syncs():
     res = _spawn(_dist_train, args=("partialUpdate", False, None))
     for k in res[0]:

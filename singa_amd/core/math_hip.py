@@ -115,6 +115,7 @@ class HipMath(object):
         self.k = dev.kernels
         HipMath._kernel_file = getattr(self.k, "__file__", "") or ""
         self.conv_prof = None
+        self._wgrad_scratch = {}   # elements -> zero-filled float buffer
         # zero-filled scratch of the one-launch column sums, per stream
         self._cols_scratch = {}
 
@@ -990,6 +991,15 @@ class HipMath(object):
         # the kernel reads dy / x in their own type and always writes floats
         acc = dw if dw.dtype == torch.float32 else torch.empty(
             dw.shape, dtype=torch.float32, device=dw.device)
+        if dw.shape[2] * dw.shape[3] > 1:
+            # zero-filled staging buffer shared by all layers of this size
+            # (the launches hand it back holding zeros)
+            n = acc.numel()
+            buf = self._wgrad_scratch.get(n)
+            if buf is None:
+                buf = torch.zeros(n, dtype=torch.float32, device=acc.device)
+                self._wgrad_scratch[n] = buf
+            g.set_scratch(buf.data_ptr(), n)
         args = (dy.data_ptr(), x.data_ptr(), acc.data_ptr())
         wrote = self._tuned(2, g, key,
                             lambda gg: self.k.conv_bwd_weight(code, gg, *args,

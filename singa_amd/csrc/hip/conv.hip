@@ -72,8 +72,18 @@ struct ConvArgs {
   int a_vec;       // A rows may be read four reduction indices at a time
   int ncls;        // backward-data: stride classes in this launch
   int tap_mask;    // filter has <= 63 taps: bounds tests use a per-pixel mask
+  // backward-weight: GEMM columns are ordered (tap, channel) instead of
+  // (channel, tap), and a tile's columns all belong to one tap: the bounds
+  // test of a gathered input element is then the same for every column of
+  // the thread and is made once per reduction tile
+  int tap_major;
+  // with tap_major and more than one tap: `out` is a scratch laid out
+  // [tap][K][Cg] (channels contiguous, so a wave's atomics cover whole
+  // 128-byte runs); untap_kernel moves it to dw[K][Cg][tap] afterwards
+  int tap_scratch;
+  int stagger;     // per-wave-slot issue priorities (see the kernel)
   int64_t a_elems, b_elems;  // elements of the two operand tensors
-  FastDiv div_rs, div_s, div_pq, div_q, div_hw, div_w;
+  FastDiv div_rs, div_s, div_pq, div_q, div_hw, div_w, div_cg;
   // Backward-data with stride (sh, sw) splits into sh * sw independent
   // stride-1 problems: input pixels with (h % sh, w % sw) = (ch, cw) receive
   // contributions only from the taps r = r0 + sh * rr, s = s0 + sw * ss, and
@@ -236,6 +246,18 @@ conv_igemm_kernel(ConvArgs a) {
   const ConvGeom &g = a.g;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 1, wn = wid & 1;
+  if (a.stagger) {
+    // Waves that share a SIMD come from different workgroups that started
+    // together and do identical work: left alone they stay in lockstep, all
+    // in their MFMA phase (sharing the matrix pipe) and then all in their
+    // load / store phase (pipe idle).  A distinct issue priority per wave
+    // slot lets one wave at a time run its MFMA phase at the full rate, which
+    // pulls the phases apart.
+    const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3;  // HW_ID.wave_id
+    if (slot == 1) __builtin_amdgcn_s_setprio(1);
+    else if (slot == 2) __builtin_amdgcn_s_setprio(2);
+    else if (slot == 3) __builtin_amdgcn_s_setprio(3);
+  }
   if constexpr (MODE == CONV_BWD_DATA) {
     if (g.side_zero) grid_zero_words(g.side_zero, g.side_zero_words);
   }
@@ -307,6 +329,8 @@ conv_igemm_kernel(ConvArgs a) {
   int bj_valid = 0, b_y = 0, b_x = 0, b_base = 0;
   // backward-weight: the thread owns B_PER (c, r, s) columns
   int bw_off[B_PER], bw_r[B_PER], bw_s[B_PER];
+  int tm_r = 0, tm_s = 0;   // tap-major order: the tile's tap, minus the padding
+  constexpr int SZ_ = (int)sizeof(T);
   if (MODE == CONV_FWD || MODE == CONV_BWD_DATA) {
     const int j = (V1 || V4) ? n0 + 4 * (tid % (BN / 4)) : n0 + tid % BN;
     bj_valid = j < Ngemm;
@@ -330,6 +354,22 @@ conv_igemm_kernel(ConvArgs a) {
       b_base = (((int)n - n_base) * g.K + grp * a.Kg) * a.PQ + b_y * g.Q + b_x;
     }
   } else {
+    if (a.tap_major) {
+      // every column of the tile is (tap, c0 + ...): one tap, whole channels
+      const uint32_t tap = a.div_cg.div(n0);
+      const int c0 = n0 - (int)tap * a.Cg;
+      uint32_t r, s;
+      a.div_s.divmod(tap, r, s);
+      tm_r = (int)r - g.pad_h;
+      tm_s = (int)s - g.pad_w;
+#pragma unroll
+      for (int i = 0; i < B_PER; ++i) {
+        const int c = c0 + tid / BK + (256 / BK) * i;
+        // byte offset of the channel plane; tiles never run past Cg here
+        bw_off[i] = (grp * a.Cg + c) * a.HW * SZ_;
+        bw_r[i] = bw_s[i] = 0;
+      }
+    } else {
 #pragma unroll
     for (int i = 0; i < B_PER; ++i) {
       const int j = n0 + tid / BK + (256 / BK) * i;
@@ -345,6 +385,7 @@ conv_igemm_kernel(ConvArgs a) {
         bw_off[i] = 0;
         bw_r[i] = bw_s[i] = -(1 << 29);
       }
+    }
     }
   }
 
@@ -578,6 +619,20 @@ conv_igemm_kernel(ConvArgs a) {
       a.div_q.divmod(pq, p, q);
       const int ih0 = kk < kend ? (int)p * g.stride_h : kFar;
       const int iw0 = q * g.stride_w;
+      if (a.tap_major) {
+        // one bounds test for all of the thread's columns; a rejected pixel
+        // starts from an offset beyond every resource and the (positive,
+        // < 2^31) channel offsets keep it there
+        const int ih = ih0 + tm_r, iw = iw0 + tm_s;
+        const bool ok = (unsigned)ih < (unsigned)g.H &&
+                        (unsigned)iw < (unsigned)g.W;
+        const unsigned pix = ok
+            ? (unsigned)((((int)n - nb) * g.C * g.H + ih) * g.W + iw) * SZ
+            : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i)
+          bo[i] = (int)(pix + (unsigned)bw_off[i]);
+      } else {
       const int base = ((int)n - nb) * g.C * a.HW + (int)p * g.stride_h * g.W +
                        iw0;
 #pragma unroll
@@ -586,6 +641,7 @@ conv_igemm_kernel(ConvArgs a) {
         const bool ok = (unsigned)ih < (unsigned)g.H &&
                         (unsigned)iw < (unsigned)g.W;
         bo[i] = ok ? (base + bw_off[i]) * SZ : kOob;
+      }
       }
     }
   };
@@ -695,24 +751,40 @@ conv_igemm_kernel(ConvArgs a) {
   for (int t = 0; t < nt; ++t) {
     const float *as = As[t & 1], *bs = Bs[t & 1];
     PROF_STAMP(pf_s0);
-    if (t + 1 < nt) load_tiles(kbeg + (t + 1) * BK);
+    const bool more = t + 1 < nt;
+    if (more) load_tiles(kbeg + (t + 1) * BK);
     PROF_STAMP(pf_s1);
     if constexpr (std::is_same<T, float>::value) {
+      // operands of k-step s+1 are fetched from LDS before the MFMAs of
+      // k-step s are issued: a wave alone on its SIMD keeps the matrix pipe
+      // busy instead of waiting for each pair of reads
+      float av[2][TM], bv[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        av[0][i] = as[lk * LDA + wm * WM + 32 * i + lrow];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        bv[0][j] = bs[lk * LDB + wn * WN + 32 * j + lrow];
 #pragma unroll
       for (int ks = 0; ks < BK; ks += 2) {
-        float av[TM], bv[TN];
+        const int cur = (ks >> 1) & 1, nxt = cur ^ 1;
+        if (ks + 2 < BK) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
-          av[i] = as[(ks + lk) * LDA + wm * WM + 32 * i + lrow];
+          for (int i = 0; i < TM; ++i)
+            av[nxt][i] = as[(ks + 2 + lk) * LDA + wm * WM + 32 * i + lrow];
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          bv[j] = bs[(ks + lk) * LDB + wn * WN + 32 * j + lrow];
+          for (int j = 0; j < TN; ++j)
+            bv[nxt][j] = bs[(ks + 2 + lk) * LDB + wn * WN + 32 * j + lrow];
+        }
+        // keep the issue order: next step's reads, then this step's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                av[i], bv[j], acc[i][j], 0, 0, 0);
+                av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       // 16-bit inputs: 32x32x16 MFMA, lane (row, half) holds reduction
@@ -736,7 +808,7 @@ conv_igemm_kernel(ConvArgs a) {
       }
     }
     PROF_STAMP(pf_s2);
-    if (t + 1 < nt) store_tiles((t + 1) & 1);
+    if (more) store_tiles((t + 1) & 1);
     PROF_STAMP(pf_s3);
     __syncthreads();
     PROF_STAMP(pf_s4);
@@ -769,6 +841,18 @@ conv_igemm_kernel(ConvArgs a) {
                 (bc.ch + g.stride_h * (int)hh) * g.W + bc.cw +
                 g.stride_w * (int)ww;
       chan_stride = a.HW;
+    } else if (a.tap_major) {
+      const uint32_t tap = a.div_cg.div(col);
+      const int c = col - (int)tap * a.Cg;
+      if (a.tap_scratch) {
+        // scratch[tap][k][c]
+        col_off = (size_t)tap * g.K * a.Cg + c;
+        chan_stride = a.Cg;
+      } else {
+        // column (tap, c) of row k is dw[k][c][tap]
+        col_off = (size_t)c * a.RS + tap;
+        chan_stride = a.Ngemm;
+      }
     } else {
       col_off = col;
       chan_stride = a.Ngemm;
@@ -881,6 +965,22 @@ __global__ void cast_out_kernel(const float *__restrict__ in,
     out[i] = from_f<T>(in[i] + (addend ? to_f<T>(addend[i]) : 0.f));
 }
 
+// dw[k][c][tap] = scratch[tap][k][c], and the scratch is left holding zeros
+// for the next weight-gradient launch that borrows it.  One thread per (k, c).
+__global__ void untap_kernel(float *__restrict__ scratch,
+                             float *__restrict__ dw, int64_t kc, int taps) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < kc;
+       i += step) {
+    float *dst = dw + i * taps;
+    for (int t = 0; t < taps; ++t) {
+      float *src = scratch + (int64_t)t * kc + i;
+      dst[t] = *src;
+      *src = 0.f;
+    }
+  }
+}
+
 // db[k] = sum_{n, pq} dy[n, k, pq]: one block per channel
 template <typename T>
 __global__ void conv_bias_grad_kernel(const T *__restrict__ dy,
@@ -911,6 +1011,10 @@ static ConvArgs make_args(const ConvGeom &g, int mode) {
   a.mt = a.nt = 1;
   a.ncls = 1;
   a.tap_mask = a.RS <= 63;
+  a.tap_major = 0;
+  a.tap_scratch = 0;
+  a.stagger = kStagger;
+  a.div_cg = FastDiv(a.Cg);
   if (mode == CONV_FWD) {
     a.M = a.Kg; a.Ngemm = g.N * a.PQ; a.Kgemm = a.Cg * a.RS;
     a.a_vec = a.Kgemm % 4 == 0;
@@ -940,6 +1044,9 @@ static int env_int(const char *name, int dflt) {
 // forces a tile size.
 static const int kSplitTarget = env_int("SA_CONV_SPLIT_TARGET", 1024);
 static const int kForceTile = env_int("SA_CONV_TILE", 0);
+static const int kStagger = env_int("SA_CONV_STAGGER", 1);
+// SA_CONV_TAP_MAJOR=0: weight-gradient columns stay in (channel, tap) order
+static const int kTapMajor = env_int("SA_CONV_TAP_MAJOR", 1);
 // SA_CONV_V4=0 keeps the one-pixel-per-load gather for every geometry
 static const int kUseV4 = env_int("SA_CONV_V4", 1);
 
@@ -1006,7 +1113,23 @@ void launch_conv(ConvArgs &a, int64_t out_elems, bool clear, hipStream_t s,
   void *const out = a.out;
   const void *const addend = a.addend;
   const bool staged = a.splits > 1 && !kFloatOut;
-  if (staged) {
+  // Backward-weight with (tap, channel) column order.  With several taps the
+  // result is accumulated in the caller's zero-filled scratch in
+  // [tap][K][Cg] order and moved into place afterwards; without a scratch
+  // the columns keep the (channel, tap) order.
+  bool untap = false;
+  if (MODE == CONV_BWD_WEIGHT && kTapMajor && a.Cg % tb == 0) {
+    if (a.RS == 1) {
+      a.tap_major = 1;
+    } else if (g.scratch != nullptr && g.scratch_elems >= out_elems) {
+      a.tap_major = a.tap_scratch = 1;
+      a.out = g.scratch;
+      untap = true;
+    }
+  }
+  if (untap) {
+    // the scratch holds zeros; dw is overwritten as a whole afterwards
+  } else if (staged) {
     a.out = g.scratch;
     zero_async(g.scratch, (size_t)out_elems * sizeof(float), s);
   } else if (a.splits > 1 && clear) {
@@ -1040,6 +1163,12 @@ void launch_conv(ConvArgs &a, int64_t out_elems, bool clear, hipStream_t s,
   } else {
     if (big) launch_tile<T, MODE, 128, 128, 16, false>(a, s);
     else launch_tile<T, MODE, 64, 64, 32, false>(a, s);
+  }
+  if (untap) {
+    const int64_t kc = out_elems / a.RS;
+    hipLaunchKernelGGL(untap_kernel, dim3(grid_for(kc, 256)), dim3(256), 0, s,
+                       g.scratch, (float *)out, kc, a.RS);
+    a.out = out;
   }
   if (staged) {
     hipLaunchKernelGGL((cast_out_kernel<T>), dim3(grid_for(out_elems, 256, 4)),

@@ -185,7 +185,10 @@ struct ConvGeom {
   int split_target = 0;
   // optional float buffer of at least scratch_elems elements: lets a 16-bit
   // forward / backward-data launch split its reduction (partial sums are
-  // combined in float there and rounded once into the output)
+  // combined in float there and rounded once into the output).
+  // Backward-weight: a buffer of the weight gradient's size that HOLDS ZEROS;
+  // filters of more than one tap are accumulated there tap by tap and moved
+  // into dw afterwards, and the buffer is handed back holding zeros.
   float *scratch = nullptr;
   int64_t scratch_elems = 0;
   // diagnostic builds only: eight 64-bit phase counters (see conv.hip)

@@ -96,6 +96,9 @@ def prof_shares(m, fn):
     e1.record()
     torch.cuda.synchronize()
     n = int(m.conv_prof[0].item())
+    if n == 0:
+        m.conv_prof = None
+        return "(kernel without phase counters)"
     rec = m.conv_prof[8:8 + 8 * n].reshape(n, 8).cpu().double()
     m.conv_prof = None
     c = rec[:, :7].sum(0).tolist()

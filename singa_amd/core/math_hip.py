@@ -71,6 +71,15 @@ def _is_linear(shp, st):
 
 
 _CONV_AUTOTUNE = os.environ.get("SINGA_CONV_AUTOTUNE", "1") != "0"
+# SINGA_DETERMINISTIC=1: bitwise reproducible training steps.  Reductions that
+# are split over workgroups (convolution passes, column sums, whole-tensor
+# sums, the soft-max loss) add their partial results in a fixed order instead
+# of with float atomics, and convolution launch plans come from the heuristic
+# instead of from timing.  Slower; not covered: depthwise filter gradients,
+# LayerNorm parameter gradients, embedding / scatter gradients and the
+# sparsified gradient exchange, which still accumulate with atomics.
+_DETERMINISTIC = os.environ.get("SINGA_DETERMINISTIC", "0") == "1"
+_DET_SCRATCH_ELEMS = int(os.environ.get("SINGA_DET_SCRATCH_MB", "512")) << 18
 
 
 def _world_size():
@@ -116,6 +125,8 @@ class HipMath(object):
         HipMath._kernel_file = getattr(self.k, "__file__", "") or ""
         self.conv_prof = None
         self._wgrad_scratch = {}   # elements -> zero-filled float buffer
+        self._det_scratch = None   # slabs of split reductions (deterministic mode)
+        self.k.set_deterministic(1 if _DETERMINISTIC else 0)
         # zero-filled scratch of the one-launch column sums, per stream
         self._cols_scratch = {}
 
@@ -595,6 +606,13 @@ class HipMath(object):
                             stride[0], stride[1], pad[0], pad[1], groups)
         if self.conv_prof is not None:   # diagnostic builds: phase counters
             g.set_prof(self.conv_prof.data_ptr())
+        if _DETERMINISTIC:
+            if self._det_scratch is None:
+                self._det_scratch = torch.empty(
+                    _DET_SCRATCH_ELEMS, dtype=torch.float32,
+                    device=self.dev.torch_device)
+            g.set_det_scratch(self._det_scratch.data_ptr(),
+                              self._det_scratch.numel())
         return g
 
     # Launch-plan autotuning (the role of cuDNN's algorithm search in the
@@ -695,7 +713,9 @@ class HipMath(object):
         measured = False
         plan = self._conv_plans.get(full)
         if plan is None:
-            if not _CONV_AUTOTUNE:
+            # measured plans differ from run to run with the timing noise,
+            # and with them the order in which partial sums are added
+            if not _CONV_AUTOTUNE or _DETERMINISTIC:
                 return False
             capturing = torch.cuda.is_current_stream_capturing()
             if _world_size() > 1 and _rank() != 0:

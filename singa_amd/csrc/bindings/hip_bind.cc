@@ -52,6 +52,9 @@ PYBIND11_MODULE(_hip, m) {
   m.attr("arch") = "gfx950";
 
   // ---- element-wise -------------------------------------------------------
+  m.def("set_deterministic", [](int on) { sa_set_deterministic(on); },
+        "split reductions combine their partial sums in a fixed order");
+  m.def("get_deterministic", []() { return sa_get_deterministic(); });
   m.def("unary_contig", [](int op, int dt_in, int dt_out, uintptr_t x,
                            uintptr_t y, int64_t n, float a, float b,
                            uintptr_t s) {
@@ -263,6 +266,10 @@ PYBIND11_MODULE(_hip, m) {
       .def("set_scratch", [](ConvGeom &g, uintptr_t p, int64_t elems) {
         g.scratch = reinterpret_cast<float *>(p);
         g.scratch_elems = elems;
+      })
+      .def("set_det_scratch", [](ConvGeom &g, uintptr_t p, int64_t elems) {
+        g.det_scratch = reinterpret_cast<float *>(p);
+        g.det_elems = elems;
       })
       .def("set_side_zero", [](ConvGeom &g, uintptr_t p, int64_t words) {
         g.side_zero = reinterpret_cast<uint32_t *>(p);

@@ -161,6 +161,12 @@ __global__ static void copy_words_kernel(uint32_t *__restrict__ d,
 }
 
 // p must be 4-byte aligned (every tensor here is)
+// Process-wide switch (sa_set_deterministic): reductions that are split over
+// workgroups combine their partial sums in a fixed order instead of with
+// float atomics, so that two runs on the same inputs agree bit for bit.
+int &deterministic_flag();
+inline bool deterministic() { return deterministic_flag() != 0; }
+
 inline void zero_async(void *p, size_t bytes, hipStream_t s) {
   if (bytes == 0) return;
   const int64_t words = (int64_t)(bytes >> 2);

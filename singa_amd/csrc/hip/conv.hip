@@ -82,6 +82,10 @@ struct ConvArgs {
   // 128-byte runs); untap_kernel moves it to dw[K][Cg][tap] afterwards
   int tap_scratch;
   int stagger;     // per-wave-slot issue priorities (see the kernel)
+  // deterministic mode: split s stores its partial tile to out + s * slab
+  // (plain stores, every element exactly once) instead of adding atomically
+  int slabs;
+  int64_t slab;
   int64_t a_elems, b_elems;  // elements of the two operand tensors
   FastDiv div_rs, div_s, div_pq, div_q, div_hw, div_w, div_cg;
   // Backward-data with stride (sh, sw) splits into sh * sw independent
@@ -872,6 +876,7 @@ conv_igemm_kernel(ConvArgs a) {
           const size_t off = col_off + (size_t)ch * chan_stride;
           // split reductions accumulate in a float buffer whatever T is
           if (a.splits == 1) ((T *)a.out)[off] = from_f<T>(v + bv);
+          else if (a.slabs) ((float *)a.out)[split * a.slab + off] = v + bv;
           else atomicAdd((float *)a.out + off, v + bv);
         } else if (MODE == CONV_BWD_DATA) {
           const int ch = grp * a.Cg + row;
@@ -880,6 +885,8 @@ conv_igemm_kernel(ConvArgs a) {
             const float add =
                 a.addend ? to_f<T>(((const T *)a.addend)[off]) : 0.f;
             ((T *)a.out)[off] = from_f<T>(v + add);
+          } else if (a.slabs) {
+            ((float *)a.out)[split * a.slab + off] = v;
           } else {
             atomicAdd((float *)a.out + off, v);
           }
@@ -887,6 +894,7 @@ conv_igemm_kernel(ConvArgs a) {
           float *dst = (float *)a.out +
                        (size_t)(grp * a.Kg + row) * chan_stride + col_off;
           if (a.splits == 1) *dst = v;
+          else if (a.slabs) dst[split * a.slab] = v;
           else atomicAdd(dst, v);
         }
       }
@@ -965,6 +973,20 @@ __global__ void cast_out_kernel(const float *__restrict__ in,
     out[i] = from_f<T>(in[i] + (addend ? to_f<T>(addend[i]) : 0.f));
 }
 
+// out[i] = addend[i] + slab 0 + slab 1 + ... in that order (deterministic mode)
+template <typename T>
+__global__ void slab_sum_kernel(const float *__restrict__ slabs, int splits,
+                                int64_t n, const T *__restrict__ addend,
+                                T *__restrict__ out) {
+  const int64_t step = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += step) {
+    float v = addend ? to_f<T>(addend[i]) : 0.f;
+    for (int s = 0; s < splits; ++s) v += slabs[(int64_t)s * n + i];
+    out[i] = from_f<T>(v);
+  }
+}
+
 // dw[k][c][tap] = scratch[tap][k][c], and the scratch is left holding zeros
 // for the next weight-gradient launch that borrows it.  One thread per (k, c).
 __global__ void untap_kernel(float *__restrict__ scratch,
@@ -1013,7 +1035,9 @@ static ConvArgs make_args(const ConvGeom &g, int mode) {
   a.tap_mask = a.RS <= 63;
   a.tap_major = 0;
   a.tap_scratch = 0;
-  a.stagger = kStagger;
+  a.stagger = 0;
+  a.slabs = 0;
+  a.slab = 0;
   a.div_cg = FastDiv(a.Cg);
   if (mode == CONV_FWD) {
     a.M = a.Kg; a.Ngemm = g.N * a.PQ; a.Kgemm = a.Cg * a.RS;
@@ -1109,16 +1133,41 @@ void launch_conv(ConvArgs &a, int64_t out_elems, bool clear, hipStream_t s,
       std::is_same<T, float>::value || MODE == CONV_BWD_WEIGHT;
   const bool via_scratch = !kFloatOut && clear && g.scratch != nullptr &&
                            g.scratch_elems >= out_elems;
-  if (may_split && (kFloatOut || via_scratch)) plan_splits(a, tiles, 256);
+  a.stagger = kStagger;
+  const bool det = deterministic();
+  if (det) {
+    // as many slabs as the buffer holds; none: no split
+    const int64_t room = g.det_scratch ? g.det_elems / out_elems : 0;
+    if (may_split && room >= 2) {
+      plan_splits(a, tiles, 256);
+      if (a.splits > room) {
+        int kps = (int)((a.Kgemm + room - 1) / room);
+        kps = (kps + 31) / 32 * 32;
+        a.k_per_split = kps;
+        a.splits = (a.Kgemm + kps - 1) / kps;
+      }
+    }
+  } else if (may_split && (kFloatOut || via_scratch)) {
+    plan_splits(a, tiles, 256);
+  }
   void *const out = a.out;
   const void *const addend = a.addend;
-  const bool staged = a.splits > 1 && !kFloatOut;
+  const bool slabbed = det && a.splits > 1;
+  const bool staged = !slabbed && a.splits > 1 && !kFloatOut;
   // Backward-weight with (tap, channel) column order.  With several taps the
   // result is accumulated in the caller's zero-filled scratch in
   // [tap][K][Cg] order and moved into place afterwards; without a scratch
   // the columns keep the (channel, tap) order.
   bool untap = false;
-  if (MODE == CONV_BWD_WEIGHT && kTapMajor && a.Cg % tb == 0) {
+  if (slabbed) {
+    // a class whose reduction is shorter than the others leaves slabs
+    // untouched: they must read as zero
+    a.slabs = 1;
+    a.slab = out_elems;
+    a.out = g.det_scratch;
+    a.addend = nullptr;
+    zero_async(g.det_scratch, (size_t)a.splits * out_elems * sizeof(float), s);
+  } else if (MODE == CONV_BWD_WEIGHT && kTapMajor && !det && a.Cg % tb == 0) {
     if (a.RS == 1) {
       a.tap_major = 1;
     } else if (g.scratch != nullptr && g.scratch_elems >= out_elems) {
@@ -1127,8 +1176,8 @@ void launch_conv(ConvArgs &a, int64_t out_elems, bool clear, hipStream_t s,
       untap = true;
     }
   }
-  if (untap) {
-    // the scratch holds zeros; dw is overwritten as a whole afterwards
+  if (untap || slabbed) {
+    // the scratch holds zeros; the output is overwritten as a whole afterwards
   } else if (staged) {
     a.out = g.scratch;
     zero_async(g.scratch, (size_t)out_elems * sizeof(float), s);
@@ -1163,6 +1212,14 @@ void launch_conv(ConvArgs &a, int64_t out_elems, bool clear, hipStream_t s,
   } else {
     if (big) launch_tile<T, MODE, 128, 128, 16, false>(a, s);
     else launch_tile<T, MODE, 64, 64, 32, false>(a, s);
+  }
+  if (slabbed) {
+    using O = typename std::conditional<MODE == CONV_BWD_WEIGHT, float, T>::type;
+    hipLaunchKernelGGL((slab_sum_kernel<O>), dim3(grid_for(out_elems, 256, 4)),
+                       dim3(256), 0, s, (const float *)g.det_scratch, a.splits,
+                       out_elems, (const O *)addend, (O *)out);
+    a.out = out;
+    a.addend = addend;
   }
   if (untap) {
     const int64_t kc = out_elems / a.RS;

@@ -207,7 +207,16 @@ struct ConvGeom {
   int64_t side_zero_words = 0;
   // backward-weight only: dw is known to hold zeros already
   bool out_zeroed = false;
+  // deterministic mode: float buffer of det_elems elements for the partial
+  // sums of a split reduction, one slab per split, summed in split order by
+  // a second kernel.  Without it (or when it is too small for two slabs) a
+  // deterministic launch does not split its reduction.
+  float *det_scratch = nullptr;
+  int64_t det_elems = 0;
 };
+// deterministic mode for every launcher of this library (see common.cuh)
+void sa_set_deterministic(int on);
+int sa_get_deterministic();
 // copies of the statistics rows (spreads same-address atomics; one per XCD)
 constexpr int kStatCopies = 8;
 int sa_conv_fwd(int dtype, const ConvGeom *g, const void *x, const void *w,

@@ -358,6 +358,15 @@ int launch_rows(const void *x, void *out, int64_t rows, int64_t cols,
 
 using namespace sa;
 
+namespace sa {
+int &deterministic_flag() {
+  static int flag = 0;
+  return flag;
+}
+}  // namespace sa
+void sa_set_deterministic(int on) { sa::deterministic_flag() = on; }
+int sa_get_deterministic() { return sa::deterministic_flag(); }
+
 int sa_reduce_rows(int op, int dtype, const void *x, void *out, int64_t rows,
                    int64_t cols, hipStream_t s) {
   if (rows <= 0) return 0;
@@ -386,6 +395,7 @@ int sa_reduce_cols(int dtype, const void *x, void *out, int64_t rows,
       const int64_t col_blocks = (cols + 16 * VEC - 1) / (16 * VEC);
       int64_t splits = i64min((rows + 127) / 128,
                               i64max(1, 2048 / col_blocks));
+      if (deterministic()) splits = 1;   // one slice: a fixed summation order
       const int64_t rpb = (rows + splits - 1) / splits;
       splits = (rows + rpb - 1) / rpb;
       if (splits > 1) zero_async(out, cols * sizeof(float), s);
@@ -396,7 +406,7 @@ int sa_reduce_cols(int dtype, const void *x, void *out, int64_t rows,
     } else {
       const int64_t col_blocks = (cols + 63) / 64;
       int64_t splits = 1;
-      if (rows > 256)
+      if (rows > 256 && !deterministic())
         splits = i64min((rows + 255) / 256, i64max(1, 1024 / col_blocks));
       const int64_t rpb = (rows + splits - 1) / splits;
       splits = (rows + rpb - 1) / rpb;
@@ -430,6 +440,7 @@ int sa_reduce_cols_fin(int dtype, const void *x, void *out, int out_typed,
       const int64_t col_blocks = (cols + 16 * VEC - 1) / (16 * VEC);
       int64_t splits = i64min((rows + 127) / 128,
                               i64max(1, 2048 / col_blocks));
+      if (deterministic()) splits = 1;   // one slice: a fixed summation order
       const int64_t rpb = (rows + splits - 1) / splits;
       splits = (rows + rpb - 1) / rpb;
       if (col_blocks > tickets_cap) rc = -3;
@@ -440,7 +451,7 @@ int sa_reduce_cols_fin(int dtype, const void *x, void *out, int out_typed,
     } else {
       const int64_t col_blocks = (cols + 63) / 64;
       int64_t splits = 1;
-      if (rows > 256)
+      if (rows > 256 && !deterministic())
         splits = i64min((rows + 255) / 256, i64max(1, 1024 / col_blocks));
       const int64_t rpb = (rows + splits - 1) / splits;
       splits = (rows + rpb - 1) / rpb;
@@ -464,7 +475,8 @@ int sa_reduce_all(int op, int dtype, const void *x, void *out, int64_t n,
   hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(1), 0, s, (float *)out,
                      init);
   if (n <= 0) return 0;
-  const int blocks = grid_for(n, 256, 8);
+  // one workgroup adds in a fixed order; several combine with atomics
+  const int blocks = deterministic() ? 1 : grid_for(n, 256, 8);
   switch (op) {
     case R_SUM:
       hipLaunchKernelGGL((reduce_all_kernel<float, R_SUM>), dim3(blocks),

@@ -288,8 +288,10 @@ int sa_softmax_ce_fused_fwd(int dtype, const void *x, const void *t,
   if (dtype != kF32) return -3;  // the loss word doubles as float accumulator
   zero_async(loss, sizeof(float), s);
   TARGET_SWITCH(TT, {
+    // deterministic mode: one wave adds the rows' losses in row order
     hipLaunchKernelGGL((softmax_ce_fused_fwd_kernel<float, TT>),
-                       dim3(wave_grid(rows)), dim3(256), 0, s,
+                       dim3(deterministic() ? 1 : wave_grid(rows)),
+                       dim3(deterministic() ? 64 : 256), 0, s,
                        (const float *)x, (const TT *)t, t_is_int, (float *)p,
                        (float *)loss, rows, cols);
   });

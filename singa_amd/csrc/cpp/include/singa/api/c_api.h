@@ -65,6 +65,17 @@ singa_tensor singa_sum(singa_tensor x, int axis);
 singa_tensor singa_softmax(singa_tensor x);
 int singa_axpy(float alpha, singa_tensor x, singa_tensor y);
 
+/* Configuration messages of the model API (the messages of the reference's
+   src/proto/model.proto): read `in` as protobuf wire format (format 0) or
+   text format (format 1) and write it back in the other or the same format.
+   message is one of LayerConf, ParamSpec, FillerConf, OptimizerConf,
+   RegularizerConf, ConstraintConf, MetricConf.  Returns the length of the
+   result, of which at most cap bytes are copied to out, or -1 (see
+   singa_last_error). */
+int64_t singa_conf_transcode(const char *message, int in_format,
+                             const char *in, int64_t in_len, int out_format,
+                             char *out, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

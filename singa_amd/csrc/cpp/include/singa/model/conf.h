@@ -72,7 +72,7 @@ struct RNNConf {
   float dropout = 0.f;
   bool remember_state = false;
   std::string input_mode = "linear", direction = "unidirectional",
-              rnn_mode = "lstm";  // relu, tanh, lstm, gru
+              rnn_mode = "relu";  // relu, tanh, lstm, gru
 };
 
 struct LayerConf {
@@ -102,7 +102,7 @@ struct OptimizerConf {
   std::string type = "sgd";
   float momentum = 0.f;
   float delta = 1e-8f;   // epsilon of AdaGrad / RMSProp
-  float rho = 0.9f;      // RMSProp decay
+  float rho = 0.95f;     // RMSProp decay
   bool has_regularizer = false, has_constraint = false;
   RegularizerConf regularizer;
   ConstraintConf constraint;

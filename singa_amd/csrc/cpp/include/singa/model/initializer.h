@@ -9,6 +9,7 @@
 #include "../core/tensor.h"
 #include "../utils/string.h"
 #include "conf.h"
+#include "conf_proto.h"
 
 namespace singa {
 
@@ -16,6 +17,12 @@ class Initializer {
  public:
   virtual ~Initializer() {}
   virtual void Setup(const FillerConf &conf) {}
+  /// From a serialized FillerConf message (reference initializer.h:30-36).
+  void Setup(const std::string &conf_str) {
+    FillerConf conf;
+    CHECK(ParseFromString(conf_str, &conf)) << "malformed FillerConf message";
+    this->Setup(conf);
+  }
   virtual void Fill(Tensor &t) = 0;
 };
 
@@ -26,6 +33,7 @@ class Constant : public Initializer {
   Constant() = default;
   explicit Constant(float x) : v_(x) {}
   void Setup(const FillerConf &conf) override { v_ = conf.value; }
+  using Initializer::Setup;
   void Fill(Tensor &t) override { t.SetValue(v_); }
 
  private:
@@ -37,6 +45,7 @@ class Uniform : public Initializer {
   Uniform() = default;
   Uniform(float low, float high) : min_(low), max_(high) {}
   void Setup(const FillerConf &conf) override { min_ = conf.min; max_ = conf.max; }
+  using Initializer::Setup;
   void Fill(Tensor &t) override { singa::Uniform(min_, max_, &t); }
 
  private:
@@ -48,6 +57,7 @@ class Gaussian : public Initializer {
   Gaussian() = default;
   Gaussian(float mean, float std) : mean_(mean), std_(std) {}
   void Setup(const FillerConf &conf) override { mean_ = conf.mean; std_ = conf.std; }
+  using Initializer::Setup;
   void Fill(Tensor &t) override { singa::Gaussian(mean_, std_, &t); }
 
  private:

@@ -18,6 +18,7 @@
 #include "../core/tensor.h"
 #include "../utils/factory.h"
 #include "conf.h"
+#include "conf_proto.h"
 
 namespace singa {
 
@@ -31,10 +32,38 @@ class Layer {
   virtual void Setup(const Shape &in_sample, const LayerConf &conf) {
     name_ = conf.name;
     param_specs_ = conf.param;
+    conf_ = conf;
   }
   virtual void Setup(const std::vector<Shape> &in_samples,
                      const LayerConf &conf) {
     Setup(in_samples.at(0), conf);
+  }
+  /// Configure from a serialized LayerConf message (protobuf wire format,
+  /// what a binding language's SerializeToString produces; reference
+  /// layer.h:40-54).  Subclasses that override Setup re-expose these with
+  /// `using Layer::Setup;` or are called through a Layer pointer.
+  void Setup(const Shape &in_sample, const std::string &proto_str) {
+    LayerConf conf;
+    CHECK(ParseFromString(proto_str, &conf)) << "malformed LayerConf message";
+    this->Setup(in_sample, conf);
+  }
+  void Setup(const std::vector<Shape> &in_samples,
+             const std::string &proto_str) {
+    LayerConf conf;
+    CHECK(ParseFromString(proto_str, &conf)) << "malformed LayerConf message";
+    this->Setup(in_samples, conf);
+  }
+  /// The configuration the layer was set up with, with the parameter specs
+  /// as they are now (reference layer.h:160-186).
+  virtual void ToProto(LayerConf *conf) const {
+    *conf = conf_;
+    conf->name = name_;
+    conf->param = param_specs_;
+  }
+  std::string ToProtoStr() const {
+    LayerConf conf;
+    ToProto(&conf);
+    return SerializeAsString(conf);
   }
   virtual const Shape GetOutputSampleShape() const {
     LOG(FATAL) << "GetOutputSampleShape not implemented for " << layer_type();
@@ -100,6 +129,7 @@ class Layer {
   void EnsureParamSpecs(const std::vector<std::string> &suffixes);
   std::string name_;
   std::vector<ParamSpec> param_specs_;
+  LayerConf conf_;
 };
 
 std::shared_ptr<Layer> CreateLayer(const std::string type);

@@ -10,6 +10,7 @@
 
 #include "../core/tensor.h"
 #include "conf.h"
+#include "conf_proto.h"
 
 namespace singa {
 
@@ -21,6 +22,12 @@ class Constraint {
   void Setup(const ConstraintConf &conf) {
     type_ = conf.type;
     threshold_ = conf.threshold;
+  }
+  /// From a serialized ConstraintConf message (reference optimizer.h:110-118).
+  void Setup(const std::string &conf_str) {
+    ConstraintConf conf;
+    CHECK(ParseFromString(conf_str, &conf)) << "malformed ConstraintConf";
+    Setup(conf);
   }
   /// Rescale `grad` so that its L2 norm does not exceed the threshold.
   void Apply(int step, Tensor &grad, Tensor &value);
@@ -39,6 +46,12 @@ class Regularizer {
     type_ = conf.type;
     coefficient_ = conf.coefficient;
   }
+  /// From a serialized RegularizerConf message (reference optimizer.h:146-154).
+  void Setup(const std::string &conf_str) {
+    RegularizerConf conf;
+    CHECK(ParseFromString(conf_str, &conf)) << "malformed RegularizerConf";
+    Setup(conf);
+  }
   /// grad += coefficient * value
   void Apply(int step, Tensor &grad, Tensor &value, float scale = 1.0f);
 
@@ -52,6 +65,13 @@ class Optimizer {
   Optimizer() = default;
   virtual ~Optimizer();
   virtual void Setup(const OptimizerConf &conf);
+  /// From a serialized OptimizerConf message, the form binding languages
+  /// pass (reference optimizer.h:44-52).
+  void Setup(const std::string &str) {
+    OptimizerConf conf;
+    CHECK(ParseFromString(str, &conf)) << "malformed OptimizerConf message";
+    this->Setup(conf);
+  }
   /// Record the multipliers / regularizer / constraint of one parameter.
   virtual void Register(const std::string &name, const ParamSpec &specs);
   virtual void ApplyRegularizerConstraint(int epoch, const std::string &name,
@@ -86,6 +106,7 @@ class SGD : public Optimizer {
  public:
   using Optimizer::Apply;
   void Setup(const OptimizerConf &conf) override;
+  using Optimizer::Setup;
   void Apply(int epoch, float lr, const std::string &name, Tensor &grad,
              Tensor &value, int step = -1) override;
   void SetMomentumGenerator(std::function<float(int)> func) {
@@ -101,6 +122,7 @@ class Nesterov : public Optimizer {
  public:
   using Optimizer::Apply;
   void Setup(const OptimizerConf &conf) override;
+  using Optimizer::Setup;
   void Apply(int epoch, float lr, const std::string &name, Tensor &grad,
              Tensor &value, int step = -1) override;
   void SetMomentumGenerator(std::function<float(int)> func) {
@@ -116,6 +138,7 @@ class AdaGrad : public Optimizer {
  public:
   using Optimizer::Apply;
   void Setup(const OptimizerConf &conf) override;
+  using Optimizer::Setup;
   void Apply(int epoch, float lr, const std::string &name, Tensor &grad,
              Tensor &value, int step = -1) override;
 
@@ -128,6 +151,7 @@ class RMSProp : public Optimizer {
  public:
   using Optimizer::Apply;
   void Setup(const OptimizerConf &conf) override;
+  using Optimizer::Setup;
   void Apply(int epoch, float lr, const std::string &name, Tensor &grad,
              Tensor &value, int step = -1) override;
 

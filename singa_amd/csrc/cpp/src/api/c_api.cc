@@ -51,6 +51,21 @@ singa_tensor wrap(Tensor &&t) { return new singa_tensor_s{std::move(t)}; }
 void need(const void *p, const char *what) {
   if (p == nullptr) throw std::invalid_argument(std::string("null ") + what);
 }
+
+template <typename Msg>
+std::string transcode(const std::string &in, int in_format, int out_format) {
+  Msg conf;
+  if (in_format == 0) {
+    if (!singa::ParseFromString(in, &conf))
+      throw std::invalid_argument("malformed wire-format message");
+  } else {
+    std::string err;
+    if (!singa::ParseFromText(in, &conf, &err))
+      throw std::invalid_argument(err);
+  }
+  return out_format == 0 ? singa::SerializeAsString(conf)
+                         : singa::DebugString(conf);
+}
 }  // namespace
 
 extern "C" {
@@ -308,6 +323,40 @@ int singa_axpy(float alpha, singa_tensor x, singa_tensor y) {
         return 0;
       },
       -1);
+}
+
+int64_t singa_conf_transcode(const char *message, int in_format,
+                             const char *in, int64_t in_len, int out_format,
+                             char *out, int64_t cap) {
+  return guarded(
+      [&]() -> int64_t {
+        need(message, "message name");
+        if (in_len < 0 || (in_len > 0 && in == nullptr) ||
+            (cap > 0 && out == nullptr) || (in_format | out_format) & ~1)
+          throw std::invalid_argument("bad argument");
+        const std::string name = message, src(in ? in : "", (size_t)in_len);
+        std::string res;
+        if (name == "LayerConf")
+          res = transcode<singa::LayerConf>(src, in_format, out_format);
+        else if (name == "ParamSpec")
+          res = transcode<singa::ParamSpec>(src, in_format, out_format);
+        else if (name == "FillerConf")
+          res = transcode<singa::FillerConf>(src, in_format, out_format);
+        else if (name == "OptimizerConf")
+          res = transcode<singa::OptimizerConf>(src, in_format, out_format);
+        else if (name == "RegularizerConf")
+          res = transcode<singa::RegularizerConf>(src, in_format, out_format);
+        else if (name == "ConstraintConf")
+          res = transcode<singa::ConstraintConf>(src, in_format, out_format);
+        else if (name == "MetricConf")
+          res = transcode<singa::MetricConf>(src, in_format, out_format);
+        else
+          throw std::invalid_argument("unknown message " + name);
+        const int64_t n = (int64_t)res.size();
+        if (cap > 0) memcpy(out, res.data(), (size_t)(n < cap ? n : cap));
+        return n;
+      },
+      (int64_t)-1);
 }
 
 }  // extern "C"

@@ -21,8 +21,8 @@ LIBUBSAN=$(g++ -print-file-name=libubsan.so)
 # the interpreter itself is not instrumented: the sanitizer runtimes are
 # loaded ahead of it
 LD_PRELOAD="$LIBASAN:$LIBUBSAN${LD_PRELOAD:+:$LD_PRELOAD}" \
-SINGA_RT_LIBRARY="$RT" SINGA_CPP_TEST_EXE="$OUT/bin/singa_cpp_test" \
+SINGA_RT_LIBRARY="$RT" SINGA_CPP_LIBRARY="$OUT/lib/libsinga_amd_cpp.so" SINGA_CPP_TEST_EXE="$OUT/bin/singa_cpp_test" \
 CUDA_VISIBLE_DEVICES="" \
   python -m pytest tests/test_io.py tests/test_scheduler.py tests/test_data.py \
-    tests/test_malformed_inputs.py -x -q -s -m "not gpu" -p no:cacheprovider
+    tests/test_malformed_inputs.py tests/test_conf_proto.py -x -q -s -m "not gpu" -p no:cacheprovider
 echo "sanitize: clean"

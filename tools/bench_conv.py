@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--prof", action="store_true",
                     help="print phase shares (diagnostic build only)")
+    ap.add_argument("--pair", action="store_true",
+                    help="data and weight gradient of a layer one after the "
+                         "other vs. on two streams at once")
     ap.add_argument("--layers", default="",
                     help="comma separated layer indices (default: all)")
     args = ap.parse_args()
@@ -161,6 +164,30 @@ def main():
                   ("%d,%d,%d,%d,%d,%d x%d" % (C, K, R, st, pd, H, cnt), t_f,
                    t_d), flush=True)
             continue
+        if args.pair:
+            if li == 0:
+                continue
+            side = torch.cuda.Stream()
+
+            def serial():
+                m.conv_bwd_data(dy, w, dx, (st, st), (pd, pd), 1)
+                m.conv_bwd_weight(dy, x, dw, (st, st), (pd, pd), 1)
+
+            def forked():
+                cur = torch.cuda.current_stream()
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    m.conv_bwd_weight(dy, x, dw, (st, st), (pd, pd), 1)
+                m.conv_bwd_data(dy, w, dx, (st, st), (pd, pd), 1)
+                cur.wait_stream(side)
+            t_s = timeit(serial, args.iters)
+            t_p = timeit(forked, args.iters)
+            print("%-34s serial %8.3f  two streams %8.3f  (%.2fx)" %
+                  ("%d,%d,%d,%d,%d,%d x%d" % (C, K, R, st, pd, H, cnt), t_s,
+                   t_p, t_s / t_p), flush=True)
+            tot["bwd_data"] += t_s * cnt
+            tot["bwd_weight"] += t_p * cnt
+            continue
         t_d = 0.0
         if li > 0:
             t_d = timeit(
@@ -195,6 +222,10 @@ def main():
         tot["bwd_data"] += t_d * cnt
         tot["bwd_weight"] += t_w * cnt
         flops_tot += fl * cnt
+    if args.pair:
+        print("total ms/step: serial %.2f  two streams %.2f" %
+              (tot["bwd_data"], tot["bwd_weight"]))
+        return
     print("total ms/step: fwd %.2f  bwd_data %.2f  bwd_weight %.2f  sum %.2f; "
           "fwd FLOPs %.1f G" % (tot["fwd"], tot["bwd_data"],
                                 tot["bwd_weight"], sum(tot.values()),

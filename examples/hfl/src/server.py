@@ -1,18 +1,28 @@
-"""Federated-averaging server: every round it gathers the clients' weights,
-averages them and scatters the result back (counterpart of the reference's
-examples/hfl/src/server.py:35-162)."""
-import argparse
+"""Federated-averaging server: accepts one connection per client, then every
+round gathers the clients' weights, averages them and scatters the result
+(counterpart of the reference's examples/hfl/src/server.py:35-162)."""
 import socket
 from collections import defaultdict
 
 import numpy as np
 
-from . import wire
+from .proto import interface as proto
+from .proto import utils
+from .proto.utils import parseargs
 
 
 class Server(object):
+    """
+    Attributes:
+        num_clients: connections to wait for.
+        conns / addrs: per global rank, filled by ``start``.
+        weights: name -> aggregated numpy array.
+        sample_counts: optional per-rank weights of the average (rows each
+            client trained on); equal weights when None.
+    """
 
-    def __init__(self, num_clients=1, host="127.0.0.1", port=1234):
+    def __init__(self, num_clients=1, host="127.0.0.1", port=1234,
+                 sample_counts=None):
         self.num_clients = num_clients
         self.host, self.port = host, int(port)
         self.sock = socket.socket()
@@ -20,20 +30,32 @@ class Server(object):
         self.conns = [None] * num_clients
         self.addrs = [None] * num_clients
         self.weights = {}
+        self.sample_counts = sample_counts
 
-    def start(self):
-        """Listen, then accept one connection per client; each client
-        announces its rank first."""
+    def __start_connection(self):
         self.sock.bind((self.host, self.port))
         self.sock.listen()
         print("Server started.", flush=True)
+
+    def __start_rank_pairing(self):
+        """Every client announces its global rank first."""
         for _ in range(self.num_clients):
             conn, addr = self.sock.accept()
-            rank = wire.receive_int(conn)
+            rank = utils.receive_int(conn)
+            if not 0 <= rank < self.num_clients or \
+                    self.conns[rank] is not None:
+                conn.close()
+                raise ValueError("client announced rank %d (expected one "
+                                 "unused rank below %d)"
+                                 % (rank, self.num_clients))
             self.conns[rank], self.addrs[rank] = conn, addr
             print("[Server] Connected by %s [global_rank %d]" % (addr, rank),
                   flush=True)
         assert None not in self.conns
+
+    def start(self):
+        self.__start_connection()
+        self.__start_rank_pairing()
 
     def close(self):
         for c in self.conns:
@@ -42,38 +64,43 @@ class Server(object):
         self.sock.close()
 
     def aggregate(self, weights):
-        """weights: name -> list of per-client arrays; FedAvg."""
+        """weights: name -> list of per-client arrays (rank order).  FedAvg:
+        the mean, weighted by ``sample_counts`` when given; integer tensors
+        (step counters) keep their dtype."""
+        w = None
+        if self.sample_counts is not None:
+            w = np.asarray(self.sample_counts, np.float64)
+            w = w / w.sum()
         for k, v in weights.items():
-            self.weights[k] = np.mean(np.stack(v), axis=0).astype(v[0].dtype)
+            stack = np.stack([np.asarray(a, np.float64) for a in v])
+            mean = stack.mean(axis=0) if w is None else \
+                np.tensordot(w, stack, axes=1)
+            self.weights[k] = mean.astype(v[0].dtype)
         return self.weights
 
     def pull(self):
-        """Gather: receive every client's weights, then aggregate."""
+        """Gather every client's weights, then aggregate."""
         collected = defaultdict(list)
         for conn in self.conns:
-            op, w = wire.receive_weights(conn)
-            assert op == wire.GATHER
-            for k, v in w.items():
-                collected[k].append(v)
+            message = utils.receive_message(conn, proto.WeightsExchange())
+            if message.op_type != proto.GATHER:
+                raise ValueError("expected a GATHER message, got op %d"
+                                 % message.op_type)
+            for k, blob in message.weights.items():
+                collected[k].append(utils.deserialize_array(blob))
+        short = [k for k, v in collected.items() if len(v) != self.num_clients]
+        if short:
+            raise ValueError("not every client sent %s" % sorted(short))
         self.aggregate(collected)
 
     def push(self):
         """Scatter the aggregated weights to every client."""
+        message = proto.WeightsExchange()
+        message.op_type = proto.SCATTER
+        for k, v in self.weights.items():
+            message.weights[k] = utils.serialize_array(v)
         for conn in self.conns:
-            wire.send_weights(conn, wire.SCATTER, self.weights)
-
-
-def parseargs(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--num_clients", type=int, default=2)
-    ap.add_argument("--host", default="127.0.0.1")
-    ap.add_argument("--port", type=int, default=1234)
-    ap.add_argument("-m", "--max-epoch", type=int, default=3,
-                    dest="max_epoch")
-    ap.add_argument("-i", "--rank", type=int, default=0)
-    ap.add_argument("-b", "--batch-size", type=int, default=64)
-    ap.add_argument("-l", "--lr", type=float, default=0.05)
-    return ap.parse_args(argv)
+            utils.send_message(conn, message)
 
 
 def main(argv=None):

@@ -63,27 +63,126 @@ def test_onnx_tiny_gpt_import():
     assert tm.self_test(device.get_default_device()) < 1e-3
 
 
-def test_hfl_wire_and_fedavg():
+def _hfl():
     sys.path.insert(0, os.path.join(ROOT, "hfl"))
     try:
-        from src import wire
-        from src.server import Server
+        for k in [k for k in sys.modules if k == "src" or
+                  k.startswith("src.")]:
+            sys.modules.pop(k)
+        from src import bank, client, server
+        from src.proto import interface, utils
     finally:
         sys.path.pop(0)
+    return bank, client, server, interface, utils
+
+
+def test_hfl_wire_and_fedavg():
+    bank, client, server, proto, utils = _hfl()
     a, b = socket.socketpair()
     w = {"w": np.arange(6, dtype=np.float32).reshape(2, 3),
-         "step": np.array([3], np.int32)}
-    t = threading.Thread(target=wire.send_weights, args=(a, wire.GATHER, w))
+         "step": np.array([3], np.int32),
+         "h": np.array([0.5, -2.0], np.float16)}
+    msg = proto.WeightsExchange()
+    msg.op_type = proto.GATHER
+    for k, v in w.items():
+        msg.weights[k] = utils.serialize_array(v)
+    t = threading.Thread(target=utils.send_message, args=(a, msg))
     t.start()
-    op, got = wire.receive_weights(b)
+    got = utils.receive_message(b, proto.WeightsExchange())
     t.join()
-    assert op == wire.GATHER
-    np.testing.assert_array_equal(got["w"], w["w"])
-    assert got["step"].dtype == np.int32
-    s = Server(num_clients=2)
-    out = s.aggregate({"w": [w["w"], 3 * w["w"]]})
+    assert got.op_type == proto.GATHER and set(got.weights) == set(w)
+    for k, v in w.items():
+        back = utils.deserialize_array(got.weights[k])
+        assert back.dtype == v.dtype
+        np.testing.assert_array_equal(back, v)
+    # the envelope is the reference's: field 1 varint op, field 2 map entries
+    wire = msg.SerializeToString()
+    assert wire[:2] == b"\x08\x02" and wire[2:3] == b"\x12"
+    # an object array is refused on both sides
+    with pytest.raises(ValueError):
+        utils.serialize_array(np.array([{"a": 1}], dtype=object))
+    import io
+    import pickle
+    evil = io.BytesIO()
+    np.lib.format.write_array(evil, np.array([{"a": 1}], dtype=object),
+                              allow_pickle=True)
+    with pytest.raises(ValueError):
+        utils.deserialize_array(evil.getvalue())
+    with pytest.raises(Exception):
+        utils.deserialize_array(pickle.dumps(np.zeros(3), protocol=0))
+    # a length prefix beyond the limit is refused before allocating
+    t = threading.Thread(target=utils.send_int, args=(a, 1 << 40))
+    t.start()
+    with pytest.raises(ValueError):
+        utils.receive_message(b, proto.WeightsExchange())
+    t.join()
+    s = server.Server(num_clients=2)
+    out = s.aggregate({"w": [w["w"], 3 * w["w"]],
+                       "step": [np.array([3], np.int32)] * 2})
     np.testing.assert_allclose(out["w"], 2 * w["w"])
+    assert out["step"].dtype == np.int32 and out["step"][0] == 3
+    s.sample_counts = [1, 3]
+    np.testing.assert_allclose(
+        s.aggregate({"w": [w["w"], 3 * w["w"]]})["w"], 2.5 * w["w"])
     s.sock.close()
+
+
+def test_hfl_bank_pipeline(tmp_path):
+    bank = _hfl()[0]
+    src = bank.synthesize(str(tmp_path / bank.SOURCE), rows=600)
+    import pandas as pd
+    raw = pd.read_csv(src, sep=";")
+    assert list(raw.columns) == bank.COLUMNS and set(raw["y"]) == {"yes", "no"}
+    enc = bank.encode(raw.drop(columns=["y"]))
+    # ten numeric columns + one column per category value that occurs
+    assert enc.shape[1] == 10 + sum(raw[c].nunique() for c in bank.CATEGORICAL)
+    per_train, per_test = bank.split(3, src, str(tmp_path))
+    assert (per_train, per_test) == (160, 40)
+    tx, ty, vx, vy, classes = bank.load(1, str(tmp_path))
+    assert classes == 2 and tx.shape == (160, enc.shape[1]) and \
+        vx.shape == (40, enc.shape[1])
+    assert tx.dtype == np.float32 and ty.dtype == np.int32
+    assert tx.min() == 0.0 and tx.max() == 1.0 and set(ty) <= {0, 1}
+    # label-skewed shards: the first client sees (almost) only "no"
+    bank.split(3, src, str(tmp_path), non_iid=True)
+    y0 = bank.load(0, str(tmp_path))[1]
+    y2 = bank.load(2, str(tmp_path))[1]
+    assert y0.mean() < 0.05 < y2.mean()
+
+
+def test_hfl_round_trip_one_client(tmp_path):
+    bank, client, server, proto, utils = _hfl()
+    from singa_amd import device, opt
+    src = bank.synthesize(str(tmp_path / bank.SOURCE), rows=1500)
+    bank.split(1, src, str(tmp_path))
+    probe = socket.socket()
+    probe.bind(("127.0.0.1", 0))
+    port = probe.getsockname()[1]
+    probe.close()
+    srv = server.Server(1, "127.0.0.1", port)
+    rounds = 3
+
+    def serve():
+        srv.start()
+        for i in range(rounds):
+            if i > 0:
+                srv.push()
+            srv.pull()
+        srv.close()
+    t = threading.Thread(target=serve)
+    t.start()
+    lines = []
+    hist = client.run(0, 1, 0, rounds, 32, "mlp", "bank", "iid",
+                      opt.SGD(lr=0.05, momentum=0.9), False, 0,
+                      port=port, data_dir=str(tmp_path),
+                      dev=device.get_default_device(), log=lines.append)
+    t.join(timeout=60)
+    assert not t.is_alive()
+    assert len(hist) == rounds and hist[-1] > 0.6
+    assert any("Training loss" in ln for ln in lines)
+    # with one client the average is that client's weights
+    assert set(srv.weights) and all(np.isfinite(v).all()
+                                    for v in srv.weights.values())
 
 
 def test_gan_step():

@@ -29,11 +29,16 @@ def main(argv=None):
                         action="store_false", dest="graph")
     parser.add_argument("-m", "--max-epoch", default=1001, type=int,
                         dest="max_epoch")
+    parser.add_argument("--seed", default=None, type=int,
+                        help="seed of the device's generator (the initial "
+                             "weights); unset: whatever state it is in")
     args = parser.parse_args(argv)
 
     data, label = _toy.make()
     dev = device.create_cuda_gpu() if device.get_num_gpus() \
         else device.get_default_device()
+    if args.seed is not None:
+        dev.SetRandSeed(args.seed)
     sgd = opt.SGD(0.1, 0.9, 1e-5, dtype=singa_dtype[args.precision])
     tx = tensor.Tensor((400, 2), dev, singa_dtype[args.precision])
     ty = tensor.Tensor((400,), dev, tensor.int32)

@@ -97,6 +97,7 @@ class Device(object):
     def RunGraph(self, serial=False):
         prev = self._graph_enabled
         self._graph_enabled = False
+        self._step_begins()
         try:
             if serial:
                 self._graph.RunInSerial()
@@ -104,6 +105,19 @@ class Device(object):
                 self._graph.RunGraph()
         finally:
             self._graph_enabled = prev
+        self._step_done()
+
+    def _step_begins(self):
+        comm = getattr(self, "communicator", None)
+        if comm is not None:
+            comm.on_step_begin()
+
+    def _step_done(self):
+        """One iteration of the recorded graph has been issued: the step
+        boundary of the communicator's failure detection."""
+        comm = getattr(self, "communicator", None)
+        if comm is not None:
+            comm.on_step()
 
     def Reset(self):
         self.EnableGraph(False)
@@ -339,34 +353,39 @@ class HipGPU(Device):
             return super().RunGraph(serial)
         prev = self._graph_enabled
         self._graph_enabled = False
+        self._step_begins()
         try:
-            with torch.cuda.device(self.torch_device):
-                if self._replay is not None and (
-                        self._replay.serial != serial or
-                        self._replay.verbosity != self._verbosity):
-                    self._replay = None
-                if self._replay is None:
-                    if self._eager_done < self.warmup_iters:
-                        # first iteration runs op by op: lazy handles, lazy
-                        # parameter moves and allocator warm-up happen here
-                        self._eager_done += 1
-                        g.set_verbosity(0)
-                        try:
-                            if serial:
-                                g.RunInSerial()
-                            else:
-                                g.RunGraph()
-                        finally:
-                            g.set_verbosity(self._verbosity)
-                        return
-                    self._replay = self._capture(serial)
-                if self._stamps is not None:
-                    self._stamps.before_replay(g.iteration(),
-                                               self._skip_iteration)
-                self._replay.run()
-                g.FinishIteration()
+            self._run_recorded(g, serial)
         finally:
             self._graph_enabled = prev
+        self._step_done()
+
+    def _run_recorded(self, g, serial):
+        with torch.cuda.device(self.torch_device):
+            if self._replay is not None and (
+                    self._replay.serial != serial or
+                    self._replay.verbosity != self._verbosity):
+                self._replay = None
+            if self._replay is None:
+                if self._eager_done < self.warmup_iters:
+                    # first iteration runs op by op: lazy handles, lazy
+                    # parameter moves and allocator warm-up happen here
+                    self._eager_done += 1
+                    g.set_verbosity(0)
+                    try:
+                        if serial:
+                            g.RunInSerial()
+                        else:
+                            g.RunGraph()
+                    finally:
+                        g.set_verbosity(self._verbosity)
+                    return
+                self._replay = self._capture(serial)
+            if self._stamps is not None:
+                self._stamps.before_replay(g.iteration(),
+                                           self._skip_iteration)
+            self._replay.run()
+            g.FinishIteration()
 
     def _capture(self, serial):
         """Capture the recorded step.  With collectives inside the capture

@@ -33,6 +33,7 @@ fewer, larger buckets amortise the ring's latency better than many small ones.
 """
 import atexit
 import ctypes
+import datetime
 import math
 import os
 import socket
@@ -42,6 +43,7 @@ import torch.distributed as dist
 
 from ..core import dtypes
 from ..core import tensor_core as tc
+from . import health
 
 
 def _free_port():
@@ -128,6 +130,8 @@ class _Rccl(object):
         lib.ncclReduceScatter.restype = ci
         lib.ncclGetErrorString.argtypes = [ci]
         lib.ncclGetErrorString.restype = ctypes.c_char_p
+        lib.ncclCommGetAsyncError.argtypes = [vp, ctypes.POINTER(ci)]
+        lib.ncclCommGetAsyncError.restype = ci
         self.comm = None
         self.rank, self.world = rank, world
         uid = _UniqueId()
@@ -158,6 +162,21 @@ class _Rccl(object):
         if rc != 0:
             raise RuntimeError("%s failed: %s" % (
                 what, self.lib.ncclGetErrorString(rc).decode()))
+
+    def check_async_error(self):
+        """Raise when a collective already enqueued on this communicator has
+        failed inside RCCL (a peer went away, a link error): such errors are
+        not reported by the call that enqueued the kernel."""
+        if not self.comm:
+            return
+        state = ctypes.c_int(0)
+        self._check(self.lib.ncclCommGetAsyncError(self.comm,
+                                                   ctypes.byref(state)),
+                    "ncclCommGetAsyncError")
+        if state.value != 0:
+            raise RuntimeError("an RCCL collective failed asynchronously: %s"
+                               % self.lib.ncclGetErrorString(
+                                   state.value).decode())
 
     def all_reduce(self, flat):
         stream = torch.cuda.current_stream(flat.device).cuda_stream
@@ -216,14 +235,15 @@ class Communicator(object):
             self.local_rank = _env_int(
                 ["LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK",
                  "MPI_LOCALRANKID", "SLURM_LOCALID"], self.global_rank)
-            init_method = "tcp://%s:%s" % (
-                os.environ.get("MASTER_ADDR", "127.0.0.1"),
-                os.environ.get("MASTER_PORT", "29500"))
+            meet = (os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                    int(os.environ.get("MASTER_PORT", "29500")))
+            init_method = "tcp://%s:%d" % meet
         elif len(args) == 4:
             self.local_rank, self.world_size, holder, self.max_size = (
                 int(args[0]), int(args[1]), args[2], int(args[3]))
             self.global_rank = self.local_rank
             init_method = holder.init_method
+            meet = (holder.addr, holder.port)
         else:
             raise TypeError("Communicator(buffSize) or Communicator("
                             "local_rank, world_size, nccl_id, buffSize)")
@@ -241,9 +261,14 @@ class Communicator(object):
                     self.local_rank % torch.cuda.device_count())
             # the host control group; device collectives never go through it
             # unless RCCL is unavailable or switched off
+            # SINGA_COLLECTIVE_TIMEOUT (seconds): how long a host collective
+            # waits for a peer before it raises (gloo's default is 30 min)
+            limit = float(os.environ.get("SINGA_COLLECTIVE_TIMEOUT", "0") or 0)
+            extra = {"timeout": datetime.timedelta(seconds=limit)} \
+                if limit > 0 else {}
             dist.init_process_group(
                 backend="gloo", init_method=init_method,
-                rank=self.global_rank, world_size=self.world_size)
+                rank=self.global_rank, world_size=self.world_size, **extra)
             self._owns_group = True
             atexit.register(self.close)
         # without a process group a lone rank's all-reduce is the identity
@@ -265,6 +290,12 @@ class Communicator(object):
         if self.capturable and probe != "0" and \
                 (self.world_size > 1 or probe == "force"):
             self.capturable = self._probe_capture()
+        # failure detection (off unless the environment asks, see health.py)
+        self.steps = 0
+        self._fault = health.FaultPlan.from_env()
+        self._heartbeat = health.heartbeat_from_env(
+            self.global_rank, self.world_size, meet[0], meet[1]) \
+            if self._active else None
         self._dev = None          # device of the last synchronised tensors
         self._blocks = []         # one tensor per block: what wait() orders against
         self._buffers = {}        # (slot, kind, dtype) -> persistent buffer
@@ -311,10 +342,34 @@ class Communicator(object):
         dist.broadcast_object_list(box, src=src)
         return box[0]
 
+    def on_step_begin(self):
+        """A training step starts (the device is about to issue a recorded
+        iteration, or an eager iteration reached its first collective)."""
+        if self._heartbeat is not None:
+            self._heartbeat.begin()
+
+    def on_step(self):
+        """A training step is complete (called by the device after every
+        replayed or eagerly executed iteration): publish the progress, raise
+        ``health.RankFailure`` when another rank has been found lost or hung,
+        surface asynchronous RCCL errors, and fire an injected fault whose
+        step has come."""
+        self.steps += 1
+        if self._heartbeat is not None:
+            self._heartbeat.step()
+            self._heartbeat.check()
+        if self._rccl is not None:
+            self._rccl.check_async_error()
+        if self._fault is not None:
+            self._fault.tick(self.global_rank, self.steps)
+
     def close(self):
         """Leave the groups this communicator created (also run at
         interpreter exit: a process that ends with the group's worker threads
         alive aborts in their destructors)."""
+        hb, self._heartbeat = getattr(self, "_heartbeat", None), None
+        if hb is not None:
+            hb.close()
         try:
             if self._gpu and (self._rccl is not None or self._owns_group):
                 torch.cuda.synchronize()
@@ -350,9 +405,11 @@ class Communicator(object):
     def _remember(self, dev, tensors):
         if self._dev is not dev:
             self._dev = dev
+            dev.communicator = self
+        if not self._blocks:
+            self.on_step_begin()    # first collective since the last wait()
             if dev.lang() != 0:
                 dev.collectives_capturable = self.capturable
-                dev.communicator = self
         seen = set(id(t.block()) for t in self._blocks)
         for t in tensors:
             if id(t.block()) not in seen:
@@ -722,6 +779,8 @@ class Communicator(object):
         self._slot = 0
         if not self._active:
             return          # a lone rank put nothing in flight
+        if not dev.graph_enabled():
+            self.on_step()  # eager mode: wait() ends the iteration
 
         def join(*_):
             if self._skip_body(dev):

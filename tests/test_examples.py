@@ -29,7 +29,9 @@ def test_mlp_native_and_model():
     native = _import("mlp", "native")
     assert native.main(["-m", "201"]) < 0.5
     model = _import("mlp", "model")
-    assert model.main(["-m", "201"]) < 0.3
+    # three hidden units: an unlucky draw of the initial weights leaves too few
+    # of them alive, so the draw is fixed
+    assert model.main(["-m", "201", "--seed", "1"]) < 0.3
 
 
 def test_train_cnn_helpers_and_epoch(capsys):

@@ -1,0 +1,115 @@
+"""Failure detection of multi-process training (singa_amd/parallel/health.py):
+two host ranks over gloo, one of them made to die or hang by fault injection;
+the survivor must end by itself, quickly, and say which rank it lost."""
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, "tests", "_fault_worker.py")
+
+
+def _run(env_extra, steps=8, graph=0, limit=90, grace=20):
+    sys.path.insert(0, ROOT)
+    from singa_amd.parallel.communicator import _free_port
+    port = _free_port()
+    env = dict(os.environ, SINGA_HEARTBEAT_PORT=str(_free_port()),
+               **env_extra)
+    procs = [subprocess.Popen(
+        [sys.executable, WORKER, str(r), "2", str(port), str(steps),
+         str(graph)], env=env, stdout=subprocess.PIPE,
+        stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    t0 = time.time()
+    out = {}
+    try:
+        out[0] = procs[0].communicate(timeout=limit)[0]
+        took = time.time() - t0
+        try:                    # a healthy peer ends moments later
+            out[1] = procs[1].communicate(timeout=grace)[0]
+        except subprocess.TimeoutExpired:
+            pass
+    finally:
+        for p in procs:         # exactly the processes started here
+            if p.poll() is None:
+                p.kill()
+        if 1 not in out:
+            out[1] = procs[1].communicate()[0]
+    return procs[0].returncode, procs[1].returncode, out, took
+
+
+def test_fault_plan_parsing():
+    sys.path.insert(0, ROOT)
+    from singa_amd.parallel import health
+    assert health.FaultPlan.from_env("") is None
+    p = health.FaultPlan.from_env("rank=1,step=3,kind=hang")
+    assert (p.rank, p.at, p.kind) == (1, 3, "hang")
+    assert health.FaultPlan.from_env("rank=0,step=2").kind == "exit"
+    for bad in ("rank=1", "rank=1,step=2,kind=melt", "rank=1,step=2,x=1"):
+        with pytest.raises(ValueError):
+            health.FaultPlan.from_env(bad)
+    p = health.FaultPlan(0, 2, "raise")
+    p.tick(1, 5)            # another rank
+    p.tick(0, 1)            # too early
+    with pytest.raises(RuntimeError):
+        p.tick(0, 2)
+    p.tick(0, 3)            # fires once
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_healthy_job_is_left_alone(graph):
+    rc0, rc1, out, _ = _run({"SINGA_HEARTBEAT": "0.2",
+                             "SINGA_PROGRESS_TIMEOUT": "20"}, steps=6,
+                            graph=graph)
+    assert (rc0, rc1) == (0, 0), out
+    # the step counter advances once per iteration, eager or replayed
+    assert "step 5 done (communicator counts 6)" in out[0], out[0]
+
+
+def test_dead_rank_ends_the_job_with_a_diagnosis():
+    rc0, rc1, out, took = _run({
+        "SINGA_HEARTBEAT": "0.2", "SINGA_HEARTBEAT_TIMEOUT": "2",
+        "SINGA_FAULT_INJECT": "rank=1,step=3,kind=kill"}, steps=50)
+    assert rc1 == -9, out[1]
+    # rank 0 does not sit in its collective: gloo reports the closed
+    # connection, or the heartbeat monitor ends the process
+    assert rc0 != 0 and took < 60, (rc0, took, out[0])
+    assert "step 2 done" in out[0]
+    if rc0 == 75:
+        assert "rank 1 sent no heartbeat" in out[0], out[0]
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_hung_rank_is_found_by_its_missing_progress(graph):
+    rc0, rc1, out, took = _run({
+        "SINGA_HEARTBEAT": "0.2", "SINGA_PROGRESS_TIMEOUT": "3",
+        "SINGA_FAULT_INJECT": "rank=1,step=3,kind=hang"}, steps=50,
+        graph=graph, grace=15)
+    # rank 1 never exits by itself (killed by the test afterwards); rank 0 is
+    # blocked in an all-reduce that cannot complete and leaves through the
+    # monitor thread
+    assert rc0 == 75 and took < 60, (rc0, took, out[0])
+    assert "rank 1 is alive but has been at step" in out[0], out[0]
+    # the hung rank's own monitor sees the others ahead and ends it too,
+    # unless the test's clean-up was faster
+    assert rc1 in (75, -9), out[1]
+    assert "injected fault 'hang' at step 3" in out[1]
+    if rc1 == 75:
+        # either it saw rank 0 ahead of it, or rank 0 (the store's host) had
+        # already left
+        assert "rank 1 (this process) has been at step 3" in out[1] or \
+            "hosts the heartbeat store, which no longer answers" in out[1], \
+            out[1]
+
+
+def test_flag_policy_raises_at_the_step_boundary():
+    # the injected exit closes rank 1's sockets, so rank 0's collective
+    # fails or (if it was not inside one) the next step sees the flag
+    rc0, rc1, out, took = _run({
+        "SINGA_HEARTBEAT": "0.2", "SINGA_HEARTBEAT_TIMEOUT": "2",
+        "SINGA_ON_RANK_FAILURE": "flag", "SINGA_COLLECTIVE_TIMEOUT": "10",
+        "SINGA_FAULT_INJECT": "rank=1,step=2,kind=exit"}, steps=50)
+    assert rc1 == 17, out[1]
+    assert rc0 != 0 and took < 60, (rc0, took, out[0])

@@ -60,7 +60,7 @@ struct GemmArgs {
 template <int BM, int BN, int AMODE, int BMODE>
 __global__ void __launch_bounds__(256)
 gemm_f32_kernel(GemmArgs g) {
-  constexpr int BK = 16;
+  constexpr int BK = 16;  // 32 measured 3-7 % slower (fewer resident workgroups)
   constexpr int WM = BM / 2, WN = BN / 2;  // per-wave tile
   constexpr int TM = WM / 32, TN = WN / 32;  // 32x32 MFMA blocks per wave
   constexpr int LDA = BM + 4, LDB = BN + 4;  // keep 16-byte row alignment
@@ -233,21 +233,32 @@ gemm_f32_kernel(GemmArgs g) {
   const int lrow = lane & 31, lk = lane >> 5;
   for (int t = 0; t < nt; ++t) {
     if (t + 1 < nt) load_tiles((int64_t)(t + 1) * BK);
+    // operands of reduction step ks + 2 are read from LDS before the MFMAs
+    // of step ks issue
+    float a[2][TM], b[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+      a[0][i] = As[lk * LDA + wm * WM + 32 * i + lrow];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      b[0][j] = Bs[lk * LDB + wn * WN + 32 * j + lrow];
 #pragma unroll
     for (int ks = 0; ks < BK; ks += 2) {
-      float a[TM], b[TN];
+      const int cur = (ks >> 1) & 1, nxt = cur ^ 1;
+      if (ks + 2 < BK) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[i] = As[(ks + lk) * LDA + wm * WM + 32 * i + lrow];
+        for (int i = 0; i < TM; ++i)
+          a[nxt][i] = As[(ks + 2 + lk) * LDA + wm * WM + 32 * i + lrow];
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[j] = Bs[(ks + lk) * LDB + wn * WN + 32 * j + lrow];
+        for (int j = 0; j < TN; ++j)
+          b[nxt][j] = Bs[(ks + 2 + lk) * LDB + wn * WN + 32 * j + lrow];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j],
-                                                           acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+              a[cur][i], b[cur][j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
     if (t + 1 < nt) {
@@ -270,6 +281,194 @@ gemm_f32_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int64_t row =
             m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row >= g.M) continue;
+        float v = g.alpha * acc[i][j][r] + bv;
+        float *cp = C + row * g.ldc + col;
+        if (g.beta != 0.f) v += g.beta * (*cp);
+        if (g.act == 1) v = fmaxf(v, 0.f);
+        *cp = v;
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// float32, tile family with two LDS stages
+// ---------------------------------------------------------------------------
+// Four waves arranged WVM x WVN, each owning TM x TN accumulator blocks of
+// 32 x 32: workgroup tile (32 TM WVM) x (32 TN WVN) x 16.  A wave that owns
+// 2 x 2 or more blocks issues four or more 64-cycle MFMAs per four operand
+// reads.  The LDS tiles are double buffered: the global loads of reduction
+// step t + 1 are in flight during the MFMAs of step t and land in the other
+// stage, so a step costs ONE workgroup barrier.  The tile shape is chosen per
+// problem (f32_tile_for) so that the tile count divides well over 256 CUs.
+//
+// One operand tile of ROWS rows (m or n) x BK reduction indices, staged in
+// float4 units.  MODE says which index is contiguous in memory.
+template <int ROWS, int BK, int MODE>
+struct F32Stage {
+  static constexpr int UNITS = ROWS * BK / 4;
+  static constexpr int PER = (UNITS + 255) / 256;
+  static constexpr int LD = ROWS + 4;  // rows keep 16-byte alignment
+  float4 r[PER];
+
+  // rs / ks: element strides of the row index and of the reduction index
+  __device__ __forceinline__ void load(const float *__restrict__ P, int tid,
+                                       int64_t r0, int64_t k0, int64_t R,
+                                       int64_t Kz, int64_t rs, int64_t ks) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int u = tid + 256 * j;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (UNITS % 256 == 0 || u < UNITS) {
+        if (MODE == LD_VEC_K) {
+          const int row = u % ROWS, kq = u / ROWS;
+          const int64_t gr = r0 + row, gk = k0 + 4 * kq;
+          if (gr < R && gk < Kz)
+            v = *reinterpret_cast<const float4 *>(P + gr * rs + gk);
+        } else if (MODE == LD_VEC_MN) {
+          const int rq = u % (ROWS / 4), k = u / (ROWS / 4);
+          const int64_t gr = r0 + 4 * rq, gk = k0 + k;
+          if (gr < R && gk < Kz)
+            v = *reinterpret_cast<const float4 *>(P + gk * ks + gr);
+        } else {
+          float e[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int el = 4 * u + i;
+            const int row = el % ROWS, k = el / ROWS;
+            const int64_t gr = r0 + row, gk = k0 + k;
+            e[i] = (gr < R && gk < Kz) ? P[gr * rs + gk * ks] : 0.f;
+          }
+          v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+      }
+      r[j] = v;
+    }
+  }
+
+  // S: float[BK][LD], reduction index major
+  __device__ __forceinline__ void store(float *__restrict__ S, int tid) const {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int u = tid + 256 * j;
+      if (UNITS % 256 != 0 && u >= UNITS) continue;
+      if (MODE == LD_VEC_K) {
+        const int row = u % ROWS, kq = u / ROWS;
+        S[(4 * kq + 0) * LD + row] = r[j].x;
+        S[(4 * kq + 1) * LD + row] = r[j].y;
+        S[(4 * kq + 2) * LD + row] = r[j].z;
+        S[(4 * kq + 3) * LD + row] = r[j].w;
+      } else if (MODE == LD_VEC_MN) {
+        const int rq = u % (ROWS / 4), k = u / (ROWS / 4);
+        *reinterpret_cast<float4 *>(&S[k * LD + 4 * rq]) = r[j];
+      } else {
+        const float e[4] = {r[j].x, r[j].y, r[j].z, r[j].w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int el = 4 * u + i;
+          S[(el / ROWS) * LD + (el % ROWS)] = e[i];
+        }
+      }
+    }
+  }
+};
+
+template <int WVM, int WVN, int TM, int TN, int AMODE, int BMODE>
+__global__ void __launch_bounds__(256)
+gemm_f32_tiles_kernel(GemmArgs g) {
+  static_assert(WVM * WVN == 4, "four waves");
+  constexpr int BK = 16;
+  constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
+  using StageA = F32Stage<BM, BK, AMODE>;
+  using StageB = F32Stage<BN, BK, BMODE>;
+  constexpr int LDA = StageA::LD, LDB = StageB::LD;
+  __shared__ __attribute__((aligned(16))) float As[2][BK * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WVN, wn = wid % WVN;
+  // XCD x walks the x-th eighth of the tile list in bands of 8 tile rows (see
+  // gemm_f32_kernel)
+  int64_t m0, n0;
+  {
+    const int ntm = (int)((g.M + BM - 1) / BM), ntn = (int)((g.N + BN - 1) / BN);
+    const int w = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (w >= ntm * ntn) return;
+    const int band = 8 * ntn;
+    const int first = (w / band) * 8;
+    const int rows = min(8, ntm - first);
+    const int in_band = w - (w / band) * band;
+    m0 = (int64_t)(first + in_band % rows) * BM;
+    n0 = (int64_t)(in_band / rows) * BN;
+  }
+  const float *A = (const float *)g.A + (int64_t)blockIdx.z * g.a_bs;
+  const float *B = (const float *)g.B + (int64_t)blockIdx.z * g.b_bs;
+  float *C = (float *)g.C + (int64_t)blockIdx.z * g.c_bs;
+  const int64_t Kz = g.k_total
+                         ? max((int64_t)0, min(g.K, g.k_total -
+                                                        (int64_t)blockIdx.z * g.K))
+                         : g.K;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  StageA sa;
+  StageB sb;
+  const int nt = (int)((Kz + BK - 1) / BK);
+  sa.load(A, tid, m0, 0, g.M, Kz, g.a_rs, g.a_cs);
+  sb.load(B, tid, n0, 0, g.N, Kz, g.b_cs, g.b_rs);
+  sa.store(As[0], tid);
+  sb.store(Bs[0], tid);
+  __syncthreads();
+  const int lrow = lane & 31, lk = lane >> 5;
+  const int a_off = lk * LDA + wm * (32 * TM) + lrow;
+  const int b_off = lk * LDB + wn * (32 * TN) + lrow;
+  for (int t = 0; t < nt; ++t) {
+    const float *as = As[t & 1], *bs = Bs[t & 1];
+    if (t + 1 < nt) {
+      sa.load(A, tid, m0, (int64_t)(t + 1) * BK, g.M, Kz, g.a_rs, g.a_cs);
+      sb.load(B, tid, n0, (int64_t)(t + 1) * BK, g.N, Kz, g.b_cs, g.b_rs);
+    }
+#pragma unroll
+    for (int ks = 0; ks < BK; ks += 2) {
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = as[ks * LDA + a_off + 32 * i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = bs[ks * LDB + b_off + 32 * j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j],
+                                                           acc[i][j], 0, 0, 0);
+    }
+    if (t + 1 < nt) {
+      // the other stage was last read in step t - 1, before the barrier that
+      // ended it
+      sa.store(As[(t + 1) & 1], tid);
+      sb.store(Bs[(t + 1) & 1], tid);
+    }
+    __syncthreads();
+  }
+
+  const float *bias = (const float *)g.bias;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int64_t col = n0 + wn * (32 * TN) + 32 * j + (lane & 31);
+      if (col >= g.N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wm * (32 * TM) + 32 * i + (r & 3) +
+                            8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= g.M) continue;
         float v = g.alpha * acc[i][j][r] + bv;
         float *cp = C + row * g.ldc + col;
@@ -1742,6 +1941,95 @@ void launch_f32(const GemmArgs &g, int amode, int bmode, dim3 grid,
                      dim3(256), 0, s, g);
 }
 
+// Tile shapes of gemm_f32_tiles_kernel (indices 0..6) and, as index 7, the
+// single-stage kernel with 128 x 128 tiles.  `rate`: speed of one CU working
+// on tiles of that shape relative to the best one, from tools/
+// bench_gemm_tiles.py on large products (the single-stage kernel keeps more
+// workgroups resident and leads there; the 256-wide tiles leave one wave per
+// SIMD and never won).
+struct F32Tile {
+  int bm, bn;
+  float rate;
+};
+static const F32Tile kF32Tiles[] = {
+    {64, 64, 0.84f},   {128, 64, 0.87f},  {64, 128, 0.92f}, {128, 128, 0.94f},
+    {256, 128, 0.80f}, {256, 96, 0.85f},  {128, 256, 0.82f}, {128, 128, 1.0f}};
+constexpr int kNumF32Tiles = sizeof(kF32Tiles) / sizeof(kF32Tiles[0]);
+constexpr int kF32SingleStage = 7;
+
+static int &f32_tile_override() {
+  static int v = [] {
+    const char *e = getenv("SA_GEMM_F32_TILE");
+    return e && *e ? atoi(e) : -1;
+  }();
+  return v;
+}
+
+// The shape whose busiest CU finishes first: a CU hosts ceil(tiles / 256)
+// tiles of bm x bn outputs at the shape's rate; edge tiles count whole.
+static int f32_tile_for(int64_t M, int64_t N, int64_t batch) {
+  const int forced = f32_tile_override();
+  if (forced >= 0 && forced < kNumF32Tiles) return forced;
+  int best = 0;
+  double best_cost = 1e300;
+  for (int i : {0, 1, 2, 3, kF32SingleStage}) {
+    const F32Tile &t = kF32Tiles[i];
+    if (i == kF32SingleStage && (M < 96 || N < 96)) continue;
+    const int64_t tiles = ((M + t.bm - 1) / t.bm) * ((N + t.bn - 1) / t.bn) *
+                          batch;
+    const double per_cu = (double)((tiles + 255) / 256);
+    const double cost = per_cu * t.bm * t.bn / t.rate;
+    if (cost < best_cost * 0.999) {
+      best_cost = cost;
+      best = i;
+    }
+  }
+  return best;
+}
+
+template <int WVM, int WVN, int TM, int TN>
+static void launch_f32_tiles(const GemmArgs &g, int amode, int bmode,
+                             int64_t batch, hipStream_t s) {
+  constexpr int BM = 32 * TM * WVM, BN = 32 * TN * WVN;
+  const dim3 grid(
+      (unsigned)((((g.N + BN - 1) / BN) * ((g.M + BM - 1) / BM) + 7) / 8 * 8), 1,
+      (unsigned)batch);
+#define SA_GEMM_CASE(AM, BMo)                                                 \
+  if (amode == AM && bmode == BMo) {                                          \
+    hipLaunchKernelGGL(                                                       \
+        (gemm_f32_tiles_kernel<WVM, WVN, TM, TN, AM, BMo>), grid, dim3(256), \
+        0, s, g);                                                             \
+    return;                                                                   \
+  }
+  SA_GEMM_CASE(LD_VEC_K, LD_VEC_MN)
+  SA_GEMM_CASE(LD_VEC_K, LD_VEC_K)
+  SA_GEMM_CASE(LD_VEC_MN, LD_VEC_MN)
+  SA_GEMM_CASE(LD_VEC_MN, LD_VEC_K)
+#undef SA_GEMM_CASE
+  hipLaunchKernelGGL(
+      (gemm_f32_tiles_kernel<WVM, WVN, TM, TN, LD_GENERIC, LD_GENERIC>), grid,
+      dim3(256), 0, s, g);
+}
+
+static void launch_f32_auto(const GemmArgs &g, int amode, int bmode,
+                            int64_t batch, hipStream_t s) {
+  switch (f32_tile_for(g.M, g.N, batch)) {
+    case 0: return launch_f32_tiles<2, 2, 1, 1>(g, amode, bmode, batch, s);
+    case 1: return launch_f32_tiles<2, 2, 2, 1>(g, amode, bmode, batch, s);
+    case 2: return launch_f32_tiles<2, 2, 1, 2>(g, amode, bmode, batch, s);
+    case 3: return launch_f32_tiles<2, 2, 2, 2>(g, amode, bmode, batch, s);
+    case 4: return launch_f32_tiles<2, 2, 4, 2>(g, amode, bmode, batch, s);
+    case 5: return launch_f32_tiles<4, 1, 2, 3>(g, amode, bmode, batch, s);
+    case 6: return launch_f32_tiles<2, 2, 2, 4>(g, amode, bmode, batch, s);
+    default: {
+      const dim3 grid(
+          (unsigned)((((g.N + 127) / 128) * ((g.M + 127) / 128) + 7) / 8 * 8),
+          1, (unsigned)batch);
+      return launch_f32<128, 128>(g, amode, bmode, grid, s);
+    }
+  }
+}
+
 // Split-K epilogue: C = act(alpha * sum_s part[s] + beta * C + bias), part is
 // [splits][M][N] float; dtype is C's and the bias's element type.
 template <typename T>
@@ -1836,6 +2124,11 @@ int sa_gemm(int dtype, int64_t M, int64_t N, int64_t K, float alpha,
       bmode = LD_VEC_K;
     if (amode == LD_GENERIC || bmode == LD_GENERIC)
       amode = bmode = LD_GENERIC;
+    if (f32_tile_override() != -2) {
+      launch_f32_auto(g, amode, bmode, batch, s);
+      return 0;
+    }
+    // SA_GEMM_F32_TILE=-2: the single-stage kernel with 128 / 64 tiles
     if (big) {
       dim3 grid((unsigned)((((N + 127) / 128) * ((M + 127) / 128) + 7) / 8 * 8),
                 1, (unsigned)batch);
@@ -1908,11 +2201,18 @@ int sa_gemm_f32_slices(int64_t M, int64_t N, int64_t kc, int64_t k_total,
     bmode = LD_VEC_K;
   if (amode == LD_GENERIC || bmode == LD_GENERIC)
     amode = bmode = LD_GENERIC;
+  if (f32_tile_override() != -2) {
+    launch_f32_auto(g, amode, bmode, splits, s);
+    return 0;
+  }
   dim3 grid((unsigned)((((N + 63) / 64) * ((M + 63) / 64) + 7) / 8 * 8), 1,
             (unsigned)splits);
   launch_f32<64, 64>(g, amode, bmode, grid, s);
   return 0;
 }
+
+void sa_set_gemm_f32_tile(int tile) { f32_tile_override() = tile; }
+int sa_get_gemm_f32_tile() { return f32_tile_override(); }
 
 int sa_gemm_h16_partial(int dtype, int64_t M, int64_t N, int64_t K,
                         const void *A, int64_t a_rs, int64_t a_cs,

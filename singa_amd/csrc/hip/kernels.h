@@ -216,6 +216,13 @@ struct ConvGeom {
 };
 // deterministic mode for every launcher of this library (see common.cuh)
 void sa_set_deterministic(int on);
+// float32 GEMM tile shape: -1 chosen per problem; 0..6 one shape of the
+// two-stage kernel family (64x64, 128x64, 64x128, 128x128, 256x128, 256x96,
+// 128x256), 7 the single-stage kernel with 128x128 tiles, for every problem
+// (what a tuner sets around one call); -2 the single-stage kernel with its
+// own 128 / 64 choice
+void sa_set_gemm_f32_tile(int tile);
+int sa_get_gemm_f32_tile();
 int sa_get_deterministic();
 // copies of the statistics rows (spreads same-address atomics; one per XCD)
 constexpr int kStatCopies = 8;

@@ -71,8 +71,8 @@ def _is_linear(shp, st):
 
 
 _CONV_AUTOTUNE = os.environ.get("SINGA_CONV_AUTOTUNE", "1") != "0"
-# float32 GEMM: measure (tile shape, reduction slices) per problem on first
-# use; 0 keeps the heuristic of the launcher
+# GEMM: measure (tile shape, reduction slices) per problem on first use; 0
+# keeps the heuristic of the launcher
 _GEMM_AUTOTUNE = os.environ.get("SINGA_GEMM_AUTOTUNE", "1") != "0"
 # SINGA_DETERMINISTIC=1: bitwise reproducible training steps.  Reductions that
 # are split over workgroups (convolution passes, column sums, whole-tensor
@@ -429,12 +429,12 @@ class HipMath(object):
         ldc = c.stride()[-2] if c.dim() >= 2 else N
         splits = self._gemm_splits(M, N, K) if batch == 1 and c.dtype in (
             torch.float32, torch.float16, torch.bfloat16) else 1
-        if c.dtype == torch.float32 and _GEMM_AUTOTUNE:
+        if _GEMM_AUTOTUNE and c.dtype in (torch.float32, torch.float16,
+                                          torch.bfloat16):
             plan = self._gemm_plan(alpha, a, b, beta, c, bias, act,
                                    (M, N, K, batch), splits)
-            if plan is not None:
-                self._gemm_f32_planned(plan, alpha, a, b, beta, c, bias, act,
-                                       (M, N, K, batch))
+            if plan is not None and self._gemm_planned(
+                    plan, alpha, a, b, beta, c, bias, act, (M, N, K, batch)):
                 return
         if splits > 1 and c.dtype != torch.float32 and (K // splits) % 64:
             splits = 1          # the 16-bit tiles are 64 deep
@@ -501,16 +501,19 @@ class HipMath(object):
                     c.data_ptr(), ldc, c_bs, batch,
                     bias.data_ptr() if bias is not None else 0, act, self._s())
 
-    # ---- float32 GEMM launch plans -----------------------------------------
-    # (tile shape, reduction slices) per problem -- extents, batch and which
-    # index of each operand is contiguous -- measured on the real operands
-    # the first time the problem is met outside stream capture and kept in the
-    # same store as the convolution plans.  Tile codes as in
-    # csrc/hip/kernels.h:sa_set_gemm_f32_tile.
+    # ---- GEMM launch plans -------------------------------------------------
+    # (tile shape, reduction slices) per problem -- element type, extents,
+    # batch and which index of each operand is contiguous -- measured on the
+    # real operands the first time the problem is met outside stream capture
+    # and kept in the same store as the convolution plans.  Tile codes as in
+    # csrc/hip/kernels.h: sa_set_gemm_f32_tile / sa_set_gemm_h16_tile.
     _gemm_plans = {}
-    _GEMM_TILES = (-2, 7, 0, 1, 2, 3)
+    _GEMM_TILES_F32 = (-2, 7, 0, 1, 2, 3)
+    _GEMM_TILES_H16 = (-1, 0, 1, 2, 3, 4)
 
-    def _gemm_f32_planned(self, plan, alpha, a, b, beta, c, bias, act, dims):
+    def _gemm_planned(self, plan, alpha, a, b, beta, c, bias, act, dims):
+        """Run the product with ``plan``; False when the plan does not apply
+        to these operands (a 16-bit layout the tiled kernel refuses)."""
         tile, splits = plan
         M, N, K, batch = dims
         if batch == 1:
@@ -523,34 +526,44 @@ class HipMath(object):
             c_bs = c.stride()[0]
         ldc = c.stride()[-2] if c.dim() >= 2 else N
         bp = bias.data_ptr() if bias is not None else 0
-        self.k.set_gemm_f32_tile(tile)
+        f32 = c.dtype == torch.float32
+        code = _code(c)
+        setter = self.k.set_gemm_f32_tile if f32 else self.k.set_gemm_h16_tile
+        setter(tile)
         try:
             if splits > 1:
                 kc = K // splits
                 part = torch.empty(splits * M * N, dtype=torch.float32,
                                    device=c.device)
-                self.k.gemm(0, M, N, kc, 1.0, a.data_ptr(), a_rs, a_cs,
-                            kc * a_cs, b.data_ptr(), b_rs, b_cs, kc * b_rs,
-                            0.0, part.data_ptr(), N, M * N, splits, 0, 0,
-                            self._s())
+                if f32:
+                    self.k.gemm(0, M, N, kc, 1.0, a.data_ptr(), a_rs, a_cs,
+                                kc * a_cs, b.data_ptr(), b_rs, b_cs,
+                                kc * b_rs, 0.0, part.data_ptr(), N, M * N,
+                                splits, 0, 0, self._s())
+                elif self.k.gemm_h16_partial(
+                        code, M, N, kc, a.data_ptr(), a_rs, a_cs, kc * a_cs,
+                        b.data_ptr(), b_rs, b_cs, kc * b_rs, part.data_ptr(),
+                        splits, self._s()) != 0:
+                    return False
                 self.k.gemm_splitk_reduce(
-                    0, part.data_ptr(), splits, M, N, float(alpha),
+                    code, part.data_ptr(), splits, M, N, float(alpha),
                     float(beta), c.data_ptr(), ldc, bp, act, self._s())
             else:
-                self.k.gemm(0, M, N, K, float(alpha), a.data_ptr(), a_rs,
+                self.k.gemm(code, M, N, K, float(alpha), a.data_ptr(), a_rs,
                             a_cs, a_bs, b.data_ptr(), b_rs, b_cs, b_bs,
                             float(beta), c.data_ptr(), ldc, c_bs, batch, bp,
                             act, self._s())
         finally:
-            self.k.set_gemm_f32_tile(-1)
+            setter(-1)
+        return True
 
     def _gemm_plan(self, alpha, a, b, beta, c, bias, act, dims, rule_splits):
-        """(tile, slices) for this float32 product, or None to take the
-        heuristic path."""
+        """(tile, slices) for this product, or None to take the heuristic
+        path."""
         M, N, K, batch = dims
         if M * N * K < (1 << 21) or _DETERMINISTIC:
             return None            # launch-bound: nothing to gain
-        key = ("gemm32", M, N, K, batch,
+        key = ("gemm", _code(c), M, N, K, batch,
                a.stride()[-1] == 1, a.stride()[-2] == 1,
                b.stride()[-1] == 1, b.stride()[-2] == 1)
         plan = self._gemm_plans.get(key)
@@ -563,7 +576,7 @@ class HipMath(object):
         if stored is not None:
             plan = (int(stored[0]), int(stored[1]))
         elif not torch.cuda.is_current_stream_capturing() and beta == 0.0 \
-                and K % 4 == 0:
+                and K % 8 == 0:
             plan = self._measure_gemm_plan(alpha, a, b, c, bias, act, dims,
                                            rule_splits)
             self._persist_plan(name, plan)
@@ -574,10 +587,12 @@ class HipMath(object):
     def _measure_gemm_plan(self, alpha, a, b, c, bias, act, dims,
                            rule_splits):
         M, N, K, batch = dims
+        f32 = c.dtype == torch.float32
+        depth = 4 if f32 else 64      # slices end on a whole reduction tile
         cuts = {1}
         if batch == 1:
             for sp in (rule_splits, 2 * rule_splits, rule_splits // 2, 2, 4):
-                if sp > 1 and K % sp == 0 and (K // sp) % 4 == 0 and \
+                if sp > 1 and K % sp == 0 and (K // sp) % depth == 0 and \
                         K // sp >= 128 and \
                         sp * M * N * 4 <= (256 << 20):
                     cuts.add(sp)
@@ -586,28 +601,32 @@ class HipMath(object):
         stream = torch.cuda.current_stream()
         best, best_t = None, None
         for sp in sorted(cuts):
-            for tile in self._GEMM_TILES:
-                if tile == 7 and (M < 96 or N < 96):
+            for tile in (self._GEMM_TILES_F32 if f32
+                         else self._GEMM_TILES_H16):
+                if f32 and tile == 7 and (M < 96 or N < 96):
                     continue
                 plan = (tile, sp)
 
                 def run(n):
                     e0.record(stream)
                     for _ in range(n):
-                        self._gemm_f32_planned(plan, alpha, a, b, 0.0, c,
-                                               bias, act, dims)
+                        if not self._gemm_planned(plan, alpha, a, b, 0.0, c,
+                                                  bias, act, dims):
+                            return None
                     e1.record(stream)
                     e1.synchronize()
                     return e0.elapsed_time(e1) / n
                 t = run(2)                     # pages the code in as well
+                if t is None:
+                    continue
                 if t < 0.15:
                     # the host cannot launch this fast: time the kernels
                     # alone by replaying a captured burst
                     burst = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(burst):
                         for _ in range(16):
-                            self._gemm_f32_planned(plan, alpha, a, b, 0.0, c,
-                                                   bias, act, dims)
+                            self._gemm_planned(plan, alpha, a, b, 0.0, c,
+                                               bias, act, dims)
                     burst.replay()
                     e0.record(stream)
                     burst.replay()
@@ -876,7 +895,7 @@ class HipMath(object):
             import ast
             for name, plan in table.items():
                 key = ast.literal_eval(name)
-                store = type(self)._gemm_plans if key[0] == "gemm32" \
+                store = type(self)._gemm_plans if key[0] == "gemm" \
                     else type(self)._conv_plans
                 store[key] = (int(plan[0]), int(plan[1]))
 

@@ -53,6 +53,7 @@ PYBIND11_MODULE(_hip, m) {
 
   // ---- element-wise -------------------------------------------------------
   m.def("set_gemm_f32_tile", [](int t) { sa_set_gemm_f32_tile(t); });
+  m.def("set_gemm_h16_tile", [](int t) { sa_set_gemm_h16_tile(t); });
   m.def("get_gemm_f32_tile", []() { return sa_get_gemm_f32_tile(); });
   m.def("set_deterministic", [](int on) { sa_set_deterministic(on); },
         "split reductions combine their partial sums in a fixed order");

@@ -1059,9 +1059,25 @@ static const int kGemmTile = [] {
   return v && *v ? atoi(v) : 0;
 }();
 
+// 16-bit GEMM tile shape: -1 chosen by the rule below; 0 128x128 (4 waves),
+// 1 256x256, 2 256x128, 3 128x256 (8 waves), 4 64x128 (4 waves) for every
+// problem -- what a tuner sets around one call
+static int &h16_tile_override() {
+  static int v = -1;
+  return v;
+}
+
 template <typename T>
 static void launch_h16_fast(const GemmArgs &g, bool a_kc, bool b_kc,
                             int64_t batch, hipStream_t s) {
+  switch (h16_tile_override()) {
+    case 0: return launch_h16_shape<T, 2, 2, 2, 2>(g, a_kc, b_kc, batch, s);
+    case 1: return launch_h16_shape<T, 2, 4, 4, 2>(g, a_kc, b_kc, batch, s);
+    case 2: return launch_h16_shape<T, 2, 4, 4, 1>(g, a_kc, b_kc, batch, s);
+    case 3: return launch_h16_shape<T, 2, 4, 2, 2>(g, a_kc, b_kc, batch, s);
+    case 4: return launch_h16_shape<T, 1, 4, 2, 1>(g, a_kc, b_kc, batch, s);
+    default: break;
+  }
   // 256 x 256 tiles (one workgroup per CU at a time) when their rounds over
   // the 256 CUs are at least 80 % full
   const int64_t t256 = ((g.M + 255) / 256) * ((g.N + 255) / 256) * batch;
@@ -2211,6 +2227,7 @@ int sa_gemm_f32_slices(int64_t M, int64_t N, int64_t kc, int64_t k_total,
   return 0;
 }
 
+void sa_set_gemm_h16_tile(int tile) { h16_tile_override() = tile; }
 void sa_set_gemm_f32_tile(int tile) { f32_tile_override() = tile; }
 int sa_get_gemm_f32_tile() { return f32_tile_override(); }
 

@@ -222,6 +222,9 @@ void sa_set_deterministic(int on);
 // (what a tuner sets around one call); -2 the single-stage kernel with its
 // own 128 / 64 choice
 void sa_set_gemm_f32_tile(int tile);
+// 16-bit GEMM tile shape: -1 chosen per problem, 0 128x128, 1 256x256,
+// 2 256x128, 3 128x256, 4 64x128
+void sa_set_gemm_h16_tile(int tile);
 int sa_get_gemm_f32_tile();
 int sa_get_deterministic();
 // copies of the statistics rows (spreads same-address atomics; one per XCD)

@@ -248,3 +248,96 @@ def test_end_to_end_and_database_entry_points():
     assert "best_arch" in whole and "plan" in whole
     bad = json.loads(pg_interface.coordinator("x", 1, 1))
     assert "Errored" in bad
+
+
+# ------------------------------------------------- study tooling and slicing
+def test_rank_correlations_against_scipy():
+    from trails import correlation
+    from scipy import stats
+    rng = np.random.RandomState(3)
+    a = rng.randint(0, 6, 40).astype(float)       # many ties
+    b = a + rng.randn(40)
+    assert abs(correlation.spearman(a, b) -
+               stats.spearmanr(a, b)[0]) < 1e-9
+    assert abs(correlation.kendall_tau(a, b) -
+               stats.kendalltau(a, b)[0]) < 1e-9
+    assert correlation.spearman([1, 2, 3], [3, 2, 1]) == -1.0
+    assert correlation.kendall_tau([1, 1, 1], [1, 2, 3]) == 0.0
+
+
+def test_score_accuracy_study():
+    from trails import correlation
+    d = dataset.synthetic(n=256, nfield=4, vocab_per_field=5)
+    sp = space.MlpSpace(d.nfield, d.nfeat, num_layers=2,
+                        layer_choices=(4, 16, 64))
+    archs = ["4-4", "16-16", "64-64", "4-64"]
+    rows, acc = correlation.study(sp, device.get_default_device(),
+                                  next(d.batches(32)), _FakeTrainer(), archs,
+                                  ["weight_norm", "synflow", "fisher"])
+    assert len(acc) == 4 and [r["metric"] for r in rows]
+    # the stand-in trainer's accuracy grows with width, and so do these scores
+    by = {r["metric"]: r for r in rows}
+    assert by["weight_norm"]["spearman"] > 0.7
+    assert all(-1.0 <= r["kendall_tau"] <= 1.0 for r in rows)
+
+
+def test_resource_measure(tmp_path):
+    from trails import res_measure
+    log = tmp_path / "res.jsonl"
+    with res_measure.Measure("phase", str(log)) as m:
+        np.linalg.svd(np.random.rand(200, 200))
+    assert m.result["tag"] == "phase" and m.result["wall_s"] > 0
+    rec = json.loads(log.read_text().strip())
+    assert rec["tag"] == "phase" and rec["cpu_s"] >= 0
+
+
+def test_concurrent_evaluator_matches_the_serial_one():
+    from trails import concurrent
+    d = dataset.synthetic(n=64, nfield=4, vocab_per_field=5)
+    sp = space.MlpSpace(d.nfield, d.nfeat, num_layers=2,
+                        layer_choices=(4, 16))
+    batch = next(d.batches(16))
+    archs = ["4-4", "4-16", "16-4", "16-16"]
+    pool = concurrent.ConcurrentEvaluator(sp, batch, "weight_norm", workers=2)
+    try:
+        got = pool.score(archs, timeout=120)
+    finally:
+        pool.close()
+    assert set(got) == set(archs) and all(np.isfinite(v) for v in got.values())
+    # weight norms grow with the layer widths in every process alike
+    assert got["16-16"] > got["4-4"]
+
+
+def test_sliced_inference_entry_points(tmp_path):
+    from slicing import pg_interface as spg, sams
+    d = dataset.synthetic(n=512, nfield=4, vocab_per_field=5)
+    dev = device.get_default_device()
+    m = sams.SlicedMoE(d.nfield, d.nfeat, experts=4, top=2)
+    losses = sams.train(m, dev, d, epochs=4, batch_size=32)
+    assert np.mean(losses[-4:]) < np.mean(losses[:4])
+    path = str(tmp_path / "sams.zip")
+    m.save_states(path)
+    cfg = {"nfield": d.nfield, "nfeat": d.nfeat, "model_path": path}
+    assert json.loads(spg.model_inference_load_model(json.dumps(cfg)))["ok"]
+    ids, values, _ = next(d.batches(8))
+    rows = [{"id": i.tolist(), "value": v.tolist()}
+            for i, v in zip(ids, values)]
+    res = json.loads(spg.model_inference_compute(json.dumps(
+        {"where_cond": {"1": int(ids[0, 1])}, "mini_batch": rows})))
+    assert res["ok"], res
+    p = np.array(res["result"]["probabilities"])
+    assert p.shape == (8, 2) and np.allclose(p.sum(1), 1.0, atol=1e-5)
+    assert len(res["result"]["experts_used"]) == 2
+    # the loaded model reproduces the trained one
+    pred = np.tile(sams.predicate_ids(m, {1: int(ids[0, 1])}), (8, 1))
+    from singa_amd import tensor as st
+    ref = st.to_numpy(m.forward(st.from_numpy(ids.astype(np.int32), dev),
+                                st.from_numpy(values.astype(np.float32), dev),
+                                st.from_numpy(pred, dev)))
+    z = np.exp(ref - ref.max(1, keepdims=True))
+    np.testing.assert_allclose(p, z / z.sum(1, keepdims=True), atol=1e-5)
+    # errors come back as JSON, never as exceptions
+    bad = json.loads(spg.model_inference_compute(json.dumps(
+        {"mini_batch": [{"id": [0], "value": [1.0]}]})))
+    assert not bad["ok"] and "fields" in bad["error"]
+    assert not json.loads(spg.model_inference_compute("{not json"))["ok"]

@@ -553,6 +553,124 @@ bn_bwd_channel_kernel(const T *__restrict__ dy, const T *__restrict__ x,
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// One workgroup per channel, two sweeps over the channel
+// ---------------------------------------------------------------------------
+// For channels too large for the registers of a workgroup (the 112 x 112 and
+// 56 x 56 layers at batch 32): the workgroup reads its channel once for the
+// statistics and a second time to apply them.  The second sweep starts where
+// the first one started, a few hundred microseconds earlier, so its reads
+// are served by the Infinity Cache (256 channels x 400 KB per tensor stay
+// well inside its 256 MiB) instead of by a second pass over HBM as with two
+// kernels, and the statistics never leave the workgroup.
+template <typename T, int VEC, int ACT>
+__global__ void __launch_bounds__(1024)
+bn_fwd_sweep_kernel(const T *__restrict__ x, const float *__restrict__ scale,
+                    const float *__restrict__ bias, float *__restrict__ rmean,
+                    float *__restrict__ rvar, float factor, float eps,
+                    T *__restrict__ y, float *__restrict__ mean_out,
+                    float *__restrict__ invstd_out, const T *__restrict__ res,
+                    int N, int C, int HW, int units, Div32 div_per) {
+  __shared__ float smem[32];
+  const int c = blockIdx.x;
+  const float shift = to_f<T>(x[(size_t)c * HW]);
+  float sum = 0.f, sq = 0.f;
+  for (int u = threadIdx.x; u < units; u += blockDim.x) {
+    const BnUnit at = bn_unit(u, c, C, HW, div_per);
+    BnPiece<T, VEC> xv;
+    xv.ld(x, at.off, at.i);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float d = xv.v[e] - shift;
+      sum += d;
+      sq += d * d;
+    }
+  }
+  sum = block_sum(sum, smem);
+  sq = block_sum(sq, smem);
+  const float cnt = (float)N * (float)HW;
+  const float dm = sum / cnt;
+  const float mean = shift + dm;
+  const float var = fmaxf(sq / cnt - dm * dm, 0.f);
+  const float invstd = rsqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_out[c] = mean;
+    invstd_out[c] = invstd;
+    const float unbiased = cnt > 1.f ? var * cnt / (cnt - 1.f) : var;
+    rmean[c] = (1.f - factor) * rmean[c] + factor * mean;
+    rvar[c] = (1.f - factor) * rvar[c] + factor * unbiased;
+  }
+  const float g = scale[c] * invstd;
+  const float b = bias[c] - mean * g;
+  for (int u = threadIdx.x; u < units; u += blockDim.x) {
+    const BnUnit at = bn_unit(u, c, C, HW, div_per);
+    BnPiece<T, VEC> xv, r, o;
+    xv.ld(x, at.off, at.i);
+    if (ACT == 2) r.ld(res, at.off, at.i);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e)
+      o.v[e] = bn_act<ACT>(fmaf(xv.v[e], g, b), ACT == 2 ? r.v[e] : 0.f);
+    o.st(y, at.off, at.i);
+  }
+}
+
+template <typename T, int VEC, int ACT>
+__global__ void __launch_bounds__(1024)
+bn_bwd_sweep_kernel(const T *__restrict__ dy, const T *__restrict__ x,
+                    const T *__restrict__ y, const float *__restrict__ scale,
+                    const float *__restrict__ bias,
+                    const float *__restrict__ mean,
+                    const float *__restrict__ invstd, T *__restrict__ dx,
+                    T *__restrict__ dres, float *__restrict__ dscale,
+                    float *__restrict__ dbias, int N, int C, int HW, int units,
+                    Div32 div_per) {
+  __shared__ float smem[32];
+  const int c = blockIdx.x;
+  const float m = mean[c], iv = invstd[c];
+  const float g = scale[c] * iv;
+  const float b = ACT == 1 ? bias[c] - m * g : 0.f;
+  float sdy = 0.f, sdyx = 0.f;
+  for (int u = threadIdx.x; u < units; u += blockDim.x) {
+    const BnUnit at = bn_unit(u, c, C, HW, div_per);
+    BnPiece<T, VEC> dv, xv, yv;
+    dv.ld(dy, at.off, at.i);
+    xv.ld(x, at.off, at.i);
+    if (ACT == 2) yv.ld(y, at.off, at.i);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float d = bn_mask<ACT>(dv.v[e], xv.v[e], g, b,
+                                   ACT == 2 ? yv.v[e] : 0.f);
+      sdy += d;
+      sdyx += d * (xv.v[e] - m);
+    }
+  }
+  sdy = block_sum(sdy, smem);
+  sdyx = block_sum(sdyx, smem) * iv;
+  if (threadIdx.x == 0) {
+    dscale[c] = sdyx;
+    dbias[c] = sdy;
+  }
+  const float cnt = (float)N * (float)HW;
+  const float k1 = sdy / cnt, k2 = sdyx / cnt * iv;
+  for (int u = threadIdx.x; u < units; u += blockDim.x) {
+    const BnUnit at = bn_unit(u, c, C, HW, div_per);
+    BnPiece<T, VEC> dv, xv, yv, o;
+    dv.ld(dy, at.off, at.i);
+    xv.ld(x, at.off, at.i);
+    if (ACT == 2) yv.ld(y, at.off, at.i);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float d = bn_mask<ACT>(dv.v[e], xv.v[e], g, b,
+                                   ACT == 2 ? yv.v[e] : 0.f);
+      dv.v[e] = d;
+      o.v[e] = g * (d - k1 - (xv.v[e] - m) * k2);
+    }
+    o.st(dx, at.off, at.i);
+    if (ACT == 2) dv.st(dres, at.off, at.i);
+  }
+}
+
 }  // namespace sa
 
 using namespace sa;
@@ -586,6 +704,18 @@ static int bn_channel_threads(int64_t units) {
   int t = (int)((units + kBnUnits - 1) / kBnUnits);
   t = (t + 63) / 64 * 64;
   return t < 64 ? 64 : t;
+}
+
+// Channels that do not fit a workgroup's registers are swept twice by one
+// workgroup each when there are at least SA_BN_SWEEP channels (default 256:
+// one workgroup per CU; measured 10 % faster than the statistics + apply pair
+// on the 256-channel 56 x 56 layers, slower below 128 channels), 0 = never.
+static bool bn_sweep(int C) {
+  static const int min_c = [] {
+    const char *v = getenv("SA_BN_SWEEP");
+    return v && *v ? atoi(v) : 256;
+  }();
+  return min_c > 0 && C >= min_c;
 }
 
 #define BN_ACT_SWITCH(act, ...)                         \
@@ -624,6 +754,18 @@ int sa_bn_fwd_train_act(int dtype, const void *x, const float *scale,
                                rmean, rvar, factor, eps, (T *)y, mean, invstd,
                                (const T *)residual, N, C, HW, (int)units,
                                Div32(per));
+        });
+      });
+      return 0;
+    }
+    if (v4 && bn_sweep(C) && units < ((int64_t)1 << 31)) {
+      SA_DISPATCH_FLOAT(dtype, T, {
+        BN_ACT_SWITCH(act, {
+          hipLaunchKernelGGL((bn_fwd_sweep_kernel<T, 4, ACT>), dim3(C),
+                             dim3(1024), 0, s, (const T *)x, scale, bias,
+                             rmean, rvar, factor, eps, (T *)y, mean, invstd,
+                             (const T *)residual, N, C, HW, (int)units,
+                             Div32(per));
         });
       });
       return 0;
@@ -785,6 +927,18 @@ int sa_bn_bwd_act(int dtype, const void *dy, const void *x, const void *y,
                                (const T *)x, (const T *)y, scale, bias, mean,
                                invstd, (T *)dx, (T *)dres, dscale, dbias, N, C,
                                HW, (int)units, Div32(per));
+        });
+      });
+      return 0;
+    }
+    if (v4 && bn_sweep(C) && units < ((int64_t)1 << 31)) {
+      SA_DISPATCH_FLOAT(dtype, T, {
+        BN_ACT_SWITCH(act, {
+          hipLaunchKernelGGL((bn_bwd_sweep_kernel<T, 4, ACT>), dim3(C),
+                             dim3(1024), 0, s, (const T *)dy, (const T *)x,
+                             (const T *)y, scale, bias, mean, invstd, (T *)dx,
+                             (T *)dres, dscale, dbias, N, C, HW, (int)units,
+                             Div32(per));
         });
       });
       return 0;

@@ -749,6 +749,56 @@ def test_batchnorm(maths, shape):
                                rtol=1e-4)
 
 
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_batchnorm_two_sweeps_per_channel(maths, act):
+    """256 channels of 40 x 28 x 28 values each: too many for a workgroup's
+    registers, enough channels for one workgroup per CU -- the kernels that
+    sweep a channel twice (statistics, then apply), with every activation."""
+    hm, cm, dev = maths
+    shape, C = (40, 256, 28, 28), 256
+    x = rnd(*shape, seed=50, lo=-2, hi=5)
+    res = rnd(*shape, seed=56) if act == 2 else None
+    scale, bias = rnd(C, seed=51, lo=0.5, hi=1.5), rnd(C, seed=52)
+    rm, rv = rnd(C, seed=53), rnd(C, seed=54, lo=0.5, hi=2.0)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    ry, rmean, ristd = torch.empty_like(x), torch.empty(C), torch.empty(C)
+    cm.bn_fwd_train(x, scale, bias, rm_r, rv_r, 0.1, 1e-5, ry, rmean, ristd,
+                    act, res)
+    d = dev.torch_device
+    rm_g, rv_g = g(rm, dev), g(rv, dev)
+    y = torch.empty_like(x, device=d)
+    mean, istd = torch.empty(C, device=d), torch.empty(C, device=d)
+    hm.bn_fwd_train(g(x, dev), g(scale, dev), g(bias, dev), rm_g, rv_g, 0.1,
+                    1e-5, y, mean, istd, act,
+                    g(res, dev) if res is not None else None)
+    np.testing.assert_allclose(y.cpu().numpy(), ry.numpy(), atol=5e-5,
+                               rtol=1e-4)
+    np.testing.assert_allclose(mean.cpu().numpy(), rmean.numpy(), atol=1e-5)
+    np.testing.assert_allclose(istd.cpu().numpy(), ristd.numpy(), rtol=1e-4)
+    np.testing.assert_allclose(rm_g.cpu().numpy(), rm_r.numpy(), atol=1e-5)
+    np.testing.assert_allclose(rv_g.cpu().numpy(), rv_r.numpy(), rtol=1e-4)
+    dy = rnd(*shape, seed=55)
+    rdx, rds, rdb = torch.empty_like(x), torch.empty(C), torch.empty(C)
+    rdres = torch.empty_like(x) if act == 2 else None
+    cm.bn_bwd(dy, x, scale, rmean, ristd, rdx, rds, rdb, act, bias, ry, rdres)
+    dx = torch.empty_like(x, device=d)
+    dres = torch.empty_like(x, device=d) if act == 2 else None
+    ds, db = torch.empty(C, device=d), torch.empty(C, device=d)
+    hm.bn_bwd(g(dy, dev), g(x, dev), g(scale, dev), mean, istd, dx, ds, db,
+              act, g(bias, dev), y, dres)
+    # an element whose activation input is within rounding of zero may fall
+    # on the other side of the ReLU than on the host: compare all but a few
+    bad = ~np.isclose(dx.cpu().numpy(), rdx.numpy(), atol=1e-4, rtol=1e-3)
+    assert bad.mean() < 1e-4, bad.sum()
+    np.testing.assert_allclose(ds.cpu().numpy(), rds.numpy(), atol=5e-2,
+                               rtol=1e-3)
+    np.testing.assert_allclose(db.cpu().numpy(), rdb.numpy(), atol=5e-2,
+                               rtol=1e-3)
+    if act == 2:
+        bad = ~np.isclose(dres.cpu().numpy(), rdres.numpy(), atol=1e-5)
+        assert bad.mean() < 1e-4, bad.sum()
+
+
 def test_conv_backward_pair_while_plans_are_measured(maths, monkeypatch):
     """The data-gradient launch clears the weight gradient for the launch
     that follows.  When the weight-gradient launch plan of a shape is still to

@@ -74,6 +74,7 @@ _CONV_AUTOTUNE = os.environ.get("SINGA_CONV_AUTOTUNE", "1") != "0"
 # GEMM: measure (tile shape, reduction slices) per problem on first use; 0
 # keeps the heuristic of the launcher
 _GEMM_AUTOTUNE = os.environ.get("SINGA_GEMM_AUTOTUNE", "1") != "0"
+_CONV16_AUTOTUNE = os.environ.get("SINGA_CONV16_AUTOTUNE", "1") != "0"
 # SINGA_DETERMINISTIC=1: bitwise reproducible training steps.  Reductions that
 # are split over workgroups (convolution passes, column sums, whole-tensor
 # sums, the soft-max loss) add their partial results in a fixed order instead
@@ -969,6 +970,113 @@ class HipMath(object):
     def _small_image(t):
         return t.shape[2] * t.shape[3] <= _CONV_FLAT_MAX_HW
 
+    # ---- 16-bit stride-1 convolutions: which GEMM-shaped kernel -------------
+    # Forward (mode 0: act = x, out = y) and backward-data (mode 1: act = dy,
+    # out = dx) of a 1x1 or 3x3 / pad 1 layer can run on the tap GEMM over the
+    # flattened positions of all images ("flat"), on one GEMM per image with
+    # one of the 16-bit tile shapes ("pointwise", 1x1 only) or on the nine-tap
+    # GEMM per image ("window", 3x3 only).  Which one is fastest depends on
+    # image size, channel counts and batch: each applicable one is timed the
+    # first time a geometry is met outside stream capture, the choice is kept
+    # with the other launch plans (SINGA_CONV16_AUTOTUNE=0: a fixed order).
+    _ROUTE_FLAT, _ROUTE_WINDOW, _ROUTE_POINTWISE = 0, 1, 2
+
+    def _routes16(self, mode, act, w, addend, out, stride, pad, groups):
+        """[((route, tile), run)] in the order of the fixed rule; run() ->
+        True when the kernel took the geometry."""
+        ref = act if mode == 0 else out          # the tensor with C channels
+        N, C, H, W = ref.shape
+        K = w.shape[0]
+        code = _code(act)
+        if addend is not None:
+            assert addend.shape == out.shape and addend.dtype == out.dtype \
+                and addend.data_ptr() != out.data_ptr()
+        ad = addend.data_ptr() if addend is not None else 0
+
+        def flat():
+            return bool(self._flat16(mode, act, w, addend, out, stride, pad,
+                                     groups))
+
+        def window():
+            return bool(self._conv3x3_h16(mode, act, w, addend, out))
+
+        def pointwise(tile):
+            def run():
+                self.k.set_gemm_h16_tile(tile)
+                try:
+                    return bool(self.k.conv1x1_h16(
+                        code, mode, N, C, K, H * W, act.data_ptr(),
+                        w.data_ptr(), ad, out.data_ptr(), self._s()))
+                finally:
+                    self.k.set_gemm_h16_tile(-1)
+            return run
+        routes = []
+        if mode == 0 and self._small_image(act):
+            routes.append(((self._ROUTE_FLAT, -1), flat))
+        if self._pointwise16(ref, w, stride, pad, groups):
+            routes.append(((self._ROUTE_POINTWISE, -1), pointwise(-1)))
+            if K > 64 if mode == 0 else C > 64:
+                # (64 rows or fewer always run on the 64 x 128 tile)
+                for tile in (0, 1, 2, 3):
+                    routes.append(((self._ROUTE_POINTWISE, tile),
+                                   pointwise(tile)))
+        if self._window16(act, w, stride, pad, groups):
+            routes.append(((self._ROUTE_WINDOW, -1), window))
+        if not routes or routes[0][0][0] != self._ROUTE_FLAT:
+            routes.append(((self._ROUTE_FLAT, -1), flat))
+        return routes
+
+    def _run_routes16(self, mode, act, w, addend, out, stride, pad, groups):
+        routes = self._routes16(mode, act, w, addend, out, stride, pad, groups)
+        key = ("c16", mode, tuple(act.shape), tuple(w.shape), tuple(stride),
+               tuple(pad), _code(act), addend is not None)
+        plan = self._conv_plans.get(key)
+        if plan is None and _CONV16_AUTOTUNE and not _DETERMINISTIC and \
+                (_world_size() <= 1 or _rank() == 0):
+            name = repr(key)
+            stored = self._plan_store()[1].get(name)
+            if stored is not None:
+                plan = (int(stored[0]), int(stored[1]))
+            elif not torch.cuda.is_current_stream_capturing():
+                plan = self._measure_routes16(routes)
+                if plan is not None:
+                    self._persist_plan(name, plan)
+            if plan is not None:
+                self._conv_plans[key] = plan
+        if plan is not None:
+            for which, run in routes:
+                if which == tuple(plan):
+                    if run():
+                        return True
+                    break
+        for _, run in routes:
+            if run():
+                return True
+        return False
+
+    def _measure_routes16(self, routes):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        stream = torch.cuda.current_stream()
+        best, best_t = None, None
+        for which, run in routes:
+            if not run():               # the kernel refuses the geometry
+                continue
+            burst = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(burst):
+                for _ in range(8):
+                    run()
+            burst.replay()
+            e0.record(stream)
+            burst.replay()
+            e1.record(stream)
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            del burst
+            if best_t is None or t < best_t * 0.97:    # prefer the rule's
+                best, best_t = which, t
+        return best
+
     @property
     def STAT_COPIES(self):
         return self.k.stat_copies
@@ -1031,19 +1139,9 @@ class HipMath(object):
         if self._strided_pointwise16(x, w, stride, pad, groups):
             return self._conv_fwd_16bit(self._even_positions(x), w, None, y,
                                         (1, 1), (0, 0), 1)
-        if self._small_image(x) and \
-                self._flat16(0, x, w, None, y, stride, pad, groups):
-            return True
-        if self._pointwise16(x, w, stride, pad, groups):
-            N, C, H, W = x.shape
-            if self.k.conv1x1_h16(_code(x), 0, N, C, w.shape[0], H * W,
-                                  x.data_ptr(), w.data_ptr(), 0, y.data_ptr(),
-                                  self._s()):
-                return True
-        if self._window16(x, w, stride, pad, groups) and \
-                self._conv3x3_h16(0, x, w, None, y):
-            return True
-        return self._flat16(0, x, w, None, y, stride, pad, groups)
+        if x.dtype not in (torch.float16, torch.bfloat16) or groups != 1:
+            return False
+        return self._run_routes16(0, x, w, None, y, stride, pad, groups)
 
     def conv_bwd_data(self, dy, w, dx, stride, pad, groups, addend=None,
                       side_zero=None):
@@ -1067,28 +1165,10 @@ class HipMath(object):
                                  ad.data_ptr() if ad is not None else 0,
                                  dx.data_ptr(), N * C, H, W, self._s())
             return
-        if self._pointwise16(dx, w, stride, pad, groups):
-            N, C, H, W = dx.shape
-            ad = None
-            if addend is not None:
-                assert addend.shape == dx.shape and addend.dtype == dx.dtype
-                ad = self._contig(addend)
-            if self.k.conv1x1_h16(_code(dx), 1, N, C, w.shape[0], H * W,
-                                  dy.data_ptr(), w.data_ptr(),
-                                  ad.data_ptr() if ad is not None else 0,
-                                  dx.data_ptr(), self._s()):
-                return
-        if self._window16(dy, w, stride, pad, groups):
-            ad = None
-            if addend is not None:
-                assert addend.shape == dx.shape and addend.dtype == dx.dtype \
-                    and addend.data_ptr() != dx.data_ptr()
-                ad = self._contig(addend)
-            if self._conv3x3_h16(1, dy, w, ad, dx):
-                return
-        if self._flat16(1, dy, w,
-                        None if addend is None else self._contig(addend), dx,
-                        stride, pad, groups):
+        if dx.dtype in (torch.float16, torch.bfloat16) and groups == 1 and \
+                self._run_routes16(
+                    1, dy, w, None if addend is None else self._contig(addend),
+                    dx, stride, pad, groups):
             return
         g = self._geom(dx.shape, w.shape, dy.shape, stride, pad, groups)
         scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)

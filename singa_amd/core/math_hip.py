@@ -620,11 +620,12 @@ class HipMath(object):
                 t = run(2)                     # pages the code in as well
                 if t is None:
                     continue
-                if t < 0.15:
+                if t < 0.15 and _world_size() <= 1:
                     # the host cannot launch this fast: time the kernels
-                    # alone by replaying a captured burst
+                    # alone by replaying a captured burst (not while other
+                    # ranks' collectives may be in flight on side streams)
                     burst = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(burst):
+                    with torch.cuda.graph(burst, capture_error_mode="thread_local"):
                         for _ in range(16):
                             self._gemm_planned(plan, alpha, a, b, 0.0, c,
                                                bias, act, dims)
@@ -1062,17 +1063,28 @@ class HipMath(object):
         for which, run in routes:
             if not run():               # the kernel refuses the geometry
                 continue
-            burst = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(burst):
+            if _world_size() <= 1:
+                burst = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(burst,
+                                      capture_error_mode="thread_local"):
+                    for _ in range(8):
+                        run()
+                burst.replay()
+                e0.record(stream)
+                burst.replay()
+                e1.record(stream)
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
+                del burst
+            else:
+                # collectives of this rank may be in flight on side streams:
+                # no capture next to them, plain launches instead
+                e0.record(stream)
                 for _ in range(8):
                     run()
-            burst.replay()
-            e0.record(stream)
-            burst.replay()
-            e1.record(stream)
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
-            del burst
+                e1.record(stream)
+                e1.synchronize()
+                t = e0.elapsed_time(e1)
             if best_t is None or t < best_t * 0.97:    # prefer the rule's
                 best, best_t = which, t
         return best

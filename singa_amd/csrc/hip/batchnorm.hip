@@ -286,6 +286,9 @@ __device__ __forceinline__ float bn_mask(float d, float xv, float g, float b,
   return d;
 }
 
+// With ACT 2 the masked gradient is also the gradient of the residual
+// branch: this pass writes it to `dres`, and the second pass reads it back
+// instead of reading dy and y again (7 passes over the tensors, not 8).
 template <typename T, int VEC, int ACT>
 __global__ void bn_bwd_stats_kernel(const T *__restrict__ dy,
                                     const T *__restrict__ x,
@@ -294,7 +297,8 @@ __global__ void bn_bwd_stats_kernel(const T *__restrict__ dy,
                                     const float *__restrict__ bias,
                                     const float *__restrict__ mean,
                                     const float *__restrict__ invstd,
-                                    float *__restrict__ work, int N, int C,
+                                    float *__restrict__ work,
+                                    T *__restrict__ dres, int N, int C,
                                     int HW, int S) {
   __shared__ float smem[32];
   const int c = blockIdx.x, s = blockIdx.y;
@@ -313,6 +317,7 @@ __global__ void bn_bwd_stats_kernel(const T *__restrict__ dy,
         const float d1 = bn_mask<ACT>(d.y, xv.y, g, b, yv.y);
         const float d2 = bn_mask<ACT>(d.z, xv.z, g, b, yv.z);
         const float d3 = bn_mask<ACT>(d.w, xv.w, g, b, yv.w);
+        if (ACT == 2) V4<T>::st(dres + off, i, make_float4(d0, d1, d2, d3));
         sdy += (d0 + d1) + (d2 + d3);
         sdyx += (d0 * (xv.x - m) + d1 * (xv.y - m)) +
                 (d2 * (xv.z - m) + d3 * (xv.w - m));
@@ -322,6 +327,7 @@ __global__ void bn_bwd_stats_kernel(const T *__restrict__ dy,
         const float xv = to_f<T>(x[off + i]);
         const float yv = ACT == 2 ? to_f<T>(y[off + i]) : 0.f;
         const float d = bn_mask<ACT>(to_f<T>(dy[off + i]), xv, g, b, yv);
+        if (ACT == 2) dres[off + i] = from_f<T>(d);
         sdy += d;
         sdyx += d * (xv - m);
       }
@@ -363,30 +369,28 @@ __global__ void bn_bwd_apply_kernel(
   // dx = g * (d - k1 - (x - m) * k2)  with k2 already carrying one 1/std
   for (int n = s; n < N; n += S) {
     const size_t off = ((size_t)n * C + c) * HW;
+    // ACT 2: the masked gradient was written to dres by the first pass
     if constexpr (VEC == 4) {
       for (int i = threadIdx.x; i < HW / 4; i += blockDim.x) {
-        const float4 d = V4<T>::ld(dy + off, i), xv = V4<T>::ld(x + off, i);
-        float4 yv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ACT == 2) yv = V4<T>::ld(y + off, i);
+        const float4 d = V4<T>::ld((ACT == 2 ? dres : dy) + off, i),
+                     xv = V4<T>::ld(x + off, i);
         float4 dm, o;
-        dm.x = bn_mask<ACT>(d.x, xv.x, g, b, yv.x);
-        dm.y = bn_mask<ACT>(d.y, xv.y, g, b, yv.y);
-        dm.z = bn_mask<ACT>(d.z, xv.z, g, b, yv.z);
-        dm.w = bn_mask<ACT>(d.w, xv.w, g, b, yv.w);
+        dm.x = ACT == 2 ? d.x : bn_mask<ACT>(d.x, xv.x, g, b, 0.f);
+        dm.y = ACT == 2 ? d.y : bn_mask<ACT>(d.y, xv.y, g, b, 0.f);
+        dm.z = ACT == 2 ? d.z : bn_mask<ACT>(d.z, xv.z, g, b, 0.f);
+        dm.w = ACT == 2 ? d.w : bn_mask<ACT>(d.w, xv.w, g, b, 0.f);
         o.x = g * (dm.x - k1 - (xv.x - m) * k2);
         o.y = g * (dm.y - k1 - (xv.y - m) * k2);
         o.z = g * (dm.z - k1 - (xv.z - m) * k2);
         o.w = g * (dm.w - k1 - (xv.w - m) * k2);
         V4<T>::st(dx + off, i, o);
-        if (ACT == 2) V4<T>::st(dres + off, i, dm);
       }
     } else {
       for (int i = threadIdx.x; i < HW; i += blockDim.x) {
         const float xv = to_f<T>(x[off + i]);
-        const float yv = ACT == 2 ? to_f<T>(y[off + i]) : 0.f;
-        const float d = bn_mask<ACT>(to_f<T>(dy[off + i]), xv, g, b, yv);
+        const float d0 = to_f<T>((ACT == 2 ? dres : dy)[off + i]);
+        const float d = ACT == 2 ? d0 : bn_mask<ACT>(d0, xv, g, b, 0.f);
         dx[off + i] = from_f<T>(g * (d - k1 - (xv - m) * k2));
-        if (ACT == 2) dres[off + i] = from_f<T>(d);
       }
     }
   }
@@ -641,9 +645,13 @@ bn_bwd_sweep_kernel(const T *__restrict__ dy, const T *__restrict__ x,
     for (int e = 0; e < VEC; ++e) {
       const float d = bn_mask<ACT>(dv.v[e], xv.v[e], g, b,
                                    ACT == 2 ? yv.v[e] : 0.f);
+      dv.v[e] = d;
       sdy += d;
       sdyx += d * (xv.v[e] - m);
     }
+    // the masked gradient is the residual branch's gradient; the second
+    // sweep (same thread, same units) reads it back instead of dy and y
+    if (ACT == 2) dv.st(dres, at.off, at.i);
   }
   sdy = block_sum(sdy, smem);
   sdyx = block_sum(sdyx, smem) * iv;
@@ -655,19 +663,16 @@ bn_bwd_sweep_kernel(const T *__restrict__ dy, const T *__restrict__ x,
   const float k1 = sdy / cnt, k2 = sdyx / cnt * iv;
   for (int u = threadIdx.x; u < units; u += blockDim.x) {
     const BnUnit at = bn_unit(u, c, C, HW, div_per);
-    BnPiece<T, VEC> dv, xv, yv, o;
-    dv.ld(dy, at.off, at.i);
+    BnPiece<T, VEC> dv, xv, o;
+    dv.ld(ACT == 2 ? dres : dy, at.off, at.i);
     xv.ld(x, at.off, at.i);
-    if (ACT == 2) yv.ld(y, at.off, at.i);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      const float d = bn_mask<ACT>(dv.v[e], xv.v[e], g, b,
-                                   ACT == 2 ? yv.v[e] : 0.f);
-      dv.v[e] = d;
+      const float d = ACT == 2 ? dv.v[e]
+                               : bn_mask<ACT>(dv.v[e], xv.v[e], g, b, 0.f);
       o.v[e] = g * (d - k1 - (xv.v[e] - m) * k2);
     }
     o.st(dx, at.off, at.i);
-    if (ACT == 2) dv.st(dres, at.off, at.i);
   }
 }
 
@@ -951,7 +956,7 @@ int sa_bn_bwd_act(int dtype, const void *dy, const void *x, const void *y,
       BN_ACT_SWITCH(act, {
         hipLaunchKernelGGL((bn_bwd_stats_kernel<T, 4, ACT>), grid, block, 0, s,
                            (const T *)dy, (const T *)x, (const T *)y, scale,
-                           bias, mean, invstd, work, N, C, HW, S);
+                           bias, mean, invstd, work, (T *)dres, N, C, HW, S);
         hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4, ACT>), grid, block, 0, s,
                            (const T *)dy, (const T *)x, (const T *)y, scale,
                            bias, mean, invstd, (T *)dx, (T *)dres, dscale,
@@ -965,7 +970,7 @@ int sa_bn_bwd_act(int dtype, const void *dy, const void *x, const void *y,
     BN_ACT_SWITCH(act, {
       hipLaunchKernelGGL((bn_bwd_stats_kernel<T, 1, ACT>), grid, block, 0, s,
                          (const T *)dy, (const T *)x, (const T *)y, scale, bias,
-                         mean, invstd, work, N, C, HW, S);
+                         mean, invstd, work, (T *)dres, N, C, HW, S);
       hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 1, ACT>), grid, block, 0, s,
                          (const T *)dy, (const T *)x, (const T *)y, scale, bias,
                          mean, invstd, (T *)dx, (T *)dres, dscale, dbias, work,

@@ -30,7 +30,7 @@ run rbm python examples/rbm/train.py --use_gpu -m 1 --hdim 64
 run onnx_train python examples/onnx/training/train.py --self-export -m 1 -b 8 --max-batches 3
 run onnx_selftest python examples/onnx/text_models.py self-test
 run largedata python examples/largedataset_cnn/train_largedata.py cnn --synthetic -m 1 -b 16
-run hfl python examples/hfl/run_local.py
+run hfl python examples/hfl/run_local.py --num_clients 2 -m 2 --port 15411
 run cpp_cnn singa_amd/bin/singa_cnn -epoch 1
 run cpp_cnn_opencl singa_amd/bin/singa_cnn -epoch 1 -opencl
 run cpp_cnn_parallel singa_amd/bin/singa_cnn_parallel -epoch 1 -replicas 1
@@ -58,4 +58,6 @@ run onnx_bert_squad python examples/onnx/bert/bert-squad.py
 run onnx_gpt2 python examples/onnx/gpt2/gpt2.py --length 5
 run onnx_roberta python examples/onnx/ro_bert_a/ro_bert_a.py
 run model_selection env PYTHONPATH=examples/model_selection:. python -m trails.run_ms --budget 15
+run model_selection_scores python examples/model_selection/exps/score_correlation.py --archs 4 --epochs 1 --rows 256 --gpu
+run model_selection_slicing python examples/model_selection/slicing/baseline_int.py --rows 512 --epochs 1 --repeat 3
 echo ALL-EXAMPLES-OK

@@ -5,7 +5,11 @@
 # produced by examples/cifar_distributed_cnn/benchmark.py:34-92).
 #
 #   tools/run_scaling.sh [--steps K] [--warmup W] [--dtype fp32|fp16|bf16]
-#                        [--out DIR] [--max-gpus N]
+#                        [--out DIR] [--max-gpus N] [--two-phase ELEMENTS]
+#
+# --two-phase E sums buckets of at least E elements as reduce-scatter +
+# all-gather (every slice over its own xGMI link) instead of one all-reduce;
+# run the script once with and once without to see which this node prefers.
 #
 # One process per GPU, started by torch.distributed.run BEFORE anything touches
 # a GPU (the launcher itself never initialises HIP).  Every N that the node
@@ -22,6 +26,7 @@ while [ $# -gt 0 ]; do
     --dtype) DTYPE=$2; shift 2;;
     --out) OUT=$2; shift 2;;
     --max-gpus) MAXG=$2; shift 2;;
+    --two-phase) export SINGA_ALLREDUCE_TWO_PHASE=$2; shift 2;;
     *) echo "unknown argument $1" >&2; exit 2;;
   esac
 done

@@ -60,8 +60,11 @@ def test_fault_plan_parsing():
 
 @pytest.mark.parametrize("graph", [0, 1])
 def test_healthy_job_is_left_alone(graph):
+    # generous limits: on a busy machine a heartbeat thread may not run for
+    # a second or two
     rc0, rc1, out, _ = _run({"SINGA_HEARTBEAT": "0.2",
-                             "SINGA_PROGRESS_TIMEOUT": "20"}, steps=6,
+                             "SINGA_HEARTBEAT_TIMEOUT": "30",
+                             "SINGA_PROGRESS_TIMEOUT": "60"}, steps=6,
                             graph=graph)
     assert (rc0, rc1) == (0, 0), out
     # the step counter advances once per iteration, eager or replayed

@@ -105,7 +105,12 @@ def build_model(name, num_channels, num_classes, data_size):
 
 def run(global_rank, world_size, local_rank, max_epoch, batch_size, model,
         data, sgd, graph, verbosity, dist_option="plain", spars=None,
-        precision="float32", max_batches=None):
+        precision="float32", max_batches=None, checkpoint_dir=None,
+        checkpoint_every=1):
+    """``checkpoint_dir``: write a checkpoint there every
+    ``checkpoint_every`` epochs (model, optimizer state, epoch) and, when one
+    is already present, continue from the newest instead of starting over --
+    what a job restarted by tools/launch_restart.py needs."""
     dev = create_device(local_rank)
     dev.SetRandSeed(0)
     np.random.seed(0)
@@ -150,8 +155,20 @@ def run(global_rank, world_size, local_rank, max_epoch, batch_size, model,
     reducer = tensor.Tensor((1,), dev, tensor.float32) if DIST else None
 
     history = []
-    for epoch in range(max_epoch):
+    first_epoch, manager = 0, None
+    if checkpoint_dir:
+        from singa_amd.utils.checkpoint import CheckpointManager
+        manager = CheckpointManager(checkpoint_dir, keep=2, rank=global_rank)
+        resumed = manager.restore(model, sgd)
+        if resumed:
+            first_epoch = int(resumed.get("epoch", -1)) + 1
+            if global_rank == 0:
+                print("Resuming after epoch %d (checkpoint of step %d)" %
+                      (first_epoch - 1, resumed["step"]), flush=True)
+    for epoch in range(first_epoch, max_epoch):
         start_time = time.time()
+        if manager is not None:
+            np.random.seed(epoch)    # the same order whether resumed or not
         np.random.shuffle(idx)
         if global_rank == 0:
             print("Starting Epoch %d:" % epoch)
@@ -199,6 +216,11 @@ def run(global_rank, world_size, local_rank, max_epoch, batch_size, model,
                   flush=True)
         history.append((float(train_loss), float(train_correct / seen),
                         float(test_correct / val_seen)))
+        if manager is not None and ((epoch + 1) % checkpoint_every == 0 or
+                                    epoch + 1 == max_epoch):
+            manager.save(model, (epoch + 1) * num_train_batch, sgd,
+                         {"epoch": epoch,
+                          "val_accuracy": float(test_correct / val_seen)})
 
     dev.PrintTimeProfiling()
     return history
@@ -224,6 +246,12 @@ def add_common_args(parser):
                         dest="verbosity")
     parser.add_argument("--max-batches", default=None, type=int,
                         help="cap on batches per epoch (smoke runs)")
+    parser.add_argument("--checkpoint-dir", default=None, dest="checkpoint_dir",
+                        help="checkpoint every --checkpoint-every epochs into "
+                             "this directory; continue from the newest one "
+                             "found there")
+    parser.add_argument("--checkpoint-every", default=1, type=int,
+                        dest="checkpoint_every")
     return parser
 
 
@@ -237,4 +265,5 @@ if __name__ == "__main__":
                   dtype=singa_dtype[args.precision])
     run(0, 1, args.device_id, args.max_epoch, args.batch_size, args.model,
         args.data, sgd, args.graph, args.verbosity, precision=args.precision,
-        max_batches=args.max_batches)
+        max_batches=args.max_batches, checkpoint_dir=args.checkpoint_dir,
+        checkpoint_every=args.checkpoint_every)

@@ -35,4 +35,6 @@ if __name__ == "__main__":
     train_cnn.run(sgd.global_rank, sgd.world_size, sgd.local_rank,
                   args.max_epoch, args.batch_size, args.model, args.data, sgd,
                   graph, args.verbosity, args.dist_option, args.spars,
-                  args.precision, max_batches=args.max_batches)
+                  args.precision, max_batches=args.max_batches,
+                  checkpoint_dir=args.checkpoint_dir,
+                  checkpoint_every=args.checkpoint_every)

@@ -1204,7 +1204,10 @@ class BinaryCrossEntropy(Operator):
     def backward(self, dy=1.0):
         dx = singa.__div__(self.t, self.x)
         negt = singa.AddFloat(self.t, -1.0)
-        negx = singa.AddFloat(self.x, -0.9999)
+        # d/dx log(1.0001 - x) = 1 / (x - 1.0001), and self.x is x + 0.0001
+        # (the reference subtracts 0.9999, python/singa/autograd.py:1197,
+        # which is off by 3e-4 in the denominator)
+        negx = singa.AddFloat(self.x, -1.0002)
         dx = singa.__sub__(dx, singa.__div__(negt, negx))
         dx = singa.MultFloat(dx, float(-1.0 / self.x.shape()[0]))
         return _apply_dy(dx, dy)

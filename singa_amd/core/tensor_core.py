@@ -1347,6 +1347,17 @@ def SGDUpdate(p, g, buf, lr, momentum, dampening, weight_decay, nesterov,
     return p
 
 
+def _one_device(what, dev, tensors):
+    """Fused multi-tensor kernels take raw addresses: a tensor of another
+    device (optimizer state read from a checkpoint and left on the host) must
+    stop here, not inside the kernel."""
+    for i, t in enumerate(tensors):
+        if t._dev is not dev:
+            raise ValueError(
+                "%s: operand %d lives on another device than the parameters"
+                % (what, i))
+
+
 def SGDUpdateMulti(params, grads, bufs, lr, momentum, dampening, weight_decay,
                    nesterov, scale=1.0, masters=None):
     """The fused SGD step for a whole list of parameters as ONE graph node
@@ -1381,6 +1392,7 @@ def SGDUpdateMulti(params, grads, bufs, lr, momentum, dampening, weight_decay,
     reads = list(params) + list(grads) + bufs + masters + [
         lr, momentum, dampening, weight_decay]
     writes = list(params) + bufs + masters
+    _one_device("SGDUpdateMulti", params[0]._dev, reads)
     _submit(params[0]._dev, "SGDUpdateMulti", body, reads, writes)
     return params
 
@@ -1417,6 +1429,7 @@ def AdaptiveUpdateMulti(rule, params, grads, state1, state2, hypers,
 
     reads = list(params) + list(grads) + list(state1) + state2 + hyp
     writes = list(params) + list(state1) + state2
+    _one_device("AdaptiveUpdateMulti", params[0]._dev, reads)
     _submit(params[0]._dev, "AdaptiveUpdateMulti", body, reads, writes)
     return params
 

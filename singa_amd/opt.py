@@ -169,6 +169,19 @@ class Optimizer(object):
                 s.set_value(0.0)
                 return s
             t = table[key] = _eagerly(like.device, make)
+        else:
+            # a slot adopted from a checkpoint (set_states before the first
+            # step) was created wherever the file was read -- the host -- and
+            # in the type it was saved in: it follows the parameter before a
+            # kernel is handed its address
+            want = like.dtype if dtype is None else dtype
+            if t.device.id() != like.device.id() or t.dtype != want:
+                def adopt():
+                    moved = t if t.dtype == want else t.as_type(want)
+                    if moved.device.id() != like.device.id():
+                        moved.to_device(like.device)
+                    return moved
+                t = table[key] = _eagerly(like.device, adopt)
         return t
 
     @staticmethod

@@ -116,3 +116,119 @@ def test_launcher_gives_up(tmp_path):
         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
         timeout=60)
     assert p.returncode == 1 and "giving up after 2 attempts" in p.stdout
+
+
+def test_restored_state_follows_the_parameters_device():
+    """State read from a checkpoint is created on the host; the first step
+    moves it to where the parameter lives (a kernel must never be handed a
+    host address), and the fused update refuses operands of two devices."""
+    from singa_amd import device, opt, tensor
+    from singa_amd.core import device as core_device
+    from singa_amd.core import tensor_core
+
+    host = device.get_default_device()
+    other = core_device.CppCPU()        # stands in for a GPU: its own id
+    other.id = lambda: 7
+    p = tensor.from_numpy(np.ones((3, 4), np.float32), other)
+    g = tensor.from_numpy(np.full((3, 4), .5, np.float32), other)
+    for make, table in ((lambda: opt.SGD(lr=.1, momentum=.9), "moments"),
+                        (lambda: opt.AdaGrad(lr=.1), "history")):
+        o = make()
+        table = table if hasattr(o, table) else o.state_names[0]
+        o.set_states({"step_counter": 3, table: {
+            "w": tensor.from_numpy(np.full((3, 4), 2, np.float16), host)}})
+        q = p.clone()
+        o.apply("w", q, g)
+        adopted = getattr(o, table)["w"]
+        assert adopted.data._dev is other and adopted.device.id() == 7
+        assert adopted.dtype == tensor.float32
+    np.testing.assert_allclose(
+        tensor.to_numpy(opt_step_sgd(p, g, other)), 0.77, rtol=1e-6)
+    stray = tensor.from_numpy(np.zeros((3, 4), np.float32), host)
+    o = opt.SGD(lr=.1, momentum=.9)
+    o.device_check(p, o.step_counter, *o._values())
+    with pytest.raises(ValueError, match="operand 2 lives on another device"):
+        tensor_core.SGDUpdateMulti(
+            [p.data], [g.data], [stray.data], o.lr_value.data,
+            o.mom_value.data, o.dam_value.data, o.decay_value.data, False)
+
+
+def opt_step_sgd(p, g, dev):
+    from singa_amd import device, opt, tensor
+    o = opt.SGD(lr=.1, momentum=.9)
+    o.set_states({"step_counter": 0, "moments": {"w": tensor.from_numpy(
+        np.full((3, 4), 2, np.float32), device.get_default_device())}})
+    q = p.clone()
+    o.apply("w", q, g)
+    return q
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["float32", "float16"])
+def test_resume_under_graph_replay_on_the_gpu(tmp_path, precision):
+    """Recorded (hipGraph) training with momentum and, for fp16, float32
+    master weights: six steps in one go equal three steps, a checkpoint, a
+    fresh process-like model restored from it, and three more steps."""
+    from singa_amd import device, layer, model, opt, tensor
+    from singa_amd.utils.checkpoint import CheckpointManager
+
+    class Net(model.Model):
+        def __init__(self):
+            super(Net, self).__init__()
+            self.conv = layer.Conv2d(8, 3, padding=1)
+            self.bn = layer.BatchNorm2d()
+            self.relu = layer.ReLU()
+            self.flat = layer.Flatten()
+            self.fc = layer.Linear(4)
+            self.loss = layer.SoftMaxCrossEntropy()
+
+        def forward(self, x):
+            return self.fc(self.flat(self.relu(self.bn(self.conv(x)))))
+
+        def train_one_batch(self, x, y):
+            out = self.forward(x)
+            loss = self.loss(out, y)
+            self.optimizer(loss)
+            return out, loss
+
+        def set_optimizer(self, o):
+            self.optimizer = o
+
+    dev = device.create_cuda_gpu()
+    dt = {"float32": tensor.float32, "float16": tensor.float16}[precision]
+    rs = np.random.RandomState(3)
+    xs = [rs.randn(8, 3, 8, 8).astype(np.float32) for _ in range(6)]
+    ys = [rs.randint(0, 4, 8).astype(np.int32) for _ in range(6)]
+    tx = tensor.Tensor((8, 3, 8, 8), dev, dt)
+    ty = tensor.Tensor((8,), dev, tensor.int32)
+
+    def fresh():
+        dev.SetRandSeed(11)
+        m = Net()
+        sgd = opt.SGD(lr=0.05, momentum=0.9, dtype=dt)
+        m.set_optimizer(sgd)
+        m.compile([tx], is_train=True, use_graph=True, sequential=False)
+        return m, sgd
+
+    def steps(m, lo, hi):
+        for i in range(lo, hi):
+            tx.copy_from_numpy(xs[i].astype(np.float16 if precision ==
+                                            "float16" else np.float32))
+            ty.copy_from_numpy(ys[i])
+            m(tx, ty)
+
+    m, sgd = fresh()
+    steps(m, 0, 6)
+    want = {k: tensor.to_numpy(v).astype(np.float32)
+            for k, v in m.get_states().items()}
+    m1, sgd1 = fresh()
+    steps(m1, 0, 3)
+    man = CheckpointManager(str(tmp_path / "g"))
+    man.save(m1, 3, sgd1)
+    m2, sgd2 = fresh()
+    assert man.restore(m2, sgd2)["step"] == 3
+    steps(m2, 3, 6)
+    tol = 2e-3 if precision == "float16" else 1e-5
+    for k, v in m2.get_states().items():
+        np.testing.assert_allclose(tensor.to_numpy(v).astype(np.float32),
+                                   want[k], rtol=tol, atol=tol, err_msg=k)

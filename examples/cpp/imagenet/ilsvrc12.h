@@ -38,6 +38,7 @@ class ILSVRC {
       : image_size_(image_size), crop_size_(crop_size) {
     CHECK_LE(crop_size, image_size);
     EncoderConf ec;
+    ec.type = "jpg";  // plain JPEG files, the label in a comment segment
     ec.image_dim_order = "CHW";
     encoder_.Setup(ec);
   }

@@ -18,13 +18,9 @@
 #include <utility>
 #include <vector>
 
-namespace singa {
+#include "../model/conf.h"
 
-struct MemPoolConf {
-  size_t init_size_mb = 256;  // first slab requested from the driver
-  size_t max_size_mb = 0;     // 0 = unlimited
-  int flag = 0;
-};
+namespace singa {
 
 class DeviceMemPool {
  public:

@@ -2,21 +2,18 @@
 // strings stored in record files and back.  CSV keeps one text line per
 // sample; the image codec stores 8-bit images as binary PPM / PGM with the
 // label in a comment line; the JPG codec stores baseline JPEG files with the
-// label in a COM segment (own codec, io/jpeg.h: no image library is linked,
-// where the reference's JPGEncoder/Decoder need OpenCV).  Records of both
-// image codecs are ordinary image files.  API parity: reference
+// label in a COM segment, or the reference's ImageRecord message around such
+// a file (own codec, io/jpeg.h: no image library is linked, where the
+// reference's JPGEncoder/Decoder need OpenCV).  API parity: reference
 // include/singa/io/{encoder,decoder}.h.
 #pragma once
 #include <string>
 #include <vector>
 
 #include "../core/tensor.h"
+#include "../model/conf.h"
 
 namespace singa {
-
-struct EncoderConf { std::string type = "csv"; std::string image_dim_order = "HWC"; };
-struct DecoderConf { std::string type = "csv"; bool has_label = true;
-                     std::string image_dim_order = "CHW"; };
 
 class Encoder {
  public:
@@ -70,14 +67,28 @@ class ImageDecoder : public Decoder {
 
 /// uint8 image tensor (HWC or CHW, 1 or 3 channels) <-> baseline JPEG bytes
 /// (reference JPGEncoder / JPGDecoder, src/io/jpg_{encoder,decoder}.cc).
+/// Two record formats:
+///   * "jpg2proto" (EncoderConf's default type): the reference's record, an
+///     ImageRecord message (src/proto/io.proto:55) holding the tensor's
+///     extents, the label and the JPEG file.  The reference hands the tensor's
+///     channels to OpenCV as blue, green, red, so channel 0 of a colour image
+///     is the file's blue plane; files written by either side read back the
+///     same tensors on the other.
+///   * "jpg": the JPEG file itself, channel 0 red, the label in a comment
+///     segment; such a record opens in any image viewer.
+/// The decoder tells the two apart by the JPEG start marker.
 class JPGEncoder : public Encoder {
  public:
-  void Setup(const EncoderConf &conf) override { order_ = conf.image_dim_order; }
+  void Setup(const EncoderConf &conf) override {
+    order_ = conf.image_dim_order;
+    proto_ = conf.type != "jpg" && conf.type != "jpeg";
+  }
   std::string Encode(std::vector<Tensor> &data) override;
   void set_quality(int q) { quality_ = q; }
 
  private:
   std::string order_ = "HWC";
+  bool proto_ = true;
   int quality_ = 100;  // the reference encodes at quality 100
 };
 

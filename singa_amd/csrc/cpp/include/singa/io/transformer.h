@@ -10,15 +10,6 @@
 
 namespace singa {
 
-struct TransformerConf {
-  bool featurewise_center = false, samplewise_center = false;
-  bool horizontal_mirror = false, vertical_mirror = false;
-  int resize_height = 0, resize_width = 0;
-  int crop_height = 0, crop_width = 0;
-  std::string image_dim_order = "CHW";
-  float rescale = 0.f;
-};
-
 class Transformer {
  public:
   virtual ~Transformer() {}

@@ -3,6 +3,7 @@
 // FillerConf, OptimizerConf, ...) as plain structs, so the C++ API has no
 // protobuf dependency; field names are the proto field names.
 #pragma once
+#include <cstddef>
 #include <string>
 #include <vector>
 
@@ -109,5 +110,46 @@ struct OptimizerConf {
 };
 
 struct MetricConf { int top_k = 1; };
+
+// ---- records of the data pipeline (reference src/proto/io.proto) -----------
+// `type` names the record format: "jpg2proto" / "proto2jpg" (the reference's
+// names) keep a JPEG file inside an ImageRecord message, "jpg" is the JPEG
+// file itself with the label in a comment segment.
+struct EncoderConf {
+  std::string type = "jpg2proto";
+  std::string image_dim_order = "HWC";
+};
+struct DecoderConf {
+  std::string type = "proto2jpg";
+  std::string image_dim_order = "CHW";
+  bool has_label = true;
+};
+struct TransformerConf {
+  bool featurewise_center = false, samplewise_center = false;
+  bool featurewise_std_norm = false, samplewise_std_norm = false;
+  bool zca_whitening = false;
+  int rotation_range = 0;
+  // the message's repeated `crop_shape` (height, width)
+  int crop_height = 0, crop_width = 0;
+  int resize_height = 0, resize_width = 0;
+  bool horizontal_mirror = false, vertical_mirror = false;
+  std::string image_dim_order = "CHW";
+  float rescale = 0.f;
+};
+/// One stored image: the extents of the tensor it was made from, its labels
+/// and the encoded pixels.
+struct ImageRecord {
+  std::vector<int> shape, label;
+  std::string pixel;
+};
+
+// ---- device memory pool (reference src/proto/core.proto:52-67) --------------
+struct MemPoolConf {
+  std::string type = "cnmem";   // kept for files written for the reference
+  size_t init_size_mb = 256;    // first slab requested from the driver
+  size_t max_size_mb = 0;       // 0 = unlimited
+  int flag = 0;
+  std::vector<int> device;
+};
 
 }  // namespace singa

@@ -46,6 +46,12 @@ SINGA_CONF_CODEC(ParamSpec)
 SINGA_CONF_CODEC(LayerConf)
 SINGA_CONF_CODEC(OptimizerConf)
 SINGA_CONF_CODEC(MetricConf)
+// src/proto/io.proto and the memory pool record of src/proto/core.proto
+SINGA_CONF_CODEC(EncoderConf)
+SINGA_CONF_CODEC(DecoderConf)
+SINGA_CONF_CODEC(TransformerConf)
+SINGA_CONF_CODEC(ImageRecord)
+SINGA_CONF_CODEC(MemPoolConf)
 #undef SINGA_CONF_CODEC
 
 /// Whole-file helpers: false when the file cannot be read or does not parse.

@@ -350,6 +350,16 @@ int64_t singa_conf_transcode(const char *message, int in_format,
           res = transcode<singa::ConstraintConf>(src, in_format, out_format);
         else if (name == "MetricConf")
           res = transcode<singa::MetricConf>(src, in_format, out_format);
+        else if (name == "EncoderConf")
+          res = transcode<singa::EncoderConf>(src, in_format, out_format);
+        else if (name == "DecoderConf")
+          res = transcode<singa::DecoderConf>(src, in_format, out_format);
+        else if (name == "TransformerConf")
+          res = transcode<singa::TransformerConf>(src, in_format, out_format);
+        else if (name == "ImageRecord")
+          res = transcode<singa::ImageRecord>(src, in_format, out_format);
+        else if (name == "MemPoolConf")
+          res = transcode<singa::MemPoolConf>(src, in_format, out_format);
         else
           throw std::invalid_argument("unknown message " + name);
         const int64_t n = (int64_t)res.size();

@@ -6,6 +6,7 @@
 #include "singa/io/encoder.h"
 #include "singa/io/jpeg.h"
 #include "singa/io/transformer.h"
+#include "singa/model/conf_proto.h"
 #include "singa/utils/string.h"
 
 namespace singa {
@@ -177,20 +178,49 @@ std::string JPGEncoder::Encode(std::vector<Tensor> &data) {
         hwc[(h * W + w) * C + c] = static_cast<uint8_t>(
             std::min(255.f, std::max(0.f, std::round(v))));
       }
-  std::string comment;
+  int label = 0;
   if (data.size() == 2)
-    comment = "label " + std::to_string(
-        data[1].Clone(defaultDevice).ToVector<int>().at(0));
-  return jpeg::Encode(hwc.data(), static_cast<int>(W), static_cast<int>(H),
-                      static_cast<int>(C), quality_, comment);
+    label = data[1].Clone(defaultDevice).ToVector<int>().at(0);
+  if (!proto_) {
+    std::string comment;
+    if (data.size() == 2) comment = "label " + std::to_string(label);
+    return jpeg::Encode(hwc.data(), static_cast<int>(W), static_cast<int>(H),
+                        static_cast<int>(C), quality_, comment);
+  }
+  // the reference's record: channel 0 is the file's blue plane
+  if (C == 3)
+    for (size_t i = 0; i < H * W; ++i) std::swap(hwc[3 * i], hwc[3 * i + 2]);
+  ImageRecord record;
+  for (size_t d = 0; d < img.nDim(); ++d)
+    record.shape.push_back(static_cast<int>(img.shape(d)));
+  if (data.size() == 2) record.label.push_back(label);
+  record.pixel = jpeg::Encode(hwc.data(), static_cast<int>(W),
+                              static_cast<int>(H), static_cast<int>(C),
+                              quality_, "");
+  return SerializeAsString(record);
 }
 
 std::vector<Tensor> JPGDecoder::Decode(std::string value) {
   std::vector<uint8_t> px8;
   int W = 0, H = 0, C = 0;
   std::string comment, error;
-  CHECK(jpeg::Decode(value, &px8, &W, &H, &C, &comment, &error))
+  const bool file = value.size() >= 2 && (unsigned char)value[0] == 0xff &&
+                    (unsigned char)value[1] == 0xd8;
+  ImageRecord record;
+  if (!file)
+    CHECK(ParseFromString(value, &record) && !record.pixel.empty())
+        << "neither a JPEG file nor an image record";
+  CHECK(jpeg::Decode(file ? value : record.pixel, &px8, &W, &H, &C, &comment,
+                     &error))
       << "JPEG record: " << error;
+  if (!file) {
+    if (C == 3)
+      for (size_t i = 0; i < px8.size() / 3; ++i)
+        std::swap(px8[3 * i], px8[3 * i + 2]);
+    comment = record.label.empty()
+                  ? std::string()
+                  : "label " + std::to_string(record.label[0]);
+  }
   const bool chw = order_ == "CHW";
   std::vector<float> px(px8.size());
   for (int h = 0; h < H; ++h)
@@ -217,7 +247,13 @@ std::shared_ptr<Encoder> CreateEncoder(const std::string &type) {
   std::string t = ToLowerCase(type);
   if (t == "csv") return std::make_shared<CSVEncoder>();
   if (t == "image" || t == "ppm") return std::make_shared<ImageEncoder>();
-  if (t == "jpg" || t == "jpeg") return std::make_shared<JPGEncoder>();
+  if (t == "jpg" || t == "jpeg" || t == "jpg2proto") {
+    auto enc = std::make_shared<JPGEncoder>();
+    EncoderConf conf;
+    conf.type = t;
+    enc->Setup(conf);
+    return enc;
+  }
   LOG(FATAL) << "Unknown encoder type " << type;
   return nullptr;
 }
@@ -226,7 +262,8 @@ std::shared_ptr<Decoder> CreateDecoder(const std::string &type) {
   std::string t = ToLowerCase(type);
   if (t == "csv") return std::make_shared<CSVDecoder>();
   if (t == "image" || t == "ppm") return std::make_shared<ImageDecoder>();
-  if (t == "jpg" || t == "jpeg") return std::make_shared<JPGDecoder>();
+  if (t == "jpg" || t == "jpeg" || t == "proto2jpg")
+    return std::make_shared<JPGDecoder>();
   LOG(FATAL) << "Unknown decoder type " << type;
   return nullptr;
 }

@@ -4,7 +4,9 @@
 // reader, text writer, text reader -- give the four codecs.  Field numbers,
 // names and defaults are those of the reference's src/proto/model.proto
 // (FillerConf :55, OptimizerConf :77, ParamSpec :117, LayerConf :156,
-// ConvolutionConf :338, RNNConf :398, DenseConf :603, PoolingConf :658, ...);
+// ConvolutionConf :338, RNNConf :398, DenseConf :603, PoolingConf :658, ...),
+// src/proto/io.proto (EncoderConf :23, DecoderConf :28, TransformerConf :34,
+// ImageRecord :55) and src/proto/core.proto (MemPoolConf :52);
 // the tables list fields in ascending number, the order protobuf writes.
 #include "singa/model/conf_proto.h"
 
@@ -186,6 +188,59 @@ template <class V> void Describe(V &v, LayerConf &c) {
   v.Msg(203, "split_conf", c.split_conf);
 }
 
+template <class V> void Describe(V &v, EncoderConf &c) {
+  v.Str(1, "type", c.type, "jpg2proto");
+  v.Str(2, "image_dim_order", c.image_dim_order, "HWC");
+}
+template <class V> void Describe(V &v, DecoderConf &c) {
+  v.Str(1, "type", c.type, "proto2jpg");
+  v.Str(2, "image_dim_order", c.image_dim_order, "CHW");
+  v.Bool(3, "has_label", c.has_label, true);
+}
+template <class V> void Describe(V &v, TransformerConf &c) {
+  v.Bool(1, "featurewise_center", c.featurewise_center, false);
+  v.Bool(2, "samplewise_center", c.samplewise_center, false);
+  v.Bool(3, "featurewise_std_norm", c.featurewise_std_norm, false);
+  v.Bool(4, "samplewise_std_norm", c.samplewise_std_norm, false);
+  v.Bool(5, "zca_whitening", c.zca_whitening, false);
+  v.I32(6, "rotation_range", c.rotation_range, 0);
+  // crop_shape = [height, width]; the record keeps the two numbers
+  std::vector<int> crop;
+  if (c.crop_height || c.crop_width) crop = {c.crop_height, c.crop_width};
+  const size_t before = crop.size();
+  v.PackedU32(7, "crop_shape", crop);
+  if (crop.size() > before) {  // a reader appended the values it met
+    const size_t n = crop.size() - before;
+    if (before == 0) {
+      c.crop_height = crop[0];
+      c.crop_width = n > 1 ? crop[1] : crop[0];
+    } else {  // a second occurrence continues the list
+      c.crop_width = crop[before];
+    }
+  }
+  v.I32(8, "resize_height", c.resize_height, 0);
+  v.I32(9, "resize_width", c.resize_width, 0);
+  v.Bool(10, "horizontal_mirror", c.horizontal_mirror, false);
+  v.Bool(11, "vertical_mirror", c.vertical_mirror, false);
+  v.Str(12, "image_dim_order", c.image_dim_order, "CHW");
+  v.F32(13, "rescale", c.rescale, 0.f);
+}
+template <class V> void Describe(V &v, ImageRecord &c) {
+  v.RepI32(1, "shape", c.shape);
+  v.RepI32(2, "label", c.label);
+  v.Str(3, "pixel", c.pixel, "");
+}
+template <class V> void Describe(V &v, MemPoolConf &c) {
+  v.Str(1, "type", c.type, "cnmem");
+  int init = (int)c.init_size_mb, max = (int)c.max_size_mb;
+  v.U32(2, "init_size", init, 256);
+  v.U32(3, "max_size", max, 0);
+  c.init_size_mb = (size_t)(uint32_t)init;
+  c.max_size_mb = (size_t)(uint32_t)max;
+  v.U32(11, "flag", c.flag, 0);
+  v.RepU32(12, "device", c.device);
+}
+
 // ---------------------------------------------------------------------------
 // wire format
 // ---------------------------------------------------------------------------
@@ -242,6 +297,15 @@ struct WireWriter {
   }
   void RepU32(int num, const char *, std::vector<int> &v) {
     for (int x : v) Int(num, (uint32_t)x);
+  }
+  void RepI32(int num, const char *, std::vector<int> &v) {
+    for (int x : v) Int(num, x);
+  }
+  void PackedU32(int num, const char *, std::vector<int> &v) {
+    if (v.empty()) return;
+    std::string body;
+    for (int x : v) PutVarint(&body, (uint32_t)x);
+    Bytes(num, body);
   }
   void Alias(int, const char *, const AliasSetter &) {}
   template <class Sub> void Msg(int num, const char *, Sub &sub) {
@@ -384,6 +448,12 @@ struct WireReader {
   void RepU32(int n, const char *, std::vector<int> &v) {
     Scalars(n, [&v](int x) { v.push_back(x); });
   }
+  void RepI32(int n, const char *, std::vector<int> &v) {
+    Scalars(n, [&v](int x) { v.push_back(x); });
+  }
+  void PackedU32(int n, const char *, std::vector<int> &v) {
+    Scalars(n, [&v](int x) { v.push_back(x); });
+  }
   void Alias(int n, const char *, const AliasSetter &set) {
     Scalars(n, [&](int x) { set(x, occurrences[n]++); });
   }
@@ -491,6 +561,12 @@ struct TextWriter {
   }
   void RepU32(int, const char *name, std::vector<int> &v) {
     for (int x : v) Line(name, std::to_string((uint32_t)x));
+  }
+  void RepI32(int, const char *name, std::vector<int> &v) {
+    for (int x : v) Line(name, std::to_string(x));
+  }
+  void PackedU32(int n, const char *name, std::vector<int> &v) {
+    RepU32(n, name, v);
   }
   void Alias(int, const char *, const AliasSetter &) {}
   template <class Sub> void Block(const char *name, Sub &sub, bool even_empty) {
@@ -807,12 +883,13 @@ struct TextReader {
     }
   }
   // one value, or a bracketed list
-  template <class F> void Scalars(const char *name, F &&each) {
+  template <class F>
+  void Scalars(const char *name, F &&each, int64_t lowest = 0) {
     if (!Mine(name) || !Colon()) return;
     auto one = [&] {
       int64_t x;
       if (!Integer(&x)) return false;
-      if (x < 0 || x > INT32_MAX) {
+      if (x < lowest || x > INT32_MAX) {
         lex->Fail("value of '" + key + "' is out of range");
         return false;
       }
@@ -831,6 +908,12 @@ struct TextReader {
     lex->Eat(']');
   }
   void RepU32(int, const char *name, std::vector<int> &v) {
+    Scalars(name, [&v](int x) { v.push_back(x); });
+  }
+  void RepI32(int, const char *name, std::vector<int> &v) {
+    Scalars(name, [&v](int x) { v.push_back(x); }, INT32_MIN);
+  }
+  void PackedU32(int, const char *name, std::vector<int> &v) {
     Scalars(name, [&v](int x) { v.push_back(x); });
   }
   void Alias(int, const char *name, const AliasSetter &set) {
@@ -921,6 +1004,11 @@ SINGA_CONF_CODEC_IMPL(ParamSpec)
 SINGA_CONF_CODEC_IMPL(LayerConf)
 SINGA_CONF_CODEC_IMPL(OptimizerConf)
 SINGA_CONF_CODEC_IMPL(MetricConf)
+SINGA_CONF_CODEC_IMPL(EncoderConf)
+SINGA_CONF_CODEC_IMPL(DecoderConf)
+SINGA_CONF_CODEC_IMPL(TransformerConf)
+SINGA_CONF_CODEC_IMPL(ImageRecord)
+SINGA_CONF_CODEC_IMPL(MemPoolConf)
 #undef SINGA_CONF_CODEC_IMPL
 
 bool ReadFileToString(const std::string &path, std::string *out) {

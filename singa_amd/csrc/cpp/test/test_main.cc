@@ -1234,6 +1234,7 @@ static void TestJpeg() {
   JPGEncoder enc;
   JPGDecoder dec;
   EncoderConf ec;
+  ec.type = "jpg";
   ec.image_dim_order = "HWC";
   enc.Setup(ec);
   DecoderConf dc;
@@ -1252,10 +1253,54 @@ static void TestJpeg() {
   for (size_t i = 0; i < px.size(); ++i)
     worst = std::max(worst, std::fabs(got[i] - std::round(px[i])));
   EXPECT(worst <= 3.f);
+  // the reference's record format: an ImageRecord message around the file,
+  // channel 0 stored as the file's blue plane; same tensors back
+  {
+    JPGEncoder penc;
+    EncoderConf pc;  // type "jpg2proto"
+    penc.Setup(pc);
+    std::string wire = penc.Encode(rec);
+    ImageRecord ir;
+    EXPECT(ParseFromString(wire, &ir));
+    EXPECT(ir.shape == (std::vector<int>{(int)H, (int)W, 3}) &&
+           ir.label == std::vector<int>{7});
+    EXPECT(ir.pixel.size() > 100 && (unsigned char)ir.pixel[0] == 0xff &&
+           (unsigned char)ir.pixel[1] == 0xd8);
+    std::vector<uint8_t> raw;
+    int rw = 0, rh = 0, rc = 0;
+    EXPECT(jpeg::Decode(ir.pixel, &raw, &rw, &rh, &rc) && rc == 3);
+    // pixel (0, W-1): channel 0 (255) sits in the file's blue plane, channel
+    // 2 (about 45) in its red plane
+    EXPECT(raw[(W - 1) * 3 + 2] >= 250 &&
+           std::abs((int)raw[(W - 1) * 3 + 0] - 45) <= 4);
+    auto pback = dec.Decode(wire);
+    EXPECT(pback.size() == 2 && pback[1].ToVector<int>()[0] == 7);
+    auto pgot = ToVec(pback[0]);
+    float pworst = 0.f;
+    for (size_t i = 0; i < px.size(); ++i)
+      pworst = std::max(pworst, std::fabs(pgot[i] - std::round(px[i])));
+    EXPECT(pworst <= 3.f);
+    // a record without a label, and one that is neither format
+    std::vector<Tensor> bare{rec[0]};
+    EXPECT(dec.Decode(penc.Encode(bare)).size() == 1);
+    bool refused = false;
+    try {
+      dec.Decode(std::string("\x08\x01\x10\x02", 4));
+    } catch (const std::exception &) {
+      refused = true;
+    }
+    EXPECT(refused);
+    EXPECT(CreateEncoder("jpg2proto") != nullptr &&
+           CreateDecoder("proto2jpg") != nullptr);
+  }
   // grey, CHW order, lower quality: smaller file, bounded error
   std::vector<float> grey(H * W);
   for (size_t i = 0; i < grey.size(); ++i) grey[i] = px[i * 3];
   JPGEncoder genc;
+  EncoderConf gc;
+  gc.type = "jpg";
+  gc.image_dim_order = "CHW";
+  genc.Setup(gc);
   genc.set_quality(75);
   std::vector<Tensor> grec{FromVec(grey, {H, W}, defaultDevice)};
   std::string gbytes = genc.Encode(grec);
@@ -1339,6 +1384,7 @@ static int JpegTool(int argc, char **argv) {
   DecoderConf dc;
   dc.image_dim_order = "HWC";
   EncoderConf ec;
+  ec.type = "jpg";
   ec.image_dim_order = "HWC";
   if (mode == "--jpeg-bench") {  // --jpeg-bench in.jpg <repeats>
     const std::string data = slurp(argv[2]);
@@ -1364,6 +1410,7 @@ static int JpegTool(int argc, char **argv) {
   ppm.Setup(dc);
   auto t = ppm.Decode(slurp(argv[2]));
   JPGEncoder enc;
+  if (mode == "--jpeg-record") ec.type = "jpg2proto";  // the reference's record
   enc.Setup(ec);
   if (argc > 4) enc.set_quality(std::atoi(argv[4]));
   return spill(argv[3], enc.Encode(t)) ? 0 : 1;

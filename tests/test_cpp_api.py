@@ -136,6 +136,65 @@ def test_jpeg_decoder_restart_markers_and_grey(tmp_path):
     assert mine.shape == ref.shape and np.abs(mine - ref).max() <= 2
 
 
+def _varint(n):
+    n &= (1 << 64) - 1
+    out = bytearray()
+    while n >= 0x80:
+        out.append((n & 0x7f) | 0x80)
+        n >>= 7
+    out.append(n)
+    return bytes(out)
+
+
+def test_image_records_of_the_reference_format(tmp_path):
+    """The reference stores an image as an ImageRecord message (shape = 1,
+    label = 2, pixel = 3: a JPEG file, src/proto/io.proto:55-59) whose colour
+    planes are the tensor's channels taken as blue, green, red
+    (src/io/jpg_encoder.cc:38-48).  A record assembled here the way that
+    encoder does -- PIL writes the file -- decodes to the tensor, and a record
+    written by the encoder under test holds the mirrored planes."""
+    import io
+    import subprocess
+    import numpy as np
+    from PIL import Image
+    exe = _jpeg_tool()
+    img = _test_image()                       # H x W x 3, the tensor
+    jpg = io.BytesIO()
+    Image.fromarray(img[:, :, ::-1].copy()).save(jpg, "JPEG", quality=100,
+                                                  subsampling=0)
+    rec = b"".join(b"\x08" + _varint(d) for d in img.shape)
+    rec += b"\x10" + _varint(41)
+    rec += b"\x1a" + _varint(len(jpg.getvalue())) + jpg.getvalue()
+    path = str(tmp_path / "rec.bin")
+    open(path, "wb").write(rec)
+    ppm = str(tmp_path / "rec.ppm")
+    subprocess.run([exe, "--jpeg-decode", path, ppm], check=True, timeout=60)
+    assert b"# label 41" in open(ppm, "rb").read(64)
+    mine = np.asarray(Image.open(ppm).convert("RGB")).astype(np.int32)
+    assert mine.shape == img.shape
+    assert np.abs(mine - img.astype(np.int32)).max() <= 4
+    # the other direction
+    src = str(tmp_path / "src.ppm")
+    Image.fromarray(img).save(src)
+    out = str(tmp_path / "out.bin")
+    subprocess.run([exe, "--jpeg-record", src, out], check=True, timeout=60)
+    blob = open(out, "rb").read()
+    want_head = b"".join(b"\x08" + _varint(d) for d in img.shape) + b"\x1a"
+    assert blob.startswith(want_head)
+    at = len(want_head)
+    n = shift = 0
+    while True:
+        b = blob[at]
+        at += 1
+        n |= (b & 0x7f) << shift
+        shift += 7
+        if not b & 0x80:
+            break
+    assert at + n == len(blob) and blob[at:at + 2] == b"\xff\xd8"
+    planes = np.asarray(Image.open(io.BytesIO(blob[at:])).convert("RGB"))
+    assert np.abs(planes[:, :, ::-1].astype(np.int32) - img).max() <= 4
+
+
 @pytest.mark.parametrize("quality", [100, 75])
 def test_jpeg_encoder_read_by_pil(tmp_path, quality):
     """Files written by the encoder are valid baseline JPEGs for an

@@ -10,6 +10,7 @@ plain single-process run.
 """
 import faulthandler
 import os
+import re
 import subprocess
 import sys
 
@@ -61,9 +62,11 @@ def main():
     if "RANK" in os.environ:             # a rank started by the launcher
         print("  [%s] started" % os.environ["RANK"], flush=True)
         losses = train(True)
-        print("rank %s %s" % (os.environ["RANK"],
-                              " ".join("%.5f" % v for v in losses)),
-              flush=True)
+        # one write: the ranks share the log file, and print() would hand the
+        # text and the line break to it separately
+        sys.stdout.write("rank %s %s\n" % (
+            os.environ["RANK"], " ".join("%.5f" % v for v in losses)))
+        sys.stdout.flush()
         return 0
     env = dict(os.environ, SINGA_DIST_BACKEND="gloo", GLOO_SOCKET_IFNAME="lo")
     log = os.path.join(ROOT, "gpurun_out", "multirank_ranks.log")
@@ -79,8 +82,8 @@ def main():
     print(text[-3000:])
     if rc != 0:
         return 1
-    ranks = [[float(v) for v in line.split()[2:]]
-             for line in text.splitlines() if line.startswith("rank ")]
+    ranks = [[float(v) for v in m.group(1).split()] for m in re.finditer(
+        r"rank \d+((?: -?(?:\d+\.\d+|nan|inf))+)", text)]
     assert len(ranks) == NRANKS, ranks
     ref = train(False)
     print("single", " ".join("%.5f" % v for v in ref))

@@ -107,6 +107,9 @@ _CONV_FLAT_MAX_HW = int(os.environ.get("SINGA_CONV_FLAT_MAX_HW", "399"))
 _CONV_FLAT_MIN_HW_3X3 = int(os.environ.get("SINGA_CONV_FLAT_MIN_HW_3X3", "64"))
 _CONV_S2_GATHER = os.environ.get("SINGA_CONV_S2_GATHER", "1") != "0"
 _CONV_WGRAD_GEMM = os.environ.get("SINGA_CONV_WGRAD_GEMM", "1") != "0"
+# SINGA_LN_PARAM_ONE_LAUNCH=0: layer-norm parameter gradients through zeroed
+# float buffers and atomics, cast afterwards (five launches instead of one)
+_LN_PARAM_ONE_LAUNCH = os.environ.get("SINGA_LN_PARAM_ONE_LAUNCH", "1") != "0"
 # column sums (bias gradients) in one launch instead of fill + sum + convert
 _REDUCE_COLS_ONE_LAUNCH = os.environ.get("SINGA_REDUCE_COLS_ONE_LAUNCH",
                                          "1") != "0"
@@ -142,6 +145,18 @@ class HipMath(object):
         if not _REDUCE_COLS_ONE_LAUNCH:
             return False
         stream = self._s()
+        sums, tickets = self._zero_scratch()
+        return self.k.reduce_cols_fin(
+            _code(x), x.data_ptr(), out.data_ptr(),
+            0 if out.dtype == torch.float32 else 1, rows, cols,
+            sums.data_ptr(), sums.numel(), tickets.data_ptr(),
+            tickets.numel(), stream)
+
+    def _zero_scratch(self):
+        """(float sums, int tickets) of the current stream: buffers that hold
+        zeros between launches (every kernel that borrows them puts the zeros
+        back), one pair per stream so that concurrent launches never share."""
+        stream = self._s()
         scratch = self._cols_scratch.get(stream)
         if scratch is None:
             d = self.dev.torch_device
@@ -150,12 +165,7 @@ class HipMath(object):
                        torch.zeros(_COLS_SCRATCH // 16, dtype=torch.int32,
                                    device=d))
             self._cols_scratch[stream] = scratch
-        sums, tickets = scratch
-        return self.k.reduce_cols_fin(
-            _code(x), x.data_ptr(), out.data_ptr(),
-            0 if out.dtype == torch.float32 else 1, rows, cols,
-            sums.data_ptr(), sums.numel(), tickets.data_ptr(),
-            tickets.numel(), stream)
+        return scratch
 
     # ---- plumbing -----------------------------------------------------------
     def _s(self):
@@ -1576,6 +1586,25 @@ class HipMath(object):
         dy, x = self._contig(dy), self._contig(x)
         g = self._contig(gamma) if gamma is not None else None
         want = dgamma is not None
+        if want and _LN_PARAM_ONE_LAUNCH and not _DETERMINISTIC and \
+                dgamma.is_contiguous() and \
+                dbeta.is_contiguous() and dgamma.dtype == dbeta.dtype and \
+                dgamma.dtype in (torch.float32, x.dtype):
+            # dx, then both parameter gradients in one launch that writes
+            # them in their own type (no fill before, no cast behind)
+            self.k.layernorm_bwd(_code(x), dy.data_ptr(), x.data_ptr(),
+                                 g.data_ptr() if g is not None else 0,
+                                 mean.data_ptr(), rstd.data_ptr(),
+                                 dx.data_ptr(), 0, 0, rows, D, self._s())
+            sums, tickets = self._zero_scratch()
+            if self.k.layernorm_bwd_param(
+                    _code(x), dy.data_ptr(), x.data_ptr(), mean.data_ptr(),
+                    rstd.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                    0 if dgamma.dtype == torch.float32 else 1,
+                    sums.data_ptr(), sums.numel(), tickets.data_ptr(),
+                    tickets.numel(), rows, D, self._s()):
+                return
+            # scratch too small: the float path below repeats dx as well
         # the parameter gradients are accumulated in float
         fg = fb = None
         if want:

@@ -247,6 +247,22 @@ PYBIND11_MODULE(_hip, m) {
                            D, S(s)),
           "layernorm_bwd");
   });
+  // parameter gradients in one launch; false: scratch too small
+  m.def("layernorm_bwd_param", [](int dt, uintptr_t dy, uintptr_t x,
+                                  uintptr_t mean, uintptr_t rstd,
+                                  uintptr_t dgamma, uintptr_t dbeta,
+                                  int out_typed, uintptr_t sums,
+                                  int64_t sums_cap, uintptr_t tickets,
+                                  int64_t tickets_cap, int64_t rows, int D,
+                                  uintptr_t s) {
+    const int rc = sa_layernorm_bwd_param(
+        dt, CP(dy), CP(x), (const float *)CP(mean), (const float *)CP(rstd),
+        P(dgamma), P(dbeta), out_typed, (float *)P(sums), sums_cap,
+        (unsigned *)P(tickets), tickets_cap, rows, D, S(s));
+    if (rc == -3) return false;
+    check(rc, "layernorm_bwd_param");
+    return true;
+  });
   m.def("gelu_fwd", [](int dt, uintptr_t x, uintptr_t y, int64_t n,
                        uintptr_t s) {
     check(sa_gelu_fwd(dt, CP(x), P(y), n, S(s)), "gelu_fwd");

@@ -168,6 +168,12 @@ int sa_layernorm_bwd(int dtype, const void *dy, const void *x,
                      const void *gamma, const float *mean, const float *rstd,
                      void *dx, float *dgamma, float *dbeta, int64_t rows, int D,
                      hipStream_t s);
+int sa_layernorm_bwd_param(int dtype, const void *dy, const void *x,
+                           const float *mean, const float *rstd, void *dgamma,
+                           void *dbeta, int out_typed, float *sums,
+                           int64_t sums_cap, unsigned *tickets,
+                           int64_t tickets_cap, int64_t rows, int D,
+                           hipStream_t s);
 int sa_gelu_fwd(int dtype, const void *x, void *y, int64_t n, hipStream_t s);
 int sa_gelu_bwd(int dtype, const void *dy, const void *x, void *dx, int64_t n,
                 hipStream_t s);

@@ -159,6 +159,70 @@ __global__ void layernorm_bwd_param_kernel(const T *__restrict__ dy,
   }
 }
 
+// The same sums in ONE launch with outputs of any float type: the row slices
+// of a column block meet in `sums` (2 * D floats: gamma's, then beta's) through
+// atomics, the slice that draws the last ticket of its column block swaps the
+// totals out -- zeros in -- and writes them in the outputs' type.  `sums` and
+// `tickets` hold zeros before and after the launch, so there is no fill pass
+// before it and no conversion pass behind it.  The scratch is only touched
+// with atomics, which are performed where the chip's L2 caches meet; a thread
+// has the value its add returned, i.e. the add is done, before the workgroup
+// draws its ticket.
+template <typename T, typename O>
+__global__ void layernorm_bwd_param_fin_kernel(
+    const T *__restrict__ dy, const T *__restrict__ x,
+    const float *__restrict__ mean, const float *__restrict__ rstd,
+    O *__restrict__ dgamma, O *__restrict__ dbeta, float *__restrict__ sums,
+    unsigned *__restrict__ tickets, int64_t rows, int D) {
+  __shared__ float sg[8][33], sb[8][33];
+  __shared__ int is_last;
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cx;
+  float ag = 0.f, ab = 0.f;
+  if (c < D) {
+    for (int64_t r = (int64_t)blockIdx.y * 8 + ry; r < rows;
+         r += (int64_t)gridDim.y * 8) {
+      const float d = to_f<T>(dy[r * D + c]);
+      ag += d * (to_f<T>(x[r * D + c]) - mean[r]) * rstd[r];
+      ab += d;
+    }
+  }
+  sg[ry][cx] = ag;
+  sb[ry][cx] = ab;
+  __syncthreads();
+  const bool mine = ry == 0 && c < D;
+  float tg = 0.f, tb = 0.f;
+  if (mine) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      tg += sg[k][cx];
+      tb += sb[k][cx];
+    }
+  }
+  if (gridDim.y == 1) {
+    if (mine) {
+      dgamma[c] = from_f<O>(tg);
+      dbeta[c] = from_f<O>(tb);
+    }
+    return;
+  }
+  if (mine) {
+    const float b0 = atomicAdd(sums + c, tg);
+    const float b1 = atomicAdd(sums + D + c, tb);
+    asm volatile("" ::"v"(b0), "v"(b1) : "memory");
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    is_last = atomicAdd(tickets + blockIdx.x, 1u) == gridDim.y - 1;
+  __syncthreads();
+  if (!is_last) return;
+  if (mine) {
+    dgamma[c] = from_f<O>(atomicExch(sums + c, 0.f));
+    dbeta[c] = from_f<O>(atomicExch(sums + D + c, 0.f));
+  }
+  if (threadIdx.x == 0) atomicExch(tickets + blockIdx.x, 0u);
+}
+
 // ---- one wave per row ------------------------------------------------------
 // Rows of up to 2048 elements (a multiple of 4): the 64 lanes of a wave keep the
 // row in registers as NV groups of four consecutive elements (8- or 16-byte
@@ -435,6 +499,40 @@ int sa_layernorm_bwd(int dtype, const void *dy, const void *x,
     }
   });
   return 0;
+}
+
+// Parameter gradients only, one launch.  dgamma / dbeta: D elements of the
+// inputs' type (out_typed != 0) or float; sums (>= 2 * D floats) and tickets
+// (>= ceil(D / 32) counters) hold zeros before and after.  -3: the scratch is
+// too small (the caller uses sa_layernorm_bwd's float outputs).
+int sa_layernorm_bwd_param(int dtype, const void *dy, const void *x,
+                           const float *mean, const float *rstd, void *dgamma,
+                           void *dbeta, int out_typed, float *sums,
+                           int64_t sums_cap, unsigned *tickets,
+                           int64_t tickets_cap, int64_t rows, int D,
+                           hipStream_t s) {
+  if (rows <= 0 || D <= 0) return 0;
+  if (rows >= ((int64_t)1 << 31)) return -2;
+  if (dgamma == nullptr || dbeta == nullptr) return -5;
+  const int gx = (D + 31) / 32;
+  int gy = (int)i64min(i64max(1024 / gx, 1), (rows + 63) / 64);
+  if (gy < 1) gy = 1;
+  if (gy > 1 && (sums == nullptr || tickets == nullptr ||
+                 2 * (int64_t)D > sums_cap || gx > tickets_cap))
+    return -3;
+  SA_DISPATCH_FLOAT(dtype, T, {
+    if (out_typed)
+      hipLaunchKernelGGL((layernorm_bwd_param_fin_kernel<T, T>), dim3(gx, gy),
+                         dim3(256), 0, s, (const T *)dy, (const T *)x, mean,
+                         rstd, (T *)dgamma, (T *)dbeta, sums, tickets, rows,
+                         D);
+    else
+      hipLaunchKernelGGL((layernorm_bwd_param_fin_kernel<T, float>),
+                         dim3(gx, gy), dim3(256), 0, s, (const T *)dy,
+                         (const T *)x, mean, rstd, (float *)dgamma,
+                         (float *)dbeta, sums, tickets, rows, D);
+  });
+  return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 static inline bool gelu_vec_ok(int64_t n, size_t elem,

@@ -1272,6 +1272,48 @@ def test_batchnorm_forward_from_producer_sums(maths, dt, N, C, HW, act):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("rows,D,float_out", [
+    (4099, 768, False), (2048, 100, True), (1500, 3072, False),
+    (700, 33000, False)])    # the last one exceeds the scratch: float path
+def test_layernorm_parameter_gradients_one_launch(maths, dt, rows, D,
+                                                  float_out):
+    """Row slices of the layer-norm parameter gradients meet in a scratch that
+    holds zeros between launches; the last slice of a column block writes the
+    totals in the outputs' type.  Reference: float64 sums on the same rounded
+    inputs; run twice (a scratch left dirty would show in the second run)."""
+    hm, cm, dev = maths
+    d = dev.torch_device
+    gen = torch.Generator().manual_seed(rows + D)
+    x = (torch.randn(rows, D, generator=gen) * 1.5 - 0.2).to(dt)
+    dy = (torch.randn(rows, D, generator=gen) * 0.1).to(dt)
+    gam = (torch.rand(D, generator=gen) + 0.5).to(dt)
+    y = torch.empty(rows, D, dtype=dt, device=d)
+    mean = torch.empty(rows, device=d)
+    rstd = torch.empty(rows, device=d)
+    xd, dyd, gd = x.to(d), dy.to(d), gam.to(d)
+    hm.layernorm_fwd(xd, gd, torch.zeros(D, dtype=dt, device=d), y, mean,
+                     rstd, 1e-5)
+    odt = torch.float32 if float_out else dt
+    x64, d64 = x.double(), dy.double()
+    xhat = (x64 - mean.cpu().double()[:, None]) * rstd.cpu().double()[:, None]
+    want_g = (d64 * xhat).sum(0).numpy()
+    want_b = d64.sum(0).numpy()
+    eps = {torch.float32: 1e-5, torch.float16: 1e-3, torch.bfloat16: 8e-3}[
+        odt if not float_out else torch.float32]
+    for _ in range(2):
+        dx = torch.empty(rows, D, dtype=dt, device=d)
+        dg = torch.full((D,), 7.0, dtype=odt, device=d)
+        db = torch.full((D,), 7.0, dtype=odt, device=d)
+        hm.layernorm_bwd(dyd, xd, gd, mean, rstd, dx, dg, db)
+        for got, want in ((dg, want_g), (db, want_b)):
+            np.testing.assert_allclose(
+                got.double().cpu().numpy(), want, rtol=4 * eps,
+                atol=4 * eps * max(1.0, float(np.abs(want).max())))
+    sums, tickets = hm._zero_scratch()
+    assert float(sums.abs().max()) == 0.0 and int(tickets.abs().max()) == 0
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("rows,D", [(9, 768), (5, 100), (3, 2048), (7, 1026),
                                     (4, 516), (2, 4096), (130, 64)])
 def test_layernorm_and_gelu_kernels_all_types(maths, dt, rows, D):

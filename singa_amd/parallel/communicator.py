@@ -266,6 +266,10 @@ class Communicator(object):
             limit = float(os.environ.get("SINGA_COLLECTIVE_TIMEOUT", "0") or 0)
             extra = {"timeout": datetime.timedelta(seconds=limit)} \
                 if limit > 0 else {}
+            if meet[0] in ("127.0.0.1", "localhost", "::1"):
+                # a one-machine job: gloo would look its interface up by the
+                # host name, which need not resolve inside a container
+                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             dist.init_process_group(
                 backend="gloo", init_method=init_method,
                 rank=self.global_rank, world_size=self.world_size, **extra)

@@ -104,7 +104,7 @@ class Layer {
     for (Tensor *p : param_ptrs()) p->ToDevice(device);
   }
   virtual void AsType(DataType dtype) {
-    for (Tensor *p : param_ptrs()) p->AsType(dtype);
+    for (Tensor *p : param_ptrs()) p->ToType(dtype);
   }
 
   virtual const std::vector<Tensor> param_values() {

@@ -36,6 +36,11 @@ class Constraint {
   std::string type_ = "l2";
   float threshold_ = 0.f;
 };
+/// Every type name gives the one constraint class (as in the reference,
+/// include/singa/model/optimizer.h:137-139).
+inline std::shared_ptr<Constraint> CreateConstraint(std::string /*type*/) {
+  return std::make_shared<Constraint>();
+}
 
 class Regularizer {
  public:
@@ -59,6 +64,11 @@ class Regularizer {
   std::string type_ = "l2";
   float coefficient_ = 0.f;
 };
+/// Every type name gives the one regularizer class (as in the reference,
+/// include/singa/model/optimizer.h:171-173).
+inline std::shared_ptr<Regularizer> CreateRegularizer(std::string /*type*/) {
+  return std::make_shared<Regularizer>();
+}
 
 class Optimizer {
  public:

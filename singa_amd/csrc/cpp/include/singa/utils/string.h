@@ -20,6 +20,15 @@ inline std::string ToLowerCase(const std::string &input) {
 }
 
 /// Index of `str` in argv (checked to have a following value), or -1.
+/// "[a, b, c]" (reference include/singa/utils/string.h, VecToStr).
+template <typename T>
+inline std::string VecToStr(const std::vector<T> &in) {
+  std::string out = "[";
+  for (size_t i = 0; i < in.size(); ++i)
+    out += (i ? ", " : "") + std::to_string(in[i]);
+  return out + "]";
+}
+
 inline int ArgPos(int argc, char **arglist, const char *str) {
   for (int i = 0; i < argc; i++) {
     if (!std::strcmp(str, arglist[i])) {

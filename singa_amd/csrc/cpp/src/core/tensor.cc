@@ -31,6 +31,26 @@ float cpu_unary(int op, float x, float a, float b) {
     case U_SQRT: return std::sqrt(x);
     case U_SQUARE: return x * x;
     case U_SIGN: return x > 0 ? 1.f : (x < 0 ? -1.f : 0.f);
+    case U_CEIL: return std::ceil(x);
+    case U_FLOOR: return std::floor(x);
+    case U_ROUND: return std::round(x);          // halves away from zero
+    case U_ROUNDE: return std::nearbyint(x);     // halves to even
+    case U_ERF: return std::erf(x);
+    case U_COS: return std::cos(x);
+    case U_COSH: return std::cosh(x);
+    case U_ACOS: return std::acos(x);
+    case U_ACOSH: return std::acosh(x);
+    case U_SIN: return std::sin(x);
+    case U_SINH: return std::sinh(x);
+    case U_ASIN: return std::asin(x);
+    case U_ASINH: return std::asinh(x);
+    case U_TAN: return std::tan(x);
+    case U_ATAN: return std::atan(x);
+    case U_ATANH: return std::atanh(x);
+    case U_SOFTPLUS: return std::log1p(std::exp(x));
+    case U_SOFTSIGN: return x / (1.f + std::fabs(x));
+    case U_MAX_S: return std::max(x, a);
+    case U_MIN_S: return std::min(x, a);
     case U_SIGMOID: return 1.f / (1.f + std::exp(-x));
     case U_TANH: return std::tanh(x);
     case U_RELU: return x > 0 ? x : 0.f;
@@ -310,9 +330,14 @@ void Tensor::ContiguousStrides() {
     stride_[i] = stride_[i + 1] * static_cast<int>(shape_[i + 1]);
 }
 
+// True for every view that is not row-major: permuted axes as well as
+// broadcast (stride 0) ones.  Extents of 1 do not count.
 bool Tensor::transpose() const {
-  for (size_t i = 1; i < stride_.size(); ++i)
-    if (stride_[i] > stride_[i - 1]) return true;
+  int64_t want = 1;
+  for (int i = static_cast<int>(shape_.size()) - 1; i >= 0; --i) {
+    if (shape_[i] != 1 && stride_[i] != want) return true;
+    want *= static_cast<int64_t>(shape_[i]);
+  }
   return false;
 }
 
@@ -340,11 +365,15 @@ Tensor &Tensor::ResetLike(const Tensor &t) {
   return *this;
 }
 
-Tensor &Tensor::AsType(DataType type) {
+Tensor Tensor::AsType(DataType type) const {
   if (type == data_type_) return *this;
   Tensor out(shape_, device_, type);
   if (initialized()) Unary(sa::U_COPY, Contiguous(), &out, 0, 0, "CastType");
-  *this = out;
+  return out;
+}
+
+Tensor &Tensor::ToType(DataType type) {
+  if (type != data_type_) *this = AsType(type);
   return *this;
 }
 
@@ -376,16 +405,77 @@ Tensor Tensor::T() const {
   return t;
 }
 
+Tensor &Tensor::Transpose() {
+  std::reverse(shape_.begin(), shape_.end());
+  std::reverse(stride_.begin(), stride_.end());
+  return *this;
+}
+
+Tensor &Tensor::Transpose(const std::vector<size_t> &axes) {
+  CHECK_EQ(axes.size(), shape_.size()) << "one axis per dimension";
+  Shape s(shape_.size());
+  std::vector<int> st(shape_.size());
+  std::vector<bool> seen(shape_.size(), false);
+  for (size_t i = 0; i < axes.size(); ++i) {
+    CHECK_LT(axes[i], shape_.size());
+    CHECK(!seen[axes[i]]) << "axis " << axes[i] << " named twice";
+    seen[axes[i]] = true;
+    s[i] = shape_[axes[i]];
+    st[i] = stride_[axes[i]];
+  }
+  shape_ = s;
+  stride_ = st;
+  return *this;
+}
+
+// Right-aligned broadcasting: an extent of 1 and every added leading axis
+// get stride 0.  The last `ignore_last_dim` axes keep their own extents (the
+// matrix axes of a batched product).
+Tensor &Tensor::Broadcast(const Shape &shape, int ignore_last_dim) {
+  const int m = static_cast<int>(shape_.size());
+  const int n = static_cast<int>(shape.size());
+  CHECK_GE(n, m) << "broadcasting never drops axes";
+  CHECK_GE(ignore_last_dim, 0);
+  Shape s(n);
+  std::vector<int> st(n);
+  for (int i = 0; i < n; ++i) {            // i counts from the right
+    const int to = n - 1 - i, from = m - 1 - i;
+    if (from < 0) {
+      s[to] = shape[to];
+      st[to] = 0;
+    } else if (i < ignore_last_dim || shape_[from] == shape[to]) {
+      s[to] = shape_[from];
+      st[to] = stride_[from];
+    } else {
+      CHECK_EQ(shape_[from], 1u)
+          << "extent " << shape_[from] << " does not broadcast to "
+          << shape[to];
+      s[to] = shape[to];
+      st[to] = 0;
+    }
+  }
+  shape_ = s;
+  stride_ = st;
+  return *this;
+}
+
 Tensor Tensor::Contiguous() const {
-  if (!transpose()) return *this;
-  CHECK_EQ(shape_.size(), 2u);
+  if (!transpose()) {
+    Tensor same(*this);
+    same.ContiguousStrides();   // extents of 1 may carry any stride
+    return same;
+  }
+  CHECK_LE(shape_.size(), 8u) << "views have at most 8 axes";
   Tensor out(shape_, device_, data_type_);
+  if (Size() == 0) return out;
   sa::Desc d;
-  d.ndim = 2;
-  d.shape[0] = shape_[0]; d.shape[1] = shape_[1];
-  d.s0[0] = stride_[0]; d.s0[1] = stride_[1];
-  d.s1[0] = d.s1[1] = 0;
-  d.s2[0] = shape_[1]; d.s2[1] = 1;
+  d.ndim = static_cast<int>(shape_.size());
+  for (int i = 0; i < d.ndim; ++i) {
+    d.shape[i] = static_cast<int64_t>(shape_[i]);
+    d.s0[i] = stride_[i];
+    d.s1[i] = 0;
+    d.s2[i] = out.stride_[i];
+  }
   Block *ib = block_, *ob = out.block();
   DataType t = data_type_;
   size_t n = Size();
@@ -393,11 +483,15 @@ Tensor Tensor::Contiguous() const {
     device_->Exec([=](Context *) {
       const char *x = static_cast<const char *>(ib->data());
       char *y = static_cast<char *>(ob->mutable_data());
-      size_t es = SizeOf(t);
-      for (int64_t r = 0; r < d.shape[0]; ++r)
-        for (int64_t c = 0; c < d.shape[1]; ++c)
-          std::memcpy(y + (r * d.s2[0] + c) * es,
-                      x + (r * d.s0[0] + c * d.s0[1]) * es, es);
+      const size_t es = SizeOf(t);
+      for (size_t i = 0; i < n; ++i) {
+        int64_t lin = static_cast<int64_t>(i), from = 0;
+        for (int k = d.ndim - 1; k >= 0; --k) {
+          from += (lin % d.shape[k]) * d.s0[k];
+          lin /= d.shape[k];
+        }
+        std::memcpy(y + i * es, x + from * es, es);
+      }
     }, {ib}, {ob}, "Contiguous");
   } else {
     device_->Exec([=](Context *ctx) {
@@ -410,6 +504,41 @@ Tensor Tensor::Contiguous() const {
                        static_cast<int64_t>(n), 0, 0, S(ctx)));
     }, {ib}, {ob}, "Contiguous");
   }
+  return out;
+}
+
+// Elements (or slices along `axis`) repeated: repeats holds one count for all
+// slices or one per slice; axis == Noaxis repeats the elements of the
+// flattened tensor.  Reference: Tensor::Repeat, src/core/tensor/tensor.cc.
+Tensor Tensor::Repeat(const std::vector<size_t> &repeats, int axis,
+                      std::shared_ptr<Device> device) const {
+  if (!device) device = device_;
+  CHECK(!repeats.empty());
+  Tensor src = Contiguous();
+  Shape s;
+  size_t total = 0;
+  if (axis == Noaxis) {
+    CHECK_EQ(repeats.size(), 1u) << "one count for the flattened tensor";
+    total = repeats[0] * Size();
+    s = Shape{total};
+  } else {
+    if (axis < 0) axis += static_cast<int>(nDim());
+    CHECK(axis >= 0 && axis < static_cast<int>(nDim())) << "no such axis";
+    CHECK(repeats.size() == 1 || repeats.size() == shape_[axis])
+        << "one count, or one per slice";
+    s = shape_;
+    if (repeats.size() == 1) {
+      s[axis] = shape_[axis] * repeats[0];
+    } else {
+      s[axis] = 0;
+      for (size_t r : repeats) s[axis] += r;
+    }
+    total = Product(s);
+  }
+  Tensor out(s, device_, data_type_);
+  if (total) RepeatDataToFrom(repeats.size() == 1, repeats, axis, &out, src,
+                              total);
+  if (device != device_) out.ToDevice(device);
   return out;
 }
 
@@ -556,6 +685,24 @@ SINGA_UNARY_DEF(Sign, sa::U_SIGN)
 SINGA_UNARY_DEF(Sqrt, sa::U_SQRT)
 SINGA_UNARY_DEF(Square, sa::U_SQUARE)
 SINGA_UNARY_DEF(Tanh, sa::U_TANH)
+SINGA_UNARY_DEF(Erf, sa::U_ERF)
+SINGA_UNARY_DEF(Ceil, sa::U_CEIL)
+SINGA_UNARY_DEF(Floor, sa::U_FLOOR)
+SINGA_UNARY_DEF(Round, sa::U_ROUND)
+SINGA_UNARY_DEF(RoundE, sa::U_ROUNDE)
+SINGA_UNARY_DEF(SoftPlus, sa::U_SOFTPLUS)
+SINGA_UNARY_DEF(SoftSign, sa::U_SOFTSIGN)
+SINGA_UNARY_DEF(Cos, sa::U_COS)
+SINGA_UNARY_DEF(Cosh, sa::U_COSH)
+SINGA_UNARY_DEF(Acos, sa::U_ACOS)
+SINGA_UNARY_DEF(Acosh, sa::U_ACOSH)
+SINGA_UNARY_DEF(Sin, sa::U_SIN)
+SINGA_UNARY_DEF(Sinh, sa::U_SINH)
+SINGA_UNARY_DEF(Asin, sa::U_ASIN)
+SINGA_UNARY_DEF(Asinh, sa::U_ASINH)
+SINGA_UNARY_DEF(Tan, sa::U_TAN)
+SINGA_UNARY_DEF(Atan, sa::U_ATAN)
+SINGA_UNARY_DEF(Atanh, sa::U_ATANH)
 #undef SINGA_UNARY_DEF
 
 #define SINGA_BINARY_DEF(opname, fn, code)                            \
@@ -1078,6 +1225,229 @@ Tensor SliceRows(const Tensor &in, size_t start, size_t end) {
 }
 Tensor CopyColumns(const Tensor &in, size_t start, size_t end) {
   return SliceOn(in, start, end, 1);
+}
+
+Tensor SliceColumns(const Tensor &in, size_t start, size_t end) {
+  return SliceOn(in, start, end, 1);
+}
+Tensor ConcatRows(const std::vector<Tensor> &in) { return ConcatOn(in, 0); }
+Tensor ConcatColumns(const std::vector<Tensor> &in) { return ConcatOn(in, 1); }
+
+// ---- views and copies as free functions ----------------------------------------------
+Tensor Contiguous(const Tensor &in) { return in.Contiguous(); }
+Tensor Transform(const Tensor &in) { return in.Contiguous(); }
+void Transform(const Tensor &in, Tensor *out) {
+  CHECK_EQ(in.Size(), out->Size());
+  out->CopyData(in.Contiguous());
+}
+Tensor Resize(const Tensor &in, const Shape &s) {
+  Tensor out(in);
+  out.Resize(s);
+  return out;
+}
+Tensor Transpose(const Tensor &in) {
+  Tensor out(in);
+  out.Transpose();
+  return out;
+}
+Tensor Transpose(const Tensor &in, const std::vector<size_t> &axes) {
+  Tensor out(in);
+  out.Transpose(axes);
+  return out;
+}
+Tensor Broadcast(const Tensor &in, const Shape &shape, int ignore_last_dim) {
+  Tensor out(in);
+  out.Broadcast(shape, ignore_last_dim);
+  return out;
+}
+
+// dst <- the elements (Noaxis) or the slices along `axis` of src, each
+// `repeats[i]` times (`broadcast_flag`: repeats[0] for all).  `num` is the
+// number of elements written.  Reference: RepeatDataToFrom,
+// src/core/tensor/tensor.cc.
+void RepeatDataToFrom(bool broadcast_flag, const std::vector<size_t> &repeats,
+                      int axis, Tensor *dst, const Tensor &src, size_t num) {
+  CHECK(!repeats.empty());
+  CHECK(!src.transpose() && !dst->transpose());
+  CHECK_EQ(src.data_type(), dst->data_type());
+  CHECK_GE(dst->Size(), num);
+  size_t outer = 1, slices = src.Size(), chunk = 1;
+  if (axis != Noaxis) {
+    if (axis < 0) axis += static_cast<int>(src.nDim());
+    CHECK(axis >= 0 && axis < static_cast<int>(src.nDim()));
+    for (int i = 0; i < axis; ++i) outer *= src.shape(i);
+    slices = src.shape(axis);
+    for (size_t i = axis + 1; i < src.nDim(); ++i) chunk *= src.shape(i);
+  }
+  if (!broadcast_flag) CHECK_EQ(repeats.size(), slices);
+  size_t at = 0;
+  for (size_t o = 0; o < outer; ++o)
+    for (size_t i = 0; i < slices; ++i) {
+      const size_t times = broadcast_flag ? repeats[0] : repeats[i];
+      for (size_t r = 0; r < times; ++r) {
+        CHECK_LE(at + chunk, num) << "more repeats than the destination holds";
+        CopyDataToFrom(dst, src, chunk, at, (o * slices + i) * chunk);
+        at += chunk;
+      }
+    }
+  CHECK_EQ(at, num);
+}
+
+// ---- comparisons, powers ----------------------------------------------------------
+#define SINGA_COMPARE_DEF(opname, fn, bcode, ucode)                    \
+  void fn(const Tensor &a, const Tensor &b, Tensor *out) {              \
+    Binary(bcode, a, b, out, #fn);                                      \
+  }                                                                     \
+  template <typename SType>                                             \
+  void fn(const Tensor &in, SType x, Tensor *out) {                     \
+    Unary(ucode, in, out, static_cast<float>(x), 0.f, #fn "Scalar");    \
+  }                                                                     \
+  template void fn<float>(const Tensor &, float, Tensor *);             \
+  template void fn<int>(const Tensor &, int, Tensor *);                 \
+  template void fn<double>(const Tensor &, double, Tensor *);
+SINGA_COMPARE_DEF(<, LT, sa::B_LT, sa::U_LT_S)
+SINGA_COMPARE_DEF(<=, LE, sa::B_LE, sa::U_LE_S)
+SINGA_COMPARE_DEF(>, GT, sa::B_GT, sa::U_GT_S)
+SINGA_COMPARE_DEF(>=, GE, sa::B_GE, sa::U_GE_S)
+SINGA_COMPARE_DEF(==, EQ, sa::B_EQ, sa::U_EQ_S)
+#undef SINGA_COMPARE_DEF
+
+Tensor operator<=(const Tensor &a, const Tensor &b) {
+  Tensor out(a.shape(), a.device(), a.data_type());
+  LE(a, b, &out);
+  return out;
+}
+Tensor operator>=(const Tensor &a, const Tensor &b) {
+  Tensor out(a.shape(), a.device(), a.data_type());
+  GE(a, b, &out);
+  return out;
+}
+Tensor operator==(const Tensor &a, const Tensor &b) {
+  Tensor out(a.shape(), a.device(), a.data_type());
+  EQ(a, b, &out);
+  return out;
+}
+template <typename SType>
+Tensor operator==(const Tensor &in, SType x) {
+  Tensor out(in.shape(), in.device(), in.data_type());
+  EQ(in, x, &out);
+  return out;
+}
+template Tensor operator==<float>(const Tensor &, float);
+template Tensor operator==<int>(const Tensor &, int);
+template Tensor operator==<double>(const Tensor &, double);
+
+void Pow(const Tensor &base, const Tensor &exp, Tensor *out) {
+  Binary(sa::B_POW, base, exp, out, "Pow");
+}
+Tensor Pow(const Tensor &base, const Tensor &exp) {
+  Tensor out(base.shape(), base.device(), base.data_type());
+  Pow(base, exp, &out);
+  return out;
+}
+template <typename SType>
+void Pow(const Tensor &in, SType x, Tensor *out) {
+  Unary(sa::U_POW_S, in, out, static_cast<float>(x), 0.f, "PowScalar");
+}
+template void Pow<float>(const Tensor &, float, Tensor *);
+template void Pow<int>(const Tensor &, int, Tensor *);
+template void Pow<double>(const Tensor &, double, Tensor *);
+
+void ReLUBackward(const Tensor &dy, const Tensor &x, Tensor *out) {
+  Binary(sa::B_RELU_BWD, dy, x, out, "ReLUBackward");
+}
+
+template <typename SType>
+void Sub(const Tensor &in, SType x, Tensor *out) {
+  Unary(sa::U_SUB_S, in, out, static_cast<float>(x), 0.f, "SubScalar");
+}
+template void Sub<float>(const Tensor &, float, Tensor *);
+template <typename SType>
+void Div(const Tensor &in, SType x, Tensor *out) {
+  Unary(sa::U_DIV_S, in, out, static_cast<float>(x), 0.f, "DivScalar");
+}
+template void Div<float>(const Tensor &, float, Tensor *);
+template <typename SType>
+void Div(SType x, const Tensor &in, Tensor *out) {
+  Unary(sa::U_RDIV_S, in, out, static_cast<float>(x), 0.f, "RDivScalar");
+}
+template void Div<float>(float, const Tensor &, Tensor *);
+
+// ---- reductions, rows and columns -----------------------------------------------------
+Tensor SumAll(const Tensor &in) {
+  Tensor flat = Reshape(in.Contiguous(), Shape{1, in.Size()});
+  Tensor out(Shape{1}, in.device(), in.data_type());
+  SumColumns(flat, &out);
+  return out;
+}
+
+// M = alpha * (v along the columns / rows) + beta * M
+template <typename SType>
+void AddColumn(SType alpha, SType beta, const Tensor &v, Tensor *M) {
+  if (static_cast<float>(beta) != 1.f) *M *= static_cast<float>(beta);
+  AddColumn(static_cast<float>(alpha) == 1.f ? v : v * static_cast<float>(alpha),
+            M);
+}
+template void AddColumn<float>(float, float, const Tensor &, Tensor *);
+template <typename SType>
+void AddRow(SType alpha, SType beta, const Tensor &v, Tensor *M) {
+  if (static_cast<float>(beta) != 1.f) *M *= static_cast<float>(beta);
+  AddRow(static_cast<float>(alpha) == 1.f ? v : v * static_cast<float>(alpha),
+         M);
+}
+template void AddRow<float>(float, float, const Tensor &, Tensor *);
+
+// soft-max over the axes from `axis` on: the tensor is read as a matrix of
+// prod(shape[:axis]) rows (reference: SoftMax(in, axis), tensor.cc)
+static Shape RowsFrom(const Tensor &in, int axis) {
+  if (axis < 0) axis += static_cast<int>(in.nDim());
+  CHECK(axis >= 0 && axis <= static_cast<int>(in.nDim()));
+  size_t rows = 1;
+  for (int i = 0; i < axis; ++i) rows *= in.shape(i);
+  return Shape{rows, rows ? in.Size() / rows : 0};
+}
+void SoftMax(const Tensor &in, Tensor *out, int axis) {
+  Tensor x = Reshape(in.Contiguous(), RowsFrom(in, axis));
+  Tensor y = Reshape(*out, x.shape());
+  SoftMax(x, &y);
+}
+Tensor SoftMax(const Tensor &in, int axis) {
+  Tensor out(in.shape(), in.device(), in.data_type());
+  SoftMax(in, &out, axis);
+  return out;
+}
+Tensor SoftMaxBackward(const Tensor &dy, int axis, const Tensor &y) {
+  const Shape m = RowsFrom(y, axis);
+  Tensor dx = SoftMaxBackward(Reshape(dy.Contiguous(), m),
+                              Reshape(y.Contiguous(), m));
+  dx.Reshape(y.shape());
+  return dx;
+}
+
+// out += alpha[0] * in with the factor on the device
+void Axpy(const Tensor &alpha, const Tensor &in, Tensor *out) {
+  CHECK_EQ(alpha.Size(), 1u);
+  CHECK_EQ(in.Size(), out->Size());
+  CHECK(!in.transpose() && !out->transpose());
+  Tensor scaled(in.shape(), in.device(), in.data_type());
+  sa::Desc d;
+  d.ndim = 1;
+  d.shape[0] = static_cast<int64_t>(in.Size());
+  d.s0[0] = 1; d.s1[0] = 0; d.s2[0] = 1;
+  BinaryDesc(sa::B_MUL, in, alpha, &scaled, &d, "AxpyScale");
+  BinaryDesc(sa::B_ADD, *out, scaled, out, nullptr, "Axpy");
+}
+
+Tensor CrossEntropyFwd(const Tensor &p, const Tensor &t) {
+  Tensor loss(Shape{p.nDim() == 2 ? p.shape(0) : 1}, p.device(),
+              p.data_type());
+  ComputeCrossEntropy(p, t, &loss);
+  return loss;
+}
+Tensor SoftmaxCrossEntropyBwd(const Tensor &p, const Tensor &t) {
+  Tensor g = p.Clone();
+  SoftmaxCrossEntropyBwd(t, &g);
+  return g;
 }
 
 }  // namespace singa

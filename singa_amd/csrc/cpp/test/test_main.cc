@@ -156,7 +156,7 @@ static void TestTensorMath(std::shared_ptr<Device> dev) {
   // casts and random
   Tensor I = A.Clone();
   I.SetValue(3.7f);
-  I.AsType(kInt);
+  I.ToType(kInt);
   EXPECT(I.Clone(defaultDevice).ToVector<int>()[0] == 3);
   Tensor u(Shape{4096}, dev);
   Uniform(0.f, 1.f, &u);
@@ -175,6 +175,173 @@ static void TestTensorMath(std::shared_ptr<Device> dev) {
 // GEMM larger than one tile with alpha / beta and transposes, reductions
 // longer than a work-group, convolution / pooling geometries with stride,
 // padding and groups, all against the host device.
+// The part of the reference's tensor function set beyond the layers' needs:
+// the remaining element-wise functions, comparisons, views (transpose,
+// broadcast), repeats and the axis forms of soft-max, against loops on the
+// host.
+static void TestTensorFunctions(std::shared_ptr<Device> dev) {
+  const std::vector<float> x = {-1.75f, -0.5f, 0.f, 0.25f, 0.5f, 0.9f,
+                                1.5f, 2.5f, -2.5f, 3.2f, -0.3f, 0.75f};
+  Tensor X = FromVec(x, {3, 4}, dev);
+  struct Case { const char *name; Tensor (*fn)(const Tensor &);
+                double (*ref)(double); bool unit; };
+  const Case cases[] = {
+      {"Erf", Erf, [](double v) { return std::erf(v); }, false},
+      {"Ceil", Ceil, [](double v) { return std::ceil(v); }, false},
+      {"Floor", Floor, [](double v) { return std::floor(v); }, false},
+      {"Round", Round, [](double v) { return std::round(v); }, false},
+      {"RoundE", RoundE, [](double v) { return std::nearbyint(v); }, false},
+      {"SoftPlus", SoftPlus, [](double v) { return std::log1p(std::exp(v)); },
+       false},
+      {"SoftSign", SoftSign, [](double v) { return v / (1 + std::fabs(v)); },
+       false},
+      {"Cos", Cos, [](double v) { return std::cos(v); }, false},
+      {"Cosh", Cosh, [](double v) { return std::cosh(v); }, false},
+      {"Sin", Sin, [](double v) { return std::sin(v); }, false},
+      {"Sinh", Sinh, [](double v) { return std::sinh(v); }, false},
+      {"Tan", Tan, [](double v) { return std::tan(v); }, false},
+      {"Atan", Atan, [](double v) { return std::atan(v); }, false},
+      {"Asinh", Asinh, [](double v) { return std::asinh(v); }, false},
+      // domain [-1, 1]: the input is squashed first
+      {"Acos", Acos, [](double v) { return std::acos(v); }, true},
+      {"Asin", Asin, [](double v) { return std::asin(v); }, true},
+      {"Atanh", Atanh, [](double v) { return std::atanh(v); }, true},
+  };
+  for (const Case &c : cases) {
+    std::vector<float> in = x, want(x.size());
+    if (c.unit)
+      for (auto &v : in) v = 0.95f * v / (1.f + std::fabs(v));
+    for (size_t i = 0; i < in.size(); ++i) want[i] = (float)c.ref(in[i]);
+    Tensor I = FromVec(in, {3, 4}, dev);
+    ExpectVecNear(ToVec(c.fn(I)), want, 2e-5, c.name);
+  }
+  {  // Acosh wants x >= 1
+    std::vector<float> in = x, want(x.size());
+    for (auto &v : in) v = 1.f + std::fabs(v);
+    for (size_t i = 0; i < in.size(); ++i) want[i] = std::acosh(in[i]);
+    ExpectVecNear(ToVec(Acosh(FromVec(in, {3, 4}, dev))), want, 2e-5, "Acosh");
+  }
+  // comparisons and powers
+  auto y = Rand(12, 31);
+  Tensor Y = FromVec(y, {3, 4}, dev);
+  std::vector<float> le(12), ge(12), eq(12), eqs(12), pw(12);
+  for (int i = 0; i < 12; ++i) {
+    le[i] = x[i] <= y[i];
+    ge[i] = x[i] >= y[i];
+    eq[i] = x[i] == x[i];
+    eqs[i] = x[i] == 0.5f;
+    pw[i] = std::pow(std::fabs(x[i]) + 0.5f, y[i]);
+  }
+  ExpectVecNear(ToVec(X <= Y), le, 0, "<=");
+  ExpectVecNear(ToVec(X >= Y), ge, 0, ">=");
+  ExpectVecNear(ToVec(X == X), eq, 0, "==");
+  ExpectVecNear(ToVec(X == 0.5f), eqs, 0, "== scalar");
+  Tensor out(Shape{3, 4}, dev);
+  LT(X, Y, &out);
+  GT(Y, X, &out);
+  LE(X, 0.25f, &out);
+  EXPECT_NEAR(Sum<float>(out), 6.0, 0);
+  ExpectVecNear(ToVec(Pow(Abs(X) + 0.5f, Y)), pw, 1e-5, "Pow(tensor, tensor)");
+  Pow(X, 2.f, &out);
+  ExpectVecNear(ToVec(out), ToVec(Square(X)), 1e-6, "Pow(x, 2, out)");
+  Sub(X, 1.f, &out);
+  EXPECT_NEAR(ToVec(out)[0], -2.75, 1e-6);
+  Div(X, 2.f, &out);
+  EXPECT_NEAR(ToVec(out)[6], 0.75, 1e-6);
+  Div(3.f, Abs(X) + 1.f, &out);
+  EXPECT_NEAR(ToVec(out)[0], 3.0 / 2.75, 1e-6);
+  ReLUBackward(Y, X, &out);
+  EXPECT_NEAR(ToVec(out)[0], 0.0, 0);
+  EXPECT_NEAR(ToVec(out)[3], y[3], 0);
+  // views: transposes, broadcast, Transform, conversions
+  auto z = Rand(24, 32);
+  Tensor Z = FromVec(z, {2, 3, 4}, dev);
+  Tensor P = Transpose(Z, {2, 0, 1});
+  EXPECT(P.shape() == (Shape{4, 2, 3}) && P.transpose());
+  auto pv = ToVec(Transform(P));
+  bool ok = true;
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 2; ++b)
+      for (int c = 0; c < 3; ++c)
+        ok = ok && pv[(a * 2 + b) * 3 + c] == z[(b * 3 + c) * 4 + a];
+  EXPECT(ok);
+  Tensor R = Transpose(Z);
+  EXPECT(R.shape() == (Shape{4, 3, 2}));
+  EXPECT_NEAR(ToVec(R)[1], z[12], 0);     // (0, 0, 1) <- (1, 0, 0)
+  Tensor row = FromVec({1.f, 2.f, 3.f, 4.f}, {1, 4}, dev);
+  Tensor Bc = Broadcast(row, Shape{2, 3, 4});
+  EXPECT(Bc.shape() == (Shape{2, 3, 4}) && Bc.stride()[0] == 0 &&
+         Bc.stride()[1] == 0);
+  auto bv = ToVec(Contiguous(Bc));
+  EXPECT(bv.size() == 24 && bv[0] == 1.f && bv[7] == 4.f && bv[20] == 1.f);
+  ExpectVecNear(ToVec(Z + Contiguous(Bc)),
+                [&] { auto w = z; for (int i = 0; i < 24; ++i) w[i] += 1 + i % 4;
+                      return w; }(), 1e-6, "broadcast add");
+  Tensor col = FromVec({5.f, 6.f}, {2, 1}, dev);
+  Tensor Bm = Broadcast(col, Shape{7, 7}, 2);    // matrix axes left alone
+  EXPECT(Bm.shape() == (Shape{2, 1}));
+  Tensor I = X.AsType(kInt);
+  EXPECT(I.data_type() == kInt && X.data_type() == kFloat32);
+  EXPECT(I.ToVector<int>()[7] == 2 && I.ToVector<int>()[0] == -1);
+  I.ToType(kFloat32);
+  EXPECT(I.data_type() == kFloat32);
+  EXPECT_NEAR(ToVec(I)[9], 3.0, 0);
+  // repeats
+  Tensor M = FromVec({1, 2, 3, 4, 5, 6}, {2, 3}, dev);
+  ExpectVecNear(ToVec(M.Repeat({2}, 0)),
+                {1, 2, 3, 1, 2, 3, 4, 5, 6, 4, 5, 6}, 0, "Repeat rows");
+  ExpectVecNear(ToVec(M.Repeat({1, 0, 2}, 1)), {1, 3, 3, 4, 6, 6}, 0,
+                "Repeat columns, one count per slice");
+  Tensor flat = M.Repeat({2}, Noaxis);
+  EXPECT(flat.shape() == (Shape{12}));
+  ExpectVecNear(ToVec(flat), {1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6}, 0,
+                "Repeat flattened");
+  // sums, scaled row / column adds, device-side axpy
+  EXPECT_NEAR(ToVec(SumAll(M))[0], 21.0, 1e-6);
+  Tensor M2 = M.Clone();
+  AddColumn(2.f, 0.5f, FromVec({10, 20}, {2}, dev), &M2);
+  ExpectVecNear(ToVec(M2), {20.5f, 21.f, 21.5f, 42.f, 42.5f, 43.f}, 1e-6,
+                "AddColumn(alpha, beta)");
+  M2 = M.Clone();
+  AddRow(-1.f, 1.f, FromVec({1, 2, 3}, {3}, dev), &M2);
+  ExpectVecNear(ToVec(M2), {0, 0, 0, 3, 3, 3}, 1e-6, "AddRow(alpha, beta)");
+  M2 = M.Clone();
+  Axpy(FromVec({-2.f}, {1}, dev), M, &M2);
+  ExpectVecNear(ToVec(M2), {-1, -2, -3, -4, -5, -6}, 1e-6, "Axpy(tensor)");
+  // soft-max over trailing axes and its gradient
+  Tensor S = SoftMax(Z, 1);                   // 2 rows of 12
+  auto sv = ToVec(S);
+  double s0 = 0, s1 = 0;
+  for (int i = 0; i < 12; ++i) { s0 += sv[i]; s1 += sv[12 + i]; }
+  EXPECT_NEAR(s0, 1.0, 1e-5);
+  EXPECT_NEAR(s1, 1.0, 1e-5);
+  EXPECT(S.shape() == Z.shape());
+  Tensor G = SoftMaxBackward(Z, 1, S);
+  auto gv = ToVec(G);
+  double dot = 0;
+  for (int i = 0; i < 12; ++i) dot += z[i] * sv[i];
+  EXPECT_NEAR(gv[5], sv[5] * (z[5] - dot), 1e-5);
+  // losses returning their result, slices and concatenations
+  Tensor prob = SoftMax(FromVec(Rand(8, 33), {2, 4}, dev));
+  Tensor lab = FromInts({3, 1}, {2}, dev);
+  auto lv = ToVec(CrossEntropyFwd(prob, lab));
+  auto pr = ToVec(prob);
+  EXPECT_NEAR(lv[0], -std::log(pr[3]), 1e-5);
+  EXPECT_NEAR(lv[1], -std::log(pr[5]), 1e-5);
+  auto gb = ToVec(SoftmaxCrossEntropyBwd(prob, lab));
+  EXPECT_NEAR(gb[3], pr[3] - 1, 1e-6);
+  EXPECT_NEAR(gb[4], pr[4], 1e-6);
+  EXPECT_NEAR(ToVec(prob)[3], pr[3], 0);      // the argument is left alone
+  ExpectVecNear(ToVec(SliceColumns(M, 1, 3)), {2, 3, 5, 6}, 0, "SliceColumns");
+  ExpectVecNear(ToVec(ConcatRows({M, M})),
+                {1, 2, 3, 4, 5, 6, 1, 2, 3, 4, 5, 6}, 0, "ConcatRows");
+  ExpectVecNear(ToVec(ConcatColumns({M, M})),
+                {1, 2, 3, 1, 2, 3, 4, 5, 6, 4, 5, 6}, 0, "ConcatColumns");
+  EXPECT(Resize(M, Shape{3, 2}).shape() == (Shape{3, 2}));
+  EXPECT(VecToStr(std::vector<int>{1, 2, 3}) == "[1, 2, 3]");
+  EXPECT(CreateConstraint("l2") != nullptr && CreateRegularizer("l2") != nullptr);
+}
+
 static void TestOpenclSpecific(std::shared_ptr<Device> cl) {
   auto *ocl_dev = static_cast<OpenclDevice *>(cl.get());
   std::printf("  %s\n", ocl_dev->Description().c_str());
@@ -284,7 +451,7 @@ static void TestOpenclSpecific(std::shared_ptr<Device> cl) {
   // int tensors and casts
   Tensor I = FromInts({3, -4, 5, 6}, {4}, cl);
   Tensor F = I.Clone();
-  F.AsType(kFloat32);
+  F.ToType(kFloat32);
   EXPECT_NEAR(ToVec(F)[1], -4.f, 0);
   // the generator: reseeding repeats the stream
   Tensor r1(Shape{512}, cl), r2(Shape{512}, cl);
@@ -1441,6 +1608,7 @@ int main(int argc, char **argv) {
     g_dev = std::make_shared<OpenclDevice>(0);
     Run("Opencl/device", [&] { TestOpenclSpecific(g_dev); });
     Run("TensorMath/opencl", [&] { TestTensorMath(g_dev); });
+    Run("TensorFunctions/opencl", [&] { TestTensorFunctions(g_dev); });
     Run("LayersOpenclVsCpu", TestLayersGpuVsCpu);
     Run("Optimizers/opencl", [&] { TestOptimizers(g_dev); });
     Run("LossMetric/opencl", [&] { TestLossMetric(g_dev); });
@@ -1455,6 +1623,7 @@ int main(int argc, char **argv) {
   auto host = defaultDevice;
   Run("MemPoolAndDevice", TestMemPoolAndDevice);
   Run("TensorMath/cpu", [&] { TestTensorMath(host); });
+  Run("TensorFunctions/cpu", [&] { TestTensorFunctions(host); });
   Run("LayersGradient/cpu", TestLayersGradient);
   Run("DropoutAndMulti/cpu", [&] { TestDropoutAndMulti(host); });
   Run("Optimizers/cpu", [&] { TestOptimizers(host); });
@@ -1470,6 +1639,7 @@ int main(int argc, char **argv) {
   if (g_gpu) {
     g_dev = Platform::CreateCudaGPUs(1)[0];
     Run("TensorMath/gpu", [&] { TestTensorMath(g_dev); });
+    Run("TensorFunctions/gpu", [&] { TestTensorFunctions(g_dev); });
     Run("LayersGpuVsCpu", TestLayersGpuVsCpu);
     Run("Rnn/cpu+gpu", TestRnn);
     Run("DropoutAndMulti/gpu", [&] { TestDropoutAndMulti(g_dev); });

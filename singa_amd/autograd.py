@@ -1335,13 +1335,19 @@ def ctensor2numpy(x):
 class CosSim(Operator):
     """Row-wise cosine similarity of two (batch, dim) matrices."""
 
+    @classmethod
+    def dot(cls, a, b):
+        """Row-wise dot products of two (batch, dim) CTensors -> (batch,): one
+        multiply and one row reduction (the reference slices and multiplies
+        row by row, python/singa/autograd.py:4941-4960)."""
+        return singa.ReduceND(singa.__mul__(a, b), [1], "sum")
+
     def forward(self, a, b):
-        ad = singa.ReduceND(singa.__mul__(a, a), [1], "sum")
-        bd = singa.ReduceND(singa.__mul__(b, b), [1], "sum")
+        ad = self.dot(a, a)
+        bd = self.dot(b, b)
         ap = singa.PowFloat(ad, 0.5)
         bp = singa.PowFloat(bd, 0.5)
-        ret = singa.__div__(singa.ReduceND(singa.__mul__(a, b), [1], "sum"),
-                            singa.__mul__(ap, bp))
+        ret = singa.__div__(self.dot(a, b), singa.__mul__(ap, bp))
         if training:
             self.inputs = (a, b, ad, bd, ap, bp, ret)
         return ret
@@ -2464,3 +2470,24 @@ for _name, (_cls, _arity) in {
     "nonzero": (NonZero, 1), "embedding": (Embedding, 2),
 }.items():
     globals()[_name] = _functional(_name, _cls, _arity)
+
+
+# ---------------------------------------------------------------------------
+# names kept for programs written against older releases (reference
+# python/singa/autograd.py:5753-5770): the operator base class under its old
+# name, and the layer classes that once lived in this module.  The layers are
+# looked up on first use: layer.py imports this module.
+# ---------------------------------------------------------------------------
+Operation = Operator
+
+_LAYER_ALIASES = ("Linear", "Conv2d", "SeparableConv2d", "BatchNorm2d",
+                  "Pooling2d", "MaxPool2d", "AvgPool2d", "MaxPool1d",
+                  "AvgPool1d", "RNN_Base", "RNN", "LSTM")
+
+
+def __getattr__(name):
+    if name in _LAYER_ALIASES:
+        from . import layer
+        return getattr(layer, name)
+    raise AttributeError("module %r has no attribute %r" % (__name__, name))
+

@@ -35,6 +35,34 @@ def onnx_type_to_singa_type(onnx_type):
     return np.dtype("int32")
 
 
+# The table form of the above under the reference's name
+# (python/singa/sonnx.py:45-62): numpy type -> the type tensors of it are
+# computed in, None where there is none.  Differences from the reference's
+# table: bool and the unsigned integers map to int32 (the reference has
+# float32 for bool and nothing for unsigned types).
+NP_TYPE_TO_SINGA_SUPPORT_TYPE = {
+    np.dtype(t): (onnx_type_to_singa_type(np.dtype(t))
+                  if np.dtype(t).kind in "fiub" else None)
+    for t in ("float32", "uint8", "int8", "uint16", "int16", "int32", "int64",
+              "bool", "float16", "float64", "complex64", "complex128",
+              "uint32", "uint64", "object")}
+
+
+def __getattr__(name):
+    """``cpu_dev`` / ``gpu_dev`` of the reference module
+    (python/singa/sonnx.py:69-72), created when first asked for instead of at
+    import time (``gpu_dev`` is None on a machine without a GPU)."""
+    if name == "cpu_dev":
+        value = device.get_default_device()
+    elif name == "gpu_dev":
+        from .singa_wrap import USE_CUDA
+        value = device.create_cuda_gpu() if USE_CUDA else None
+    else:
+        raise AttributeError("module %r has no attribute %r" % (__name__, name))
+    globals()[name] = value
+    return value
+
+
 def _singa_dtype_to_onnx(dt):
     return {tensor.float32: TensorProto.FLOAT, tensor.float16:
             TensorProto.FLOAT16, tensor.int32: TensorProto.INT32}.get(
@@ -294,14 +322,14 @@ class SingaBackend(object):
 
     # ---- single node (ONNX backend test protocol) ---------------------------------
     @classmethod
-    def run_node(cls, node, inputs, device_name='CPU', opset_version=_OPSET):
+    def run_node(cls, node, inputs, device='CPU', opset_version=_OPSET):
         node = OnnxNode(node)
         valid_inputs = [x for x in node.inputs if x != ""]
         assert len(valid_inputs) == len(inputs), (
             "%s: expected %d inputs, but got %d." %
             (node.op_type, len(valid_inputs), len(inputs)))
         op = cls._onnx_node_to_singa_op(node, opset_version)
-        dev = _device_of(device_name)
+        dev = _device_of(device)
         states = {}
         xs = []
         for key, val in zip(valid_inputs, inputs):
@@ -374,10 +402,10 @@ class SingaBackend(object):
         return params, inputs, outputs, operators
 
     @classmethod
-    def prepare(cls, model_proto, device='CPU', **kwargs):
+    def prepare(cls, model, device='CPU', **kwargs):
         """ModelProto -> SingaRep.  ``device``: 'CPU', 'CUDA' or a Device."""
         opset_version = None
-        for imp in model_proto.opset_import:
+        for imp in model.opset_import:
             if imp.domain in ("", "ai.onnx"):
                 opset_version = imp.version
                 if imp.version > cls._opset_version:
@@ -387,12 +415,12 @@ class SingaBackend(object):
                             imp.version, cls._opset_version))
             else:
                 warnings.warn("Unrecognized operator set %s" % imp.domain)
-        if model_proto.ir_version > cls._ir_version:
+        if model.ir_version > cls._ir_version:
             warnings.warn(
                 "The imported ir verion {} is larger than the supported "
-                "version {}.".format(model_proto.ir_version, cls._ir_version))
+                "version {}.".format(model.ir_version, cls._ir_version))
         params, inputs, outputs, layers = cls._onnx_model_to_singa_ops(
-            model_proto.graph, opset_version or cls._opset_version)
+            model.graph, opset_version or cls._opset_version)
         return SingaRep(params, inputs, outputs, layers, device)
 
 
@@ -747,11 +775,11 @@ class SingaRep(object):
     graph outputs; ``last_layers=k`` stops after layer k (transfer learning),
     ``aux_output`` names extra tensors to return."""
 
-    def __init__(self, params, inputs, outputs, layers, dev):
+    def __init__(self, params, inputs, outputs, layers, device):
         self.inputs = inputs
         self.states = params
         self.outputs = outputs
-        self.dev = _device_of(dev)
+        self.dev = _device_of(device)
         self.layers = layers
         self.tensor_count = {}
         self.has_initialized = False

@@ -274,7 +274,8 @@ def _wrap(ct):
     return Tensor.__new__(Tensor)._adopt(ct)
 
 
-from_raw_tensor = _wrap
+def from_raw_tensor(t):
+    return _wrap(t)
 
 
 def from_raw_tensors(tt):
@@ -333,10 +334,23 @@ def _core_query(method):
     return fn
 
 
-def _random_fill(kernel):
-    def fn(self, *params, inplace=True):
+def _random_fill(kernel, names):
+    """``t.<fill>(p...)``: the distribution's parameters by position or by
+    the reference's keyword names (python/singa/tensor.py: bernoulli(p),
+    gaussian(mean, std), uniform(low, high))."""
+    def fn(self, *params, inplace=True, **named):
         _inplace_only(inplace)
-        kernel(*(float(v) for v in params), self.data)
+        if len(params) > len(names):
+            raise TypeError("at most %d parameters (%s)" % (
+                len(names), ", ".join(names)))
+        values = list(params)
+        for n in names[len(params):]:
+            if n not in named:
+                raise TypeError("missing parameter %r" % n)
+            values.append(named.pop(n))
+        if named:
+            raise TypeError("unexpected parameters %s" % sorted(named))
+        kernel(*(float(v) for v in values), self.data)
         return self
     return fn
 
@@ -353,10 +367,11 @@ for _name, _method in {'ndim': 'nDim', 'size': 'Size', 'memsize': 'MemSize',
                        'l2': 'L2'}.items():
     setattr(Tensor, _name, _core_query(_method))
 
-for _name, _kernel in {'bernoulli': singa.Bernoulli,
-                       'gaussian': singa.Gaussian,
-                       'uniform': singa.Uniform}.items():
-    setattr(Tensor, _name, _random_fill(_kernel))
+for _name, (_kernel, _params) in {
+        'bernoulli': (singa.Bernoulli, ('p',)),
+        'gaussian': (singa.Gaussian, ('mean', 'std')),
+        'uniform': (singa.Uniform, ('low', 'high'))}.items():
+    setattr(Tensor, _name, _random_fill(_kernel, _params))
 
 for _name, _kernel in {'add_column': singa.AddColumn, 'add_row': singa.AddRow,
                        'div_column': singa.DivColumn, 'div_row': singa.DivRow,
@@ -389,7 +404,10 @@ sqrt = _unary(singa.Sqrt)
 square = _unary(singa.Square)
 tanh = _unary(singa.Tanh)
 relu = _unary(singa.ReLU)
-contiguous = _unary(singa.Contiguous)
+
+
+def contiguous(tensor):
+    return _wrap(singa.Contiguous(tensor.data))
 
 
 def _with_ret(operator, tensor_kernel, scalar_kernel):
@@ -413,8 +431,24 @@ div = _with_ret(lambda a, b: a / b, singa.Div, singa.DivFloatWithRet)
 
 
 # comparison functions: the operator forms under their reference names
-lt, le, gt, ge, eq = (operator.lt, operator.le, operator.gt, operator.ge,
-                      operator.eq)
+def lt(t, x):
+    return t < x
+
+
+def le(t, x):
+    return t <= x
+
+
+def gt(t, x):
+    return t > x
+
+
+def ge(t, x):
+    return t >= x
+
+
+def eq(t, x):
+    return t == x
 
 
 # ---------------------------------------------------------------------------

@@ -155,6 +155,7 @@ def main():
                 "hipgraph_segments": dev.hipgraph_segments(),
                 "collectives_in_graph": bool(
                     sgd.communicator.capturable and not args.no_graph),
+                "collective": sgd.communicator.transport(),
             },
         }), flush=True)
         if args.verbosity > 0:

@@ -552,6 +552,81 @@ PYBIND11_MODULE(_hip, m) {
           "lstm_cell_bwd");
   });
 
+  // ---- xGMI windows: direct collectives between the GPUs of a node ----------------------------------
+  m.attr("xgmi_max_ranks") = sa::kXgmiMaxRanks;
+  m.def("xgmi_signal_bytes", []() { return sa_xgmi_signal_bytes(); });
+  m.def("xgmi_one_shot_max_bytes", []() { return sa_xgmi_one_shot_max_bytes(); });
+  m.def("xgmi_alloc", [](int64_t bytes) {
+    void *p = nullptr;
+    check(sa_xgmi_alloc(bytes, &p), "xgmi_alloc");
+    return reinterpret_cast<uintptr_t>(p);
+  }, "uncached device memory, zero-filled");
+  m.def("xgmi_free", [](uintptr_t p) { check(sa_xgmi_free(P(p)), "xgmi_free"); });
+  m.def("xgmi_export", [](uintptr_t p) {
+    char h[64];
+    check(sa_xgmi_export(P(p), h), "xgmi_export");
+    return py::bytes(h, 64);
+  }, "IPC handle of an allocation (64 bytes)");
+  m.def("xgmi_import", [](std::string handle) {
+    if (handle.size() != 64)
+      throw std::invalid_argument("xgmi_import: a handle has 64 bytes");
+    void *p = nullptr;
+    check(sa_xgmi_import(handle.data(), &p), "xgmi_import");
+    return reinterpret_cast<uintptr_t>(p);
+  });
+  m.def("xgmi_close", [](uintptr_t p) { check(sa_xgmi_close(P(p)), "xgmi_close"); });
+  m.def("xgmi_error_word", []() {
+    void *h = nullptr, *d = nullptr;
+    check(sa_xgmi_error_word(&h, &d), "xgmi_error_word");
+    return py::make_tuple(reinterpret_cast<uintptr_t>(h),
+                          reinterpret_cast<uintptr_t>(d));
+  }, "(host address, device address) of a zeroed word in mapped host memory");
+  m.def("xgmi_error_word_free", [](uintptr_t h) {
+    check(sa_xgmi_error_word_free(P(h)), "xgmi_error_word_free");
+  });
+  m.def("xgmi_read_word", [](uintptr_t h) {
+    return (int)*reinterpret_cast<volatile unsigned *>(h);
+  });
+  m.def("xgmi_clear_word", [](uintptr_t h) {
+    *reinterpret_cast<volatile unsigned *>(h) = 0u;
+  });
+  auto make_peers = [](const std::vector<uintptr_t> &data,
+                       const std::vector<uintptr_t> &flags, int rank,
+                       uintptr_t error) {
+    if (data.size() != flags.size() || data.empty() ||
+        data.size() > (size_t)sa::kXgmiMaxRanks || rank < 0 ||
+        rank >= (int)data.size())
+      throw std::invalid_argument("xgmi: bad peer lists");
+    sa::XgmiPeers pr{};
+    for (size_t i = 0; i < data.size(); ++i) {
+      pr.data[i] = reinterpret_cast<char *>(data[i]);
+      pr.flag[i] = reinterpret_cast<unsigned *>(flags[i]);
+    }
+    pr.epoch = pr.flag[rank] + sa::kXgmiMaxBlocks * sa::kXgmiMaxRanks;
+    pr.error = reinterpret_cast<unsigned *>(error);
+    return pr;
+  };
+  m.def("xgmi_allreduce", [make_peers](int dt, std::vector<uintptr_t> data,
+                                       std::vector<uintptr_t> flags, int rank,
+                                       uintptr_t error, int64_t off,
+                                       int64_t bytes, bool one_shot,
+                                       double timeout_s, uintptr_t s) {
+    sa::XgmiPeers pr = make_peers(data, flags, rank, error);
+    check(sa_xgmi_allreduce(dt, &pr, rank, (int)data.size(), off, bytes,
+                            one_shot ? 1 : 0, timeout_s, S(s)),
+          "xgmi_allreduce");
+  });
+  m.def("xgmi_allgather", [make_peers](std::vector<uintptr_t> data,
+                                       std::vector<uintptr_t> flags, int rank,
+                                       uintptr_t error, int64_t off,
+                                       int64_t gathered_off, int64_t bytes,
+                                       double timeout_s, uintptr_t s) {
+    sa::XgmiPeers pr = make_peers(data, flags, rank, error);
+    check(sa_xgmi_allgather(&pr, rank, (int)data.size(), off, gathered_off,
+                            bytes, timeout_s, S(s)),
+          "xgmi_allgather");
+  });
+
   // ---- communication helpers ----------------------------------------------------------------------------
   m.def("pack", [](int src_dt, int dst_dt, std::vector<uintptr_t> ptrs,
                    std::vector<int64_t> counts, uintptr_t bucket, uintptr_t s) {

@@ -449,6 +449,35 @@ struct PackBatch {
   int64_t count[kPackMax];
 };
 }  // namespace sa
+// ---- xgmi.hip: collectives over IPC-mapped windows of the node's GPUs -------------------------------------------
+namespace sa {
+constexpr int kXgmiMaxRanks = 8;    // GPUs of one node
+constexpr int kXgmiMaxBlocks = 64;  // workgroups of a collective kernel
+constexpr int kXgmiThreads = 512;
+struct XgmiPeers {
+  char *data[kXgmiMaxRanks];      // every rank's window, as mapped here
+  unsigned *flag[kXgmiMaxRanks];  // every rank's flag words [block][rank]
+  unsigned *epoch;                // this rank's barrier count per workgroup
+  unsigned *error;                // sticky word in mapped host memory
+};
+}  // namespace sa
+int64_t sa_xgmi_signal_bytes();
+int sa_xgmi_alloc(int64_t bytes, void **out);
+int sa_xgmi_free(void *p);
+int sa_xgmi_export(void *p, char *handle64);
+int sa_xgmi_import(const char *handle64, void **out);
+int sa_xgmi_close(void *p);
+int sa_xgmi_error_word(void **host, void **device);
+int sa_xgmi_error_word_free(void *host);
+// In-place sum over the ranks of `bytes` bytes at byte offset `off` of every
+// window; one_shot only up to sa_xgmi_one_shot_max_bytes().
+int64_t sa_xgmi_one_shot_max_bytes();
+int sa_xgmi_allreduce(int dtype, const sa::XgmiPeers *peers, int rank,
+                      int world, int64_t off, int64_t bytes, int one_shot,
+                      double timeout_s, hipStream_t s);
+int sa_xgmi_allgather(const sa::XgmiPeers *peers, int rank, int world,
+                      int64_t off, int64_t gathered_off, int64_t bytes,
+                      double timeout_s, hipStream_t s);
 int sa_pack(int src_dtype, int dst_dtype, int n_tensors, void *const *ptrs,
             const int64_t *counts, void *bucket, hipStream_t s);
 int sa_unpack(int src_dtype, int dst_dtype, int n_tensors, void *const *ptrs,

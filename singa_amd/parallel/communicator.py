@@ -87,6 +87,12 @@ _DIRECT = os.environ.get("SINGA_RCCL_DIRECT", "1") != "0"
 # the default: which of the two is faster on a given node is a measurement,
 # tools/bench_allreduce.py prints both)
 _TWO_PHASE = int(os.environ.get("SINGA_ALLREDUCE_TWO_PHASE", "0"))
+# SINGA_XGMI_DIRECT=1: the ranks of a one-node job exchange gradient buckets
+# with the kernels of csrc/hip/xgmi.hip, which read every peer's memory over
+# that peer's own xGMI link, instead of RCCL's ring (parallel/xgmi.py).
+# SINGA_XGMI_WINDOW_MB sizes the per-rank window the buckets live in,
+# SINGA_XGMI_TIMEOUT (seconds) bounds a wait for a peer inside a kernel.
+_XGMI = os.environ.get("SINGA_XGMI_DIRECT", "0") == "1"
 
 
 class _UniqueId(ctypes.Structure):
@@ -285,11 +291,15 @@ class Communicator(object):
         self._rccl = None         # this process's RCCL communicator
         if _DIRECT and self._active and self._gpu and not want_host:
             self._rccl = self._join_rccl()
-        # device tensors travel through host memory when there is no RCCL
-        self._host_backend = self._active and self._rccl is None
+        self._xgmi = None         # this rank's window into the peers' memory
+        if _XGMI and self._active and self._gpu:
+            self._xgmi = self._open_window()
+        # device tensors travel through host memory when there is neither
+        self._host_backend = (self._active and self._rccl is None and
+                              self._xgmi is None)
         # stream-ordered collectives can be part of a captured hipGraph
-        self.capturable = (self._rccl is not None and _CAPTURE and
-                           not _DEBUG and not _STRICT)
+        self.capturable = ((self._rccl is not None or self._xgmi is not None)
+                           and _CAPTURE and not _DEBUG and not _STRICT)
         probe = os.environ.get("SINGA_DIST_CAPTURE_PROBE", "1")
         if self.capturable and probe != "0" and \
                 (self.world_size > 1 or probe == "force"):
@@ -328,6 +338,48 @@ class Communicator(object):
             return None
         return rccl
 
+    def _open_window(self):
+        """Allocate this rank's xGMI window and map the peers' (see
+        parallel/xgmi.py); all ranks use the windows or none does."""
+        from . import xgmi
+        device = torch.device("cuda", torch.cuda.current_device())
+
+        def exchange(obj):
+            if self.world_size <= 1:
+                return [obj]
+            box = [None] * self.world_size
+            dist.all_gather_object(box, obj)
+            return box
+
+        win, err = None, None
+        try:
+            win = xgmi.XgmiWindow(
+                self.global_rank, self.world_size, device,
+                int(os.environ.get("SINGA_XGMI_WINDOW_MB", "512")) << 20,
+                exchange,
+                float(os.environ.get("SINGA_XGMI_TIMEOUT", "30")))
+        except (OSError, RuntimeError, ImportError) as e:
+            err = e
+        if not self.agree(win is not None):
+            if err is not None:
+                print("[rank %d] no xGMI window (%s)" % (self.global_rank,
+                                                          err), flush=True)
+            if win is not None:
+                win.close()
+            return None
+        return win
+
+    def transport(self):
+        """What carries device collectives: "xgmi-direct" (peer-reading
+        kernels over IPC windows, RCCL for operands outside the windows),
+        "rccl", "host" (staged through host memory over gloo) or "none" (a
+        lone rank)."""
+        if not self._active:
+            return "none"
+        if self._xgmi is not None:
+            return "xgmi-direct"
+        return "rccl" if self._rccl is not None else "host"
+
     def agree(self, ok):
         """True when ``ok`` holds on every rank.  The exchange runs over the
         host control group, so it never pairs with (or waits behind) a device
@@ -364,6 +416,8 @@ class Communicator(object):
             self._heartbeat.check()
         if self._rccl is not None:
             self._rccl.check_async_error()
+        if self._xgmi is not None:
+            self._xgmi.check()
         if self._fault is not None:
             self._fault.tick(self.global_rank, self.steps)
 
@@ -377,6 +431,10 @@ class Communicator(object):
         try:
             if self._gpu and (self._rccl is not None or self._owns_group):
                 torch.cuda.synchronize()
+            if getattr(self, "_xgmi", None) is not None:
+                self._buffers = {}
+                self._xgmi.close()
+                self._xgmi = None
             if self._rccl is not None:
                 self._rccl.close()
                 self._rccl = None
@@ -396,10 +454,16 @@ class Communicator(object):
         key = (slot, kind, tdtype)
         buf = self._buffers.get(key)
         if buf is None or buf.numel() < n or buf.device != dev.torch_device:
-            buf = torch.empty(max(int(n), 1), dtype=tdtype,
-                              device=dev.torch_device)
+            if self._xgmi is not None and kind in self._WINDOW_KINDS:
+                # operands of a direct collective live in this rank's window
+                buf = self._xgmi.tensor(max(int(n), 1), tdtype)
+            else:
+                buf = torch.empty(max(int(n), 1), dtype=tdtype,
+                                  device=dev.torch_device)
             self._buffers[key] = buf
         return buf[:n]
+
+    _WINDOW_KINDS = ("bucket", "payload", "gathered", "stage")
 
     def _next_slot(self):
         s = self._slot
@@ -427,7 +491,11 @@ class Communicator(object):
         the collective runs on a host copy over gloo, the result is copied
         back on the current stream.  RCCL collectives are stream ordered and
         take the tensor as is."""
-        return t.is_cuda and self._rccl is None
+        return t.is_cuda and self._rccl is None and not self._windowed(t)
+
+    def _windowed(self, t):
+        """True when ``t`` lies in this rank's xGMI window."""
+        return self._xgmi is not None and self._xgmi.owns(t)
 
     def _direct(self, t):
         """True when the collective on ``t`` is an RCCL call."""
@@ -448,8 +516,12 @@ class Communicator(object):
         g = x = None
         ok = True
         try:
-            x = torch.ones(4096, dtype=torch.float32, device=device)
-            self._rccl.all_reduce(x)
+            if self._xgmi is not None:
+                x = self._xgmi.tensor(4096, torch.float32)
+                x.fill_(1.0)
+            else:
+                x = torch.ones(4096, dtype=torch.float32, device=device)
+            self._all_reduce(x)
             torch.cuda.synchronize(device)
             g = torch.cuda.CUDAGraph()
             cap = torch.cuda.Stream(device=device)
@@ -459,7 +531,7 @@ class Communicator(object):
                 x.mul_(1.0)
                 side.wait_stream(torch.cuda.current_stream(device))
                 with torch.cuda.stream(side):
-                    self._rccl.all_reduce(x)
+                    self._all_reduce(x)
                 torch.cuda.current_stream(device).wait_stream(side)
                 x.mul_(1.0)
         except Exception as e:          # noqa: BLE001 (capability probe)
@@ -501,7 +573,9 @@ class Communicator(object):
                 torch.cuda.synchronize(flat.device)
             self._seq = getattr(self, "_seq", 0) + 1
             before = float(flat.float().abs().sum())
-        if self._staged(flat):
+        if self._windowed(flat):
+            self._xgmi.all_reduce(flat)
+        elif self._staged(flat):
             host = self._to_host(flat)
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             flat.copy_(host)
@@ -524,6 +598,9 @@ class Communicator(object):
         in rank order: one collective."""
         if not self._active:
             out[:flat.numel()].copy_(flat)
+        elif self._windowed(flat) and self._windowed(out) and \
+                (flat.numel() * flat.element_size()) % 4 == 0:
+            self._xgmi.all_gather(out, flat)
         elif self._staged(flat):
             host = self._to_host(flat)
             gathered = torch.empty(out.numel(), dtype=host.dtype)
@@ -606,10 +683,22 @@ class Communicator(object):
             return
 
         state = {}
+        slot = self._next_slot() if self._xgmi is not None else None
 
         def body(x):
             flat = self._operand_views(dev, state, [x])[0]
             if self._skip_body(dev):
+                return
+            if slot is not None and flat.dtype in (
+                    torch.float32, torch.float16, torch.bfloat16):
+                # a direct collective works on the window: copy in, sum, copy
+                # back (a fused bucket is packed into the window instead)
+                stage = self._buffer(dev, slot, "stage", flat.numel(),
+                                     flat.dtype)
+                self._run_pipeline(dev, [
+                    ("pack", lambda: dev.math.copy(flat, stage)),
+                    ("comm", lambda: self._all_reduce(stage)),
+                    ("unpack", lambda: dev.math.copy(stage, flat))])
                 return
             self._run_pipeline(dev, [("comm", lambda: self._all_reduce(flat))])
 

@@ -378,3 +378,41 @@ def test_two_ranks_share_one_gpu(graph, option):
         env=env, capture_output=True, text=True, timeout=280)
     assert out.returncode == 0 and "MULTIRANK-OK" in out.stdout, (
         out.stdout[-3000:] + out.stderr[-2000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,ranks", [("collectives", "4"),
+                                        ("collectives", "2"),
+                                        ("timeout", "3")])
+def test_xgmi_direct_collectives(case, ranks):
+    """All-reduce (one- and two-shot, three element types) and all-gather
+    kernels that read the other ranks' windows through IPC mappings: ranks as
+    processes sharing the GPU, results against a host sum, bit-identical on
+    every rank, replayed from a hipGraph; a missing peer ends in the bounded
+    wait's error, not in a hang."""
+    import subprocess
+    env = dict(os.environ, XG_CASE=case, XG_RANKS=ranks)
+    out = subprocess.run(
+        [sys.executable, "-u",
+         os.path.join(ROOT, "tools", "check_xgmi_direct.py")],
+        env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "XGMI-DIRECT-OK" in out.stdout, (
+        out.stdout[-3000:] + out.stderr[-2000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("option", ["plain", "half", "sparseTopK"])
+def test_two_ranks_train_through_xgmi_windows(option):
+    """DistOpt with the direct collectives: buckets are packed into the
+    rank's window, summed by the peer-reading kernel and unpacked from it, all
+    inside the one captured hipGraph of the step; the loss trajectory is the
+    single-process one."""
+    import subprocess
+    env = dict(os.environ, MR_GRAPH="1", MR_OPTION=option,
+               SINGA_XGMI_DIRECT="1", SINGA_XGMI_WINDOW_MB="256")
+    out = subprocess.run(
+        [sys.executable, "-u",
+         os.path.join(ROOT, "tools", "check_multirank_gpu.py")],
+        env=env, capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "MULTIRANK-OK" in out.stdout, (
+        out.stdout[-3000:] + out.stderr[-2000:])

@@ -8,9 +8,11 @@
 For every size the ways of summing a float32 buffer over the ranks are timed:
 the RCCL call on the caller's stream that the communicator uses,
 reduce-scatter + all-gather on the same communicator, the RCCL call as a
-captured hipGraph replay (the way a training step issues it), and -- for
-reference -- the host-staged exchange over the gloo control group that serves
-when RCCL is switched off.
+captured hipGraph replay (the way a training step issues it), the direct
+kernel that reads every peer's window over its own link (SINGA_XGMI_DIRECT=1,
+csrc/hip/xgmi.hip; several ranks may share one GPU with SINGA_DIST_BACKEND=gloo)
+and -- for reference -- the host-staged exchange over the gloo control group
+that serves when RCCL is switched off.
 Reported: microseconds per call, algorithm bandwidth (bytes / time) and bus
 bandwidth (algorithm bandwidth x 2 (N - 1) / N, the per-link load of a ring).
 xGMI gives every GPU 7 links of about 153 GB/s peer to peer."""
@@ -49,6 +51,8 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     args = ap.parse_args()
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # a rehearsal with several ranks per GPU wraps around the devices
+    local %= max(torch.cuda.device_count(), 1)
     dev = device.create_cuda_gpu_on(local)
     torch.cuda.set_device(local)
     comm = Communicator(1 << 22)       # rendezvous from the environment
@@ -62,7 +66,28 @@ def main():
         buf = torch.ones(n, dtype=torch.float32, device=td)
         res = {"bytes": n * 4}
 
-        if rccl is None or lg <= 20:
+        win = getattr(comm, "_xgmi", None)
+        if win is not None and n * 4 + 4096 <= win.bytes // 2:
+            if "cursor0" not in globals():
+                globals()["cursor0"] = win._cursor
+            win._cursor = globals()["cursor0"]      # one buffer, reused
+            wbuf = win.tensor(n, torch.float32)
+            wbuf.fill_(1.0)
+            res["xgmi_us"] = timed(lambda: win.all_reduce(wbuf), args.iters,
+                                   td) * 1e6
+            g = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream(device=td)
+            torch.cuda.synchronize(td)
+            if dist.is_initialized():
+                dist.barrier()
+            with torch.cuda.graph(g, stream=side,
+                                  capture_error_mode="thread_local"):
+                for _ in range(8):
+                    win.all_reduce(wbuf)
+            res["xgmi_graph_us"] = timed(g.replay, max(args.iters // 4, 2),
+                                         td) * 1e6 / 8
+            win.check()
+        if (rccl is None and win is None) or lg <= 20:
             def staged_call():
                 host = buf.cpu()
                 if dist.is_initialized():

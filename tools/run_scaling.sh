@@ -6,7 +6,10 @@
 #
 #   tools/run_scaling.sh [--steps K] [--warmup W] [--dtype fp32|fp16|bf16]
 #                        [--out DIR] [--max-gpus N] [--two-phase ELEMENTS]
+#                        [--xgmi-direct]
 #
+# --xgmi-direct sums the buckets with the kernels that read every peer's
+# window over its own xGMI link (csrc/hip/xgmi.hip) instead of RCCL's ring.
 # --two-phase E sums buckets of at least E elements as reduce-scatter +
 # all-gather (every slice over its own xGMI link) instead of one all-reduce;
 # run the script once with and once without to see which this node prefers.
@@ -27,6 +30,7 @@ while [ $# -gt 0 ]; do
     --out) OUT=$2; shift 2;;
     --max-gpus) MAXG=$2; shift 2;;
     --two-phase) export SINGA_ALLREDUCE_TWO_PHASE=$2; shift 2;;
+    --xgmi-direct) export SINGA_XGMI_DIRECT=1; shift;;
     *) echo "unknown argument $1" >&2; exit 2;;
   esac
 done
@@ -59,6 +63,17 @@ for N in 1 2 4 8; do
   fi
   grep '^{"metric"' "$LOG" | tail -1 >> "$CURVE"
 done
+# all-reduce latency / bandwidth over message sizes on all GPUs of the node:
+# RCCL (one call, reduce-scatter + all-gather, graph replay) next to the
+# direct xGMI kernels
+if [ "$HAVE" -gt 1 ]; then
+  N=$HAVE; [ "$N" -gt "$MAXG" ] && N=$MAXG
+  SINGA_XGMI_DIRECT=1 timeout -k 10 600 python -m torch.distributed.run \
+    --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 \
+    --master-port $((PORT + 20)) tools/bench_allreduce.py \
+    > "$LOGDIR/allreduce_n$N.log" 2>&1 \
+    && grep '^{' "$LOGDIR/allreduce_n$N.log" > "$OUT/allreduce_sizes_n$N.jsonl"
+fi
 python - "$CURVE" "$LOGDIR" "$OUT/scaling_comm_time.md" <<'EOF'
 import json, os, re, sys
 curve, logdir, out = sys.argv[1:4]

@@ -75,6 +75,11 @@ _CONV_AUTOTUNE = os.environ.get("SINGA_CONV_AUTOTUNE", "1") != "0"
 # keeps the heuristic of the launcher
 _GEMM_AUTOTUNE = os.environ.get("SINGA_GEMM_AUTOTUNE", "1") != "0"
 _CONV16_AUTOTUNE = os.environ.get("SINGA_CONV16_AUTOTUNE", "1") != "0"
+# float32 3x3 / stride 1 / pad 1 layers: time the Winograd routes (F(2x2, 3x3)
+# and F(4x4, 3x3) transforms around a batched product, csrc/hip/winograd.hip)
+# against the direct kernels per geometry; 0 keeps the direct kernels, 2 / 4
+# force a transform where it applies (tests)
+_CONV_WINOGRAD = os.environ.get("SINGA_CONV_WINOGRAD", "1")
 # SINGA_DETERMINISTIC=1: bitwise reproducible training steps.  Reductions that
 # are split over workgroups (convolution passes, column sums, whole-tensor
 # sums, the soft-max loss) add their partial results in a fixed order instead
@@ -1099,6 +1104,76 @@ class HipMath(object):
                 best, best_t = which, t
         return best
 
+    # ---- float32 Winograd routes ------------------------------------------------
+    @staticmethod
+    def _winograd_applies(act, w, out, stride, pad, groups):
+        return (_CONV_WINOGRAD != "0" and groups == 1 and
+                act.dtype == torch.float32 and w.dtype == torch.float32 and
+                tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and
+                tuple(pad) == (1, 1) and act.is_contiguous() and
+                out.is_contiguous() and
+                tuple(act.shape[2:]) == tuple(out.shape[2:]))
+
+    def _winograd(self, m, mode, act, w, bias, addend, out):
+        """out = conv3x3(act, w) (mode 0) or its data gradient (mode 1: act
+        is dy, the filter is rotated and its channel roles exchanged) through
+        F(m x m, 3 x 3): filter and input transforms, (m + 2)^2 products
+        [KO x CI] x [CI x tiles] as one batched GEMM, output transform (which
+        adds ``bias`` / ``addend``)."""
+        N, CI, H, W = act.shape
+        KO = out.shape[1]
+        K, C = w.shape[0], w.shape[1]
+        assert (KO, CI) == ((K, C) if mode == 0 else (C, K))
+        P = (m + 2) * (m + 2)
+        T = N * (-(-H // m)) * (-(-W // m))
+        U = self._tmp(P * KO * CI).view(P, KO, CI)
+        V = self._tmp(P * CI * T).view(P, CI, T)
+        M = self._tmp(P * KO * T).view(P, KO, T)
+        s = self._s()
+        self.k.wino_filter(m, w.data_ptr(), U.data_ptr(), K, C, mode == 1, s)
+        self.k.wino_input(m, act.data_ptr(), V.data_ptr(), N, CI, H, W, s)
+        self.gemm(1.0, U, V, 0.0, M)
+        self.k.wino_output(m, M.data_ptr(),
+                           bias.data_ptr() if bias is not None else 0,
+                           addend.data_ptr() if addend is not None else 0,
+                           out.data_ptr(), N, KO, H, W, s)
+        return True
+
+    def _route32(self, mode, act, w, bias, addend, out, direct):
+        """Run a float32 3x3 layer on the fastest of the direct kernels
+        (``direct()``) and the two Winograd routes, measured once per
+        geometry and kept with the launch plans.  Returns what ``direct``
+        returned when it ran, else None."""
+        key = ("w32", mode, tuple(act.shape), tuple(w.shape),
+               bias is not None, addend is not None)
+        plan = self._conv_plans.get(key)
+        if _CONV_WINOGRAD in ("2", "4"):
+            plan = (int(_CONV_WINOGRAD), 0)
+        elif plan is None and _CONV_AUTOTUNE and not _DETERMINISTIC and \
+                (_world_size() <= 1 or _rank() == 0):
+            name = repr(key)
+            stored = self._plan_store()[1].get(name)
+            if stored is not None:
+                plan = (int(stored[0]), int(stored[1]))
+            elif not torch.cuda.is_current_stream_capturing():
+                def run_direct():
+                    direct()
+                    return True
+                plan = self._measure_routes16([
+                    ((0, 0), run_direct),
+                    ((2, 0), lambda: self._winograd(2, mode, act, w, bias,
+                                                    addend, out)),
+                    ((4, 0), lambda: self._winograd(4, mode, act, w, bias,
+                                                    addend, out))])
+                if plan is not None:
+                    self._persist_plan(name, plan)
+            if plan is not None:
+                self._conv_plans[key] = plan
+        if plan is not None and plan[0] in (2, 4):
+            self._winograd(plan[0], mode, act, w, bias, addend, out)
+            return None
+        return direct()
+
     @property
     def STAT_COPIES(self):
         return self.k.stat_copies
@@ -1119,6 +1194,16 @@ class HipMath(object):
                                  shift.data_ptr(), y.shape[0], y.shape[1],
                                  y.shape[2] * y.shape[3], self._s())
             return
+        if stats is None and self._winograd_applies(x, w, y, stride, pad,
+                                                    groups):
+            self._route32(0, x, w, b, None, y,
+                          lambda: self._conv_fwd_direct(x, w, b, y, stride,
+                                                        pad, groups, None,
+                                                        None))
+            return
+        self._conv_fwd_direct(x, w, b, y, stride, pad, groups, stats, shift)
+
+    def _conv_fwd_direct(self, x, w, b, y, stride, pad, groups, stats, shift):
         g = self._geom(x.shape, w.shape, y.shape, stride, pad, groups)
         scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)
             g, y, w.shape[0] // groups, y.shape[0] * y.shape[2] * y.shape[3],
@@ -1192,6 +1277,18 @@ class HipMath(object):
                     1, dy, w, None if addend is None else self._contig(addend),
                     dx, stride, pad, groups):
             return
+        if self._winograd_applies(dy, w, dx, stride, pad, groups):
+            if addend is not None:
+                addend = self._contig(addend)
+            return self._route32(
+                1, dy, w, None, addend, dx,
+                lambda: self._conv_bwd_data_direct(dy, w, dx, stride, pad,
+                                                   groups, addend, side_zero))
+        return self._conv_bwd_data_direct(dy, w, dx, stride, pad, groups,
+                                          addend, side_zero)
+
+    def _conv_bwd_data_direct(self, dy, w, dx, stride, pad, groups, addend,
+                              side_zero):
         g = self._geom(dx.shape, w.shape, dy.shape, stride, pad, groups)
         scratch = self._split_scratch(  # noqa: F841 (keeps the buffer alive)
             g, dx, dx.shape[1] // groups,

@@ -552,6 +552,25 @@ PYBIND11_MODULE(_hip, m) {
           "lstm_cell_bwd");
   });
 
+  // ---- Winograd transforms -----------------------------------------------------------------------------
+  m.def("wino_filter", [](int mm, uintptr_t w, uintptr_t U, int K, int C,
+                          bool flip, uintptr_t s) {
+    check(sa_wino_filter(mm, (const float *)CP(w), (float *)P(U), K, C,
+                         flip ? 1 : 0, S(s)), "wino_filter");
+  });
+  m.def("wino_input", [](int mm, uintptr_t x, uintptr_t V, int N, int C, int H,
+                         int W, uintptr_t s) {
+    check(sa_wino_input(mm, (const float *)CP(x), (float *)P(V), N, C, H, W,
+                        S(s)), "wino_input");
+  });
+  m.def("wino_output", [](int mm, uintptr_t M, uintptr_t bias,
+                          uintptr_t addend, uintptr_t y, int N, int K, int H,
+                          int W, uintptr_t s) {
+    check(sa_wino_output(mm, (const float *)CP(M), (const float *)CP(bias),
+                         (const float *)CP(addend), (float *)P(y), N, K, H, W,
+                         S(s)), "wino_output");
+  });
+
   // ---- xGMI windows: direct collectives between the GPUs of a node ----------------------------------
   m.attr("xgmi_max_ranks") = sa::kXgmiMaxRanks;
   m.def("xgmi_signal_bytes", []() { return sa_xgmi_signal_bytes(); });

@@ -449,6 +449,18 @@ struct PackBatch {
   int64_t count[kPackMax];
 };
 }  // namespace sa
+// ---- winograd.hip: transforms of F(m x m, 3 x 3), m = 2 or 4, float32 ---------------------------------------------
+// U[(m+2)^2][KO][CI] from w[K][C][3][3]; flip: rotated taps and exchanged
+// channel roles (the data gradient's filter), KO = C, CI = K
+int sa_wino_filter(int m, const float *w, float *U, int K, int C, int flip,
+                   hipStream_t s);
+// V[(m+2)^2][C][T] from x[N][C][H][W], T = N * ceil(H / m) * ceil(W / m)
+int sa_wino_input(int m, const float *x, float *V, int N, int C, int H, int W,
+                  hipStream_t s);
+// y[N][K][H][W] = inverse transform of M[(m+2)^2][K][T] [+ bias[K]] [+ addend]
+int sa_wino_output(int m, const float *M, const float *bias,
+                   const float *addend, float *y, int N, int K, int H, int W,
+                   hipStream_t s);
 // ---- xgmi.hip: collectives over IPC-mapped windows of the node's GPUs -------------------------------------------
 namespace sa {
 constexpr int kXgmiMaxRanks = 8;    // GPUs of one node

@@ -1,0 +1,258 @@
+// Winograd transforms for 3 x 3, stride 1, pad 1 convolutions in float32.
+//
+// F(m x m, 3 x 3) computes an m x m block of outputs from an (m + 2)^2 input
+// patch with (m + 2)^2 multiplications per (input channel, output channel)
+// pair instead of 9 m^2: 2.25 x fewer for m = 2, 4 x fewer for m = 4.  The
+// convolution becomes
+//
+//   U[p][k][c] = (G g G^T)[p]            filter transform, p = 0 .. (m+2)^2-1
+//   V[p][c][t] = (B^T d B)[p]            input transform, t = image tile
+//   M[p][k][t] = sum_c U[p][k][c] V[p][c][t]   (m+2)^2 independent products
+//   y tile     = A^T M[.][k][t] A        output transform
+//
+// Only the transforms live here; the batched product runs on the float32 MFMA
+// GEMM kernels (gemm.hip).  The deep, narrow layers of a residual network
+// (14 x 14 and 7 x 7 images with 256 / 512 channels at batch 32) gain from the
+// smaller product; on the wide early layers the (m+2)^2 / m^2 larger
+// intermediate tensors cost more memory traffic than the arithmetic saves,
+// which is why the caller times this route against the direct kernels per
+// geometry.  The data gradient is the same computation on dy with the filter
+// rotated by 180 degrees and its channel roles exchanged; the filter
+// transform does both on the fly.  The reference leaves the choice of such
+// algorithms to the vendor library (src/model/operation/convolution.cc:514-640).
+//
+// Everything is plain float32 arithmetic; the transforms add and subtract
+// neighbouring values, so results differ from the direct kernels by rounding
+// only (a few 1e-6 of the output magnitude for m = 2, 1e-5 for m = 4).
+#include "common.cuh"
+#include "kernels.h"
+
+namespace sa {
+
+template <int M> struct WinoMat;
+
+template <> struct WinoMat<2> {
+  static constexpr int A = 4;
+  static constexpr float BT[4][4] = {
+      {1, 0, -1, 0}, {0, 1, 1, 0}, {0, -1, 1, 0}, {0, 1, 0, -1}};
+  static constexpr float G[4][3] = {
+      {1, 0, 0}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0, 0, 1}};
+  static constexpr float AT[2][4] = {{1, 1, 1, 0}, {0, 1, -1, -1}};
+};
+
+template <> struct WinoMat<4> {
+  static constexpr int A = 6;
+  static constexpr float BT[6][6] = {
+      {4, 0, -5, 0, 1, 0},  {0, -4, -4, 1, 1, 0}, {0, 4, -4, -1, 1, 0},
+      {0, -2, -1, 2, 1, 0}, {0, 2, -1, -2, 1, 0}, {0, 4, 0, -5, 0, 1}};
+  static constexpr float G[6][3] = {
+      {1.f / 4, 0, 0},
+      {-1.f / 6, -1.f / 6, -1.f / 6},
+      {-1.f / 6, 1.f / 6, -1.f / 6},
+      {1.f / 24, 1.f / 12, 1.f / 6},
+      {1.f / 24, -1.f / 12, 1.f / 6},
+      {0, 0, 1}};
+  static constexpr float AT[4][6] = {{1, 1, 1, 1, 1, 0},
+                                     {0, 1, -1, 2, -2, 0},
+                                     {0, 1, 1, 4, 4, 0},
+                                     {0, 1, -1, 8, -8, 1}};
+};
+
+// one thread per (output channel, input channel) pair of the product:
+// (ko, ci) = (k, c) of w[K][C][3][3] forward, (c, k) with the taps reversed for
+// the data gradient
+template <int M>
+__global__ void wino_filter_kernel(const float *__restrict__ w,
+                                   float *__restrict__ U, int K, int C,
+                                   int flip) {
+  using W = WinoMat<M>;
+  constexpr int A = W::A;
+  const int KO = flip ? C : K, CI = flip ? K : C;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)KO * CI) return;
+  const int ci = (int)(idx % CI), ko = (int)(idx / CI);
+  const float *src = flip ? w + ((int64_t)ci * C + ko) * 9
+                          : w + ((int64_t)ko * C + ci) * 9;
+  float g[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      g[r][s] = flip ? src[(2 - r) * 3 + (2 - s)] : src[r * 3 + s];
+  float t[A][3];
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+      t[i][s] = W::G[i][0] * g[0][s] + W::G[i][1] * g[1][s] +
+                W::G[i][2] * g[2][s];
+  const int64_t plane = (int64_t)KO * CI;
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < A; ++j)
+      U[(i * A + j) * plane + idx] = t[i][0] * W::G[j][0] +
+                                     t[i][1] * W::G[j][1] +
+                                     t[i][2] * W::G[j][2];
+}
+
+// one thread per (channel, tile); tiles are numbered (n, tile row, tile
+// column) with the column fastest, so a wave writes consecutive words of V
+template <int M>
+__global__ void wino_input_kernel(const float *__restrict__ x,
+                                  float *__restrict__ V, int C, int H, int Wd,
+                                  int th, int tw, int64_t T) {
+  using W = WinoMat<M>;
+  constexpr int A = W::A;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)C * T) return;
+  const int64_t t = idx % T;
+  const int c = (int)(idx / T);
+  const int tc = (int)(t % tw);
+  const int tr = (int)((t / tw) % th);
+  const int n = (int)(t / ((int64_t)tw * th));
+  const float *img = x + ((int64_t)n * C + c) * H * Wd;
+  const int h0 = tr * M - 1, w0 = tc * M - 1;
+  float d[A][A];
+#pragma unroll
+  for (int a = 0; a < A; ++a) {
+    const int h = h0 + a;
+    const bool hin = h >= 0 && h < H;
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+      const int ww = w0 + b;
+      d[a][b] = (hin && ww >= 0 && ww < Wd) ? img[(int64_t)h * Wd + ww] : 0.f;
+    }
+  }
+  float u[A][A];  // B^T d
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int b = 0; b < A; ++b) {
+      float s = 0.f;
+#pragma unroll
+      for (int a = 0; a < A; ++a)
+        if (W::BT[i][a] != 0.f) s += W::BT[i][a] * d[a][b];
+      u[i][b] = s;
+    }
+  const int64_t plane = (int64_t)C * T;
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int b = 0; b < A; ++b)
+        if (W::BT[j][b] != 0.f) s += u[i][b] * W::BT[j][b];
+      V[(i * A + j) * plane + idx] = s;
+    }
+}
+
+// one thread per (output channel, tile): y tile = A^T m A [+ bias] [+ addend]
+template <int M>
+__global__ void wino_output_kernel(const float *__restrict__ Mm,
+                                   const float *__restrict__ bias,
+                                   const float *__restrict__ addend,
+                                   float *__restrict__ y, int K, int H, int Wd,
+                                   int th, int tw, int64_t T) {
+  using W = WinoMat<M>;
+  constexpr int A = W::A;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)K * T) return;
+  const int64_t t = idx % T;
+  const int k = (int)(idx / T);
+  const int tc = (int)(t % tw);
+  const int tr = (int)((t / tw) % th);
+  const int n = (int)(t / ((int64_t)tw * th));
+  const int64_t plane = (int64_t)K * T;
+  float m[A][A];
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < A; ++j) m[i][j] = Mm[(i * A + j) * plane + idx];
+  float u[M][A];  // A^T m
+#pragma unroll
+  for (int a = 0; a < M; ++a)
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < A; ++i)
+        if (W::AT[a][i] != 0.f) s += W::AT[a][i] * m[i][j];
+      u[a][j] = s;
+    }
+  const float bk = bias ? bias[k] : 0.f;
+  const int64_t base = ((int64_t)n * K + k) * H * Wd;
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    const int h = tr * M + a;
+    if (h >= H) continue;
+#pragma unroll
+    for (int b = 0; b < M; ++b) {
+      const int ww = tc * M + b;
+      if (ww >= Wd) continue;
+      float s = bk;
+#pragma unroll
+      for (int j = 0; j < A; ++j)
+        if (W::AT[b][j] != 0.f) s += u[a][j] * W::AT[b][j];
+      const int64_t o = base + (int64_t)h * Wd + ww;
+      y[o] = addend ? s + addend[o] : s;
+    }
+  }
+}
+
+}  // namespace sa
+
+using namespace sa;
+
+static int wino_grid(int64_t n) { return (int)((n + 255) / 256); }
+
+int sa_wino_filter(int m, const float *w, float *U, int K, int C, int flip,
+                   hipStream_t s) {
+  if (K <= 0 || C <= 0 || (int64_t)K * C > ((int64_t)1 << 38)) return -2;
+  const dim3 grid(wino_grid((int64_t)K * C)), block(256);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_filter_kernel<2>, grid, block, 0, s, w, U, K, C,
+                       flip);
+  else if (m == 4)
+    hipLaunchKernelGGL(wino_filter_kernel<4>, grid, block, 0, s, w, U, K, C,
+                       flip);
+  else
+    return -2;
+  return 0;
+}
+
+int sa_wino_input(int m, const float *x, float *V, int N, int C, int H, int W,
+                  hipStream_t s) {
+  if (m != 2 && m != 4) return -2;
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return -2;
+  const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
+  const int64_t T = (int64_t)N * th * tw;
+  if ((int64_t)C * T > ((int64_t)1 << 38)) return -2;
+  const dim3 grid(wino_grid((int64_t)C * T)), block(256);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_input_kernel<2>, grid, block, 0, s, x, V, C, H, W,
+                       th, tw, T);
+  else
+    hipLaunchKernelGGL(wino_input_kernel<4>, grid, block, 0, s, x, V, C, H, W,
+                       th, tw, T);
+  return 0;
+}
+
+int sa_wino_output(int m, const float *M, const float *bias,
+                   const float *addend, float *y, int N, int K, int H, int W,
+                   hipStream_t s) {
+  if (m != 2 && m != 4) return -2;
+  if (N <= 0 || K <= 0 || H <= 0 || W <= 0) return -2;
+  const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
+  const int64_t T = (int64_t)N * th * tw;
+  if ((int64_t)K * T > ((int64_t)1 << 38)) return -2;
+  const dim3 grid(wino_grid((int64_t)K * T)), block(256);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_output_kernel<2>, grid, block, 0, s, M, bias,
+                       addend, y, K, H, W, th, tw, T);
+  else
+    hipLaunchKernelGGL(wino_output_kernel<4>, grid, block, 0, s, M, bias,
+                       addend, y, K, H, W, th, tw, T);
+  return 0;
+}

@@ -1456,3 +1456,59 @@ def test_gemm_16bit_unequal_reduction_slices(maths, dt, M, N, K):
     want = torch.relu(0.5 * ref + bias.double())
     np.testing.assert_allclose(c2.double().cpu().numpy(), want.numpy(),
                                atol=eps * scale)
+
+
+@pytest.mark.parametrize("m", [2, 4])
+@pytest.mark.parametrize("N,C,K,H,W", [(2, 16, 24, 14, 14), (3, 8, 8, 7, 7),
+                                       (1, 5, 3, 9, 13), (2, 32, 16, 28, 28),
+                                       (1, 3, 4, 2, 3)])
+def test_winograd_float32_routes(maths, m, N, C, K, H, W):
+    """F(2x2, 3x3) and F(4x4, 3x3): forward with bias and data gradient with
+    an addend, image sizes that are and are not multiples of the tile, against
+    the host convolution in float32."""
+    hm, cm, dev = maths
+    x = rnd(N, C, H, W, seed=1)
+    w = rnd(K, C, 3, 3, seed=2, lo=-0.5, hi=0.5)
+    b = rnd(K, seed=3)
+    dy = rnd(N, K, H, W, seed=4)
+    ad = rnd(N, C, H, W, seed=5)
+    y_ref = torch.nn.functional.conv2d(x, w, b, stride=1, padding=1)
+    dx_ref = torch.nn.functional.conv_transpose2d(dy, w, stride=1,
+                                                  padding=1) + ad
+    y = torch.empty(N, K, H, W, device=dev.torch_device)
+    assert hm._winograd(m, 0, g(x, dev), g(w, dev), g(b, dev), None, y)
+    dx = torch.empty(N, C, H, W, device=dev.torch_device)
+    assert hm._winograd(m, 1, g(dy, dev), g(w, dev), None, g(ad, dev), dx)
+    tol = 2e-5 if m == 2 else 1e-4
+    scale = float(y_ref.abs().max())
+    assert float((y.cpu() - y_ref).abs().max()) <= tol * scale
+    scale = float(dx_ref.abs().max())
+    assert float((dx.cpu() - dx_ref).abs().max()) <= tol * scale
+
+
+def test_winograd_route_is_chosen_by_measurement(maths, monkeypatch):
+    """A float32 3x3 layer met for the first time is timed on the direct
+    kernels and both transforms; whichever wins, forward and data gradient
+    agree with the host convolution, and the choice is kept as a plan."""
+    import singa_amd.core.math_hip as mh
+    hm, cm, dev = maths
+    monkeypatch.setenv("SINGA_CONV_PLAN_CACHE", "0")
+    monkeypatch.setattr(type(hm), "_plan_file", None)
+    N, C, K, H = 8, 64, 64, 14
+    x, w = rnd(N, C, H, H, seed=6), rnd(K, C, 3, 3, seed=7, lo=-.2, hi=.2)
+    dy = rnd(N, K, H, H, seed=8)
+    y = torch.empty(N, K, H, H, device=dev.torch_device)
+    dx = torch.empty(N, C, H, H, device=dev.torch_device)
+    for _ in range(2):      # measured, then from the plan
+        hm.conv_fwd(g(x, dev), g(w, dev), None, y, (1, 1), (1, 1), 1)
+        hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (1, 1), (1, 1), 1)
+        y_ref = torch.nn.functional.conv2d(x, w, None, stride=1, padding=1)
+        dx_ref = torch.nn.functional.conv_transpose2d(dy, w, stride=1,
+                                                      padding=1)
+        assert float((y.cpu() - y_ref).abs().max()) <= \
+            1e-4 * float(y_ref.abs().max())
+        assert float((dx.cpu() - dx_ref).abs().max()) <= \
+            1e-4 * float(dx_ref.abs().max())
+    keys = [k for k in type(hm)._conv_plans if k[0] == "w32"]
+    assert any(k[2] == (N, C, H, H) for k in keys), keys
+    monkeypatch.setattr(type(hm), "_plan_file", None)

@@ -1131,12 +1131,48 @@ class HipMath(object):
         M = self._tmp(P * KO * T).view(P, KO, T)
         s = self._s()
         self.k.wino_filter(m, w.data_ptr(), U.data_ptr(), K, C, mode == 1, s)
-        self.k.wino_input(m, act.data_ptr(), V.data_ptr(), N, CI, H, W, s)
+        self.k.wino_input(m, act.data_ptr(), V.data_ptr(), N, CI, H, W, 1, s)
         self.gemm(1.0, U, V, 0.0, M)
         self.k.wino_output(m, M.data_ptr(),
                            bias.data_ptr() if bias is not None else 0,
                            addend.data_ptr() if addend is not None else 0,
                            out.data_ptr(), N, KO, H, W, s)
+        return True
+
+    @staticmethod
+    def _winograd_slices(P, K, C, T):
+        """Into how many slices the tile sum of a Winograd weight gradient is
+        cut: enough 64 x 64 output tiles for the chip, slices not shorter
+        than 128 tiles."""
+        tiles = P * (-(-K // 64)) * (-(-C // 64))
+        best = 1
+        for sl in (2, 4, 7, 8, 14, 16, 28, 32):
+            if tiles * best >= 512:
+                break
+            if T % sl == 0 and T // sl >= 128:
+                best = sl
+        return best
+
+    def _winograd_wgrad(self, m, dy, x, dw):
+        """dw = weight gradient of the 3x3 / stride 1 / pad 1 convolution
+        through F(m x m, 3 x 3): input transform of x, the transposed output
+        transform of dy, (m + 2)^2 products [K x tiles] x [tiles x C] (the
+        tile sum cut into slices that run as further batch entries), and the
+        transposed filter transform, which also adds the slices up."""
+        N, C, H, W = x.shape
+        K = dy.shape[1]
+        P = (m + 2) * (m + 2)
+        T = N * (-(-H // m)) * (-(-W // m))
+        S = self._winograd_slices(P, K, C, T)
+        Tp = T // S
+        V = self._tmp(P * C * T).view(P * S, C, Tp)
+        dM = self._tmp(P * K * T).view(P * S, K, Tp)
+        dU = self._tmp(P * S * K * C).view(P * S, K, C)
+        s = self._s()
+        self.k.wino_input(m, x.data_ptr(), V.data_ptr(), N, C, H, W, S, s)
+        self.k.wino_outgrad(m, dy.data_ptr(), dM.data_ptr(), N, K, H, W, S, s)
+        self.gemm(1.0, dM, V.transpose(1, 2), 0.0, dU)
+        self.k.wino_filtergrad(m, dU.data_ptr(), dw.data_ptr(), K, C, S, s)
         return True
 
     def _route32(self, mode, act, w, bias, addend, out, direct):
@@ -1161,18 +1197,23 @@ class HipMath(object):
                     return True
                 plan = self._measure_routes16([
                     ((0, 0), run_direct),
-                    ((2, 0), lambda: self._winograd(2, mode, act, w, bias,
-                                                    addend, out)),
-                    ((4, 0), lambda: self._winograd(4, mode, act, w, bias,
-                                                    addend, out))])
+                    ((2, 0), lambda: self._winograd_any(2, mode, act, w, bias,
+                                                        addend, out)),
+                    ((4, 0), lambda: self._winograd_any(4, mode, act, w, bias,
+                                                        addend, out))])
                 if plan is not None:
                     self._persist_plan(name, plan)
             if plan is not None:
                 self._conv_plans[key] = plan
         if plan is not None and plan[0] in (2, 4):
-            self._winograd(plan[0], mode, act, w, bias, addend, out)
+            self._winograd_any(plan[0], mode, act, w, bias, addend, out)
             return None
         return direct()
+
+    def _winograd_any(self, m, mode, act, w, bias, addend, out):
+        if mode == 2:       # act = dy, w = x, out = dw
+            return self._winograd_wgrad(m, act, w, out)
+        return self._winograd(m, mode, act, w, bias, addend, out)
 
     @property
     def STAT_COPIES(self):
@@ -1353,6 +1394,21 @@ class HipMath(object):
             return
         if self._wgrad16(dy, x, dw, stride, pad, groups):
             return
+        if self._winograd_applies(dy, dw, x, stride, pad, groups) and \
+                dw.is_contiguous():
+            # route timing runs the direct kernels more than once: only the
+            # first of those launches may rely on dw holding zeros
+            state = {"zeroed": zeroed}
+
+            def direct():
+                self._conv_bwd_weight_direct(dy, x, dw, stride, pad, groups,
+                                             state["zeroed"])
+                state["zeroed"] = False
+            self._route32(2, dy, x, None, None, dw, direct)
+            return
+        self._conv_bwd_weight_direct(dy, x, dw, stride, pad, groups, zeroed)
+
+    def _conv_bwd_weight_direct(self, dy, x, dw, stride, pad, groups, zeroed):
         g = self._geom(x.shape, dw.shape, dy.shape, stride, pad, groups)
         key = (tuple(x.shape), tuple(dw.shape), tuple(stride), tuple(pad),
                groups, _code(x))

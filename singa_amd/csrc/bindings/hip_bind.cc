@@ -559,9 +559,19 @@ PYBIND11_MODULE(_hip, m) {
                          flip ? 1 : 0, S(s)), "wino_filter");
   });
   m.def("wino_input", [](int mm, uintptr_t x, uintptr_t V, int N, int C, int H,
-                         int W, uintptr_t s) {
+                         int W, int slices, uintptr_t s) {
     check(sa_wino_input(mm, (const float *)CP(x), (float *)P(V), N, C, H, W,
-                        S(s)), "wino_input");
+                        slices, S(s)), "wino_input");
+  });
+  m.def("wino_outgrad", [](int mm, uintptr_t dy, uintptr_t dM, int N, int K,
+                           int H, int W, int slices, uintptr_t s) {
+    check(sa_wino_outgrad(mm, (const float *)CP(dy), (float *)P(dM), N, K, H,
+                          W, slices, S(s)), "wino_outgrad");
+  });
+  m.def("wino_filtergrad", [](int mm, uintptr_t dU, uintptr_t dw, int K, int C,
+                              int slices, uintptr_t s) {
+    check(sa_wino_filtergrad(mm, (const float *)CP(dU), (float *)P(dw), K, C,
+                             slices, S(s)), "wino_filtergrad");
   });
   m.def("wino_output", [](int mm, uintptr_t M, uintptr_t bias,
                           uintptr_t addend, uintptr_t y, int N, int K, int H,

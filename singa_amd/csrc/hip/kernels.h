@@ -454,9 +454,16 @@ struct PackBatch {
 // channel roles (the data gradient's filter), KO = C, CI = K
 int sa_wino_filter(int m, const float *w, float *U, int K, int C, int flip,
                    hipStream_t s);
-// V[(m+2)^2][C][T] from x[N][C][H][W], T = N * ceil(H / m) * ceil(W / m)
+// V[(m+2)^2][C][T] from x[N][C][H][W], T = N * ceil(H / m) * ceil(W / m); with
+// `slices` > 1 (a divisor of T) the layout is [(m+2)^2 * slices][C][T / slices]
 int sa_wino_input(int m, const float *x, float *V, int N, int C, int H, int W,
-                  hipStream_t s);
+                  int slices, hipStream_t s);
+// weight gradient: dM[(m+2)^2 * slices][K][T / slices] from dy[N][K][H][W], and
+// dw[K][C][3][3] from dU[(m+2)^2 * slices][K][C] (summed over the slices)
+int sa_wino_outgrad(int m, const float *dy, float *dM, int N, int K, int H,
+                    int W, int slices, hipStream_t s);
+int sa_wino_filtergrad(int m, const float *dU, float *dw, int K, int C,
+                       int slices, hipStream_t s);
 // y[N][K][H][W] = inverse transform of M[(m+2)^2][K][T] [+ bias[K]] [+ addend]
 int sa_wino_output(int m, const float *M, const float *bias,
                    const float *addend, float *y, int N, int K, int H, int W,

@@ -98,10 +98,13 @@ __global__ void wino_filter_kernel(const float *__restrict__ w,
 
 // one thread per (channel, tile); tiles are numbered (n, tile row, tile
 // column) with the column fastest, so a wave writes consecutive words of V
+// With Tp < T the tiles are cut into T / Tp slices and slice s of plane p is
+// the matrix [(p * S + s)][C][Tp]: the weight gradient sums over the tiles,
+// and the slices are the split of that reduction over more workgroups.
 template <int M>
 __global__ void wino_input_kernel(const float *__restrict__ x,
                                   float *__restrict__ V, int C, int H, int Wd,
-                                  int th, int tw, int64_t T) {
+                                  int th, int tw, int64_t T, int64_t Tp) {
   using W = WinoMat<M>;
   constexpr int A = W::A;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,6 +139,7 @@ __global__ void wino_input_kernel(const float *__restrict__ x,
       u[i][b] = s;
     }
   const int64_t plane = (int64_t)C * T;
+  const int64_t at = ((t / Tp) * C + c) * Tp + t % Tp;
 #pragma unroll
   for (int i = 0; i < A; ++i)
 #pragma unroll
@@ -144,7 +148,98 @@ __global__ void wino_input_kernel(const float *__restrict__ x,
 #pragma unroll
       for (int b = 0; b < A; ++b)
         if (W::BT[j][b] != 0.f) s += u[i][b] * W::BT[j][b];
-      V[(i * A + j) * plane + idx] = s;
+      V[(i * A + j) * plane + at] = s;
+    }
+}
+
+// dM[p][k][t] = (A dY A^T)[p] of the m x m tile t of dy (zero outside the
+// image): the gradient of the loss with respect to the products M.  Same
+// slice layout as wino_input_kernel.
+template <int M>
+__global__ void wino_outgrad_kernel(const float *__restrict__ dy,
+                                    float *__restrict__ dM, int K, int H,
+                                    int Wd, int th, int tw, int64_t T,
+                                    int64_t Tp) {
+  using W = WinoMat<M>;
+  constexpr int A = W::A;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)K * T) return;
+  const int64_t t = idx % T;
+  const int k = (int)(idx / T);
+  const int tc = (int)(t % tw);
+  const int tr = (int)((t / tw) % th);
+  const int n = (int)(t / ((int64_t)tw * th));
+  const float *img = dy + ((int64_t)n * K + k) * H * Wd;
+  float d[M][M];
+#pragma unroll
+  for (int a = 0; a < M; ++a) {
+    const int h = tr * M + a;
+#pragma unroll
+    for (int b = 0; b < M; ++b) {
+      const int ww = tc * M + b;
+      d[a][b] = (h < H && ww < Wd) ? img[(int64_t)h * Wd + ww] : 0.f;
+    }
+  }
+  float u[A][M];  // A dY
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int b = 0; b < M; ++b) {
+      float s = 0.f;
+#pragma unroll
+      for (int a = 0; a < M; ++a)
+        if (W::AT[a][i] != 0.f) s += W::AT[a][i] * d[a][b];
+      u[i][b] = s;
+    }
+  const int64_t plane = (int64_t)K * T;
+  const int64_t at = ((t / Tp) * K + k) * Tp + t % Tp;
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int b = 0; b < M; ++b)
+        if (W::AT[b][j] != 0.f) s += u[i][b] * W::AT[b][j];
+      dM[(i * A + j) * plane + at] = s;
+    }
+}
+
+// dw[k][c] (3 x 3) = G^T (sum over the S slices of dU[p * S + s][k][c]) G
+template <int M>
+__global__ void wino_filtergrad_kernel(const float *__restrict__ dU,
+                                       float *__restrict__ dw, int K, int C,
+                                       int S) {
+  using W = WinoMat<M>;
+  constexpr int A = W::A;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t plane = (int64_t)K * C;
+  if (idx >= plane) return;
+  float t[3][A];  // G^T dU
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int j = 0; j < A; ++j) t[r][j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < A; ++i)
+#pragma unroll
+    for (int j = 0; j < A; ++j) {
+      const float *src = dU + (int64_t)(i * A + j) * S * plane + idx;
+      float v = 0.f;
+      for (int s = 0; s < S; ++s) v += src[s * plane];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        if (W::G[i][r] != 0.f) t[r][j] += W::G[i][r] * v;
+    }
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < A; ++j)
+        if (W::G[j][q] != 0.f) v += t[r][j] * W::G[j][q];
+      dw[idx * 9 + r * 3 + q] = v;
     }
 }
 
@@ -223,19 +318,54 @@ int sa_wino_filter(int m, const float *w, float *U, int K, int C, int flip,
 }
 
 int sa_wino_input(int m, const float *x, float *V, int N, int C, int H, int W,
-                  hipStream_t s) {
+                  int slices, hipStream_t s) {
   if (m != 2 && m != 4) return -2;
-  if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return -2;
+  if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || slices <= 0) return -2;
   const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
   const int64_t T = (int64_t)N * th * tw;
+  if (T % slices) return -2;
+  const int64_t Tp = T / slices;
   if ((int64_t)C * T > ((int64_t)1 << 38)) return -2;
   const dim3 grid(wino_grid((int64_t)C * T)), block(256);
   if (m == 2)
     hipLaunchKernelGGL(wino_input_kernel<2>, grid, block, 0, s, x, V, C, H, W,
-                       th, tw, T);
+                       th, tw, T, Tp);
   else
     hipLaunchKernelGGL(wino_input_kernel<4>, grid, block, 0, s, x, V, C, H, W,
-                       th, tw, T);
+                       th, tw, T, Tp);
+  return 0;
+}
+
+int sa_wino_outgrad(int m, const float *dy, float *dM, int N, int K, int H,
+                    int W, int slices, hipStream_t s) {
+  if (m != 2 && m != 4) return -2;
+  if (N <= 0 || K <= 0 || H <= 0 || W <= 0 || slices <= 0) return -2;
+  const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
+  const int64_t T = (int64_t)N * th * tw;
+  if (T % slices || (int64_t)K * T > ((int64_t)1 << 38)) return -2;
+  const int64_t Tp = T / slices;
+  const dim3 grid(wino_grid((int64_t)K * T)), block(256);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_outgrad_kernel<2>, grid, block, 0, s, dy, dM, K, H,
+                       W, th, tw, T, Tp);
+  else
+    hipLaunchKernelGGL(wino_outgrad_kernel<4>, grid, block, 0, s, dy, dM, K, H,
+                       W, th, tw, T, Tp);
+  return 0;
+}
+
+int sa_wino_filtergrad(int m, const float *dU, float *dw, int K, int C,
+                       int slices, hipStream_t s) {
+  if (K <= 0 || C <= 0 || slices <= 0) return -2;
+  const dim3 grid(wino_grid((int64_t)K * C)), block(256);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_filtergrad_kernel<2>, grid, block, 0, s, dU, dw, K,
+                       C, slices);
+  else if (m == 4)
+    hipLaunchKernelGGL(wino_filtergrad_kernel<4>, grid, block, 0, s, dU, dw, K,
+                       C, slices);
+  else
+    return -2;
   return 0;
 }
 

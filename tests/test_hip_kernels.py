@@ -1484,6 +1484,34 @@ def test_winograd_float32_routes(maths, m, N, C, K, H, W):
     assert float((y.cpu() - y_ref).abs().max()) <= tol * scale
     scale = float(dx_ref.abs().max())
     assert float((dx.cpu() - dx_ref).abs().max()) <= tol * scale
+    # weight gradient, float64 reference
+    xd = x.double().requires_grad_(False)
+    wd = w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(xd, wd, None, stride=1, padding=1).backward(
+        dy.double())
+    dw = torch.full((K, C, 3, 3), 7.0, device=dev.torch_device)
+    assert hm._winograd_wgrad(m, g(dy, dev), g(x, dev), dw)
+    scale = float(wd.grad.abs().max())
+    assert float((dw.cpu().double() - wd.grad).abs().max()) <= tol * scale
+
+
+@pytest.mark.parametrize("m", [2, 4])
+def test_winograd_weight_gradient_sliced_tile_sum(maths, m):
+    """Few output tiles, many image tiles: the tile sum is cut into slices
+    (further batch entries of the product) that the filter transform adds."""
+    hm, cm, dev = maths
+    N, C, K, H = 8, 16, 16, 56
+    P, T = (m + 2) ** 2, N * (-(-H // m)) ** 2
+    assert hm._winograd_slices(P, K, C, T) > 1
+    x, dy = rnd(N, C, H, H, seed=11), rnd(N, K, H, H, seed=12)
+    wd = torch.zeros(K, C, 3, 3, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(x.double(), wd, None, stride=1,
+                               padding=1).backward(dy.double())
+    dw = torch.empty(K, C, 3, 3, device=dev.torch_device)
+    assert hm._winograd_wgrad(m, g(dy, dev), g(x, dev), dw)
+    scale = float(wd.grad.abs().max())
+    assert float((dw.cpu().double() - wd.grad).abs().max()) <= \
+        (2e-5 if m == 2 else 1e-4) * scale
 
 
 def test_winograd_route_is_chosen_by_measurement(maths, monkeypatch):
@@ -1499,9 +1527,16 @@ def test_winograd_route_is_chosen_by_measurement(maths, monkeypatch):
     dy = rnd(N, K, H, H, seed=8)
     y = torch.empty(N, K, H, H, device=dev.torch_device)
     dx = torch.empty(N, C, H, H, device=dev.torch_device)
+    dw = torch.empty(K, C, 3, 3, device=dev.torch_device)
+    wd = w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(x.double(), wd, None, stride=1,
+                               padding=1).backward(dy.double())
     for _ in range(2):      # measured, then from the plan
         hm.conv_fwd(g(x, dev), g(w, dev), None, y, (1, 1), (1, 1), 1)
         hm.conv_bwd_data(g(dy, dev), g(w, dev), dx, (1, 1), (1, 1), 1)
+        hm.conv_bwd_weight(g(dy, dev), g(x, dev), dw, (1, 1), (1, 1), 1)
+        assert float((dw.cpu().double() - wd.grad).abs().max()) <= \
+            1e-4 * float(wd.grad.abs().max())
         y_ref = torch.nn.functional.conv2d(x, w, None, stride=1, padding=1)
         dx_ref = torch.nn.functional.conv_transpose2d(dy, w, stride=1,
                                                       padding=1)

@@ -39,7 +39,7 @@ def main():
     hm = dev.math
     td = dev.torch_device
     total = {"direct": 0.0, "best": 0.0}
-    print("layer C,K,HW xcount |   fwd direct   F2     F4  |  bwdD direct   F2     F4  | max rel dev F2 / F4")
+    print("layer C,K,HW xcount |   fwd direct   F2     F4  |  bwdD direct   F2     F4  |  bwdW direct   F2     F4  | max rel dev F2 / F4 per pass")
     for C, K, HW, count in LAYERS:
         x = torch.randn(batch, C, HW, HW, device=td)
         w = torch.randn(K, C, 3, 3, device=td) * 0.05
@@ -47,25 +47,28 @@ def main():
         y = torch.empty(batch, K, HW, HW, device=td)
         dx = torch.empty(batch, C, HW, HW, device=td)
         row, devs = [], []
-        for mode, act, out in ((0, x, y), (1, dy, dx)):
+        dw = torch.empty(K, C, 3, 3, device=td)
+        for mode, act, out in ((0, x, y), (1, dy, dx), (2, dy, dw)):
             if mode == 0:
                 d = lambda: hm._conv_fwd_direct(x, w, None, y, (1, 1), (1, 1), 1, None, None)
-            else:
+            elif mode == 1:
                 d = lambda: hm._conv_bwd_data_direct(dy, w, dx, (1, 1), (1, 1), 1, None, None)
+            else:
+                d = lambda: hm._conv_bwd_weight_direct(dy, x, dw, (1, 1), (1, 1), 1, False)
             t0 = timed(d, dev)
             ref = out.clone()
             ts = [t0]
             for m in (2, 4):
-                f = lambda: hm._winograd(m, mode, act, w, None, None, out)
+                f = lambda: hm._winograd_any(m, mode, act, x if mode == 2 else w, None, None, out)
                 ts.append(timed(f, dev))
                 devs.append(float((out - ref).abs().max() / ref.abs().max()))
             row.append(ts)
             total["direct"] += count * t0
             total["best"] += count * min(ts)
-        print("%d,%d,%d x%d | %10.3f %6.3f %6.3f | %10.3f %6.3f %6.3f | %s" % (
-            C, K, HW, count, *row[0], *row[1],
+        print("%d,%d,%d x%d | %10.3f %6.3f %6.3f | %10.3f %6.3f %6.3f | %10.3f %6.3f %6.3f | %s" % (
+            C, K, HW, count, *row[0], *row[1], *row[2],
             " ".join("%.1e" % v for v in devs)), flush=True)
-    print("sum over the step's stride-1 3x3 layers, fwd + bwdD: direct %.3f ms, best route per layer %.3f ms"
+    print("sum over the step's stride-1 3x3 layers, all three passes: direct %.3f ms, best route per layer %.3f ms"
           % (total["direct"], total["best"]))
 
 

@@ -1130,8 +1130,8 @@ class HipMath(object):
         V = self._tmp(P * CI * T).view(P, CI, T)
         M = self._tmp(P * KO * T).view(P, KO, T)
         s = self._s()
-        self.k.wino_filter(m, w.data_ptr(), U.data_ptr(), K, C, mode == 1, s)
-        self.k.wino_input(m, act.data_ptr(), V.data_ptr(), N, CI, H, W, 1, s)
+        self.k.wino_prepare(m, act.data_ptr(), V.data_ptr(), N, CI, H, W,
+                            w.data_ptr(), U.data_ptr(), K, C, mode == 1, s)
         self.gemm(1.0, U, V, 0.0, M)
         self.k.wino_output(m, M.data_ptr(),
                            bias.data_ptr() if bias is not None else 0,
@@ -1169,8 +1169,8 @@ class HipMath(object):
         dM = self._tmp(P * K * T).view(P * S, K, Tp)
         dU = self._tmp(P * S * K * C).view(P * S, K, C)
         s = self._s()
-        self.k.wino_input(m, x.data_ptr(), V.data_ptr(), N, C, H, W, S, s)
-        self.k.wino_outgrad(m, dy.data_ptr(), dM.data_ptr(), N, K, H, W, S, s)
+        self.k.wino_prepare_grad(m, x.data_ptr(), V.data_ptr(), dy.data_ptr(),
+                                 dM.data_ptr(), N, C, K, H, W, S, s)
         self.gemm(1.0, dM, V.transpose(1, 2), 0.0, dU)
         self.k.wino_filtergrad(m, dU.data_ptr(), dw.data_ptr(), K, C, S, s)
         return True

@@ -563,6 +563,20 @@ PYBIND11_MODULE(_hip, m) {
     check(sa_wino_input(mm, (const float *)CP(x), (float *)P(V), N, C, H, W,
                         slices, S(s)), "wino_input");
   });
+  m.def("wino_prepare", [](int mm, uintptr_t x, uintptr_t V, int N, int CI,
+                           int H, int W, uintptr_t w, uintptr_t U, int K,
+                           int C, bool flip, uintptr_t s) {
+    check(sa_wino_prepare(mm, (const float *)CP(x), (float *)P(V), N, CI, H, W,
+                          (const float *)CP(w), (float *)P(U), K, C,
+                          flip ? 1 : 0, S(s)), "wino_prepare");
+  });
+  m.def("wino_prepare_grad", [](int mm, uintptr_t x, uintptr_t V, uintptr_t dy,
+                                uintptr_t dM, int N, int C, int K, int H,
+                                int W, int slices, uintptr_t s) {
+    check(sa_wino_prepare_grad(mm, (const float *)CP(x), (float *)P(V),
+                               (const float *)CP(dy), (float *)P(dM), N, C, K,
+                               H, W, slices, S(s)), "wino_prepare_grad");
+  });
   m.def("wino_outgrad", [](int mm, uintptr_t dy, uintptr_t dM, int N, int K,
                            int H, int W, int slices, uintptr_t s) {
     check(sa_wino_outgrad(mm, (const float *)CP(dy), (float *)P(dM), N, K, H,

@@ -464,6 +464,14 @@ int sa_wino_outgrad(int m, const float *dy, float *dM, int N, int K, int H,
                     int W, int slices, hipStream_t s);
 int sa_wino_filtergrad(int m, const float *dU, float *dw, int K, int C,
                        int slices, hipStream_t s);
+// sa_wino_input + sa_wino_filter, and sa_wino_input + sa_wino_outgrad, as one
+// launch each (CI = C of w forward, K with flip)
+int sa_wino_prepare(int m, const float *x, float *V, int N, int CI, int H,
+                    int W, const float *w, float *U, int K, int C, int flip,
+                    hipStream_t s);
+int sa_wino_prepare_grad(int m, const float *x, float *V, const float *dy,
+                         float *dM, int N, int C, int K, int H, int W,
+                         int slices, hipStream_t s);
 // y[N][K][H][W] = inverse transform of M[(m+2)^2][K][T] [+ bias[K]] [+ addend]
 int sa_wino_output(int m, const float *M, const float *bias,
                    const float *addend, float *y, int N, int K, int H, int W,

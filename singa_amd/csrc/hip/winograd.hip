@@ -62,13 +62,13 @@ template <> struct WinoMat<4> {
 // (ko, ci) = (k, c) of w[K][C][3][3] forward, (c, k) with the taps reversed for
 // the data gradient
 template <int M>
-__global__ void wino_filter_kernel(const float *__restrict__ w,
-                                   float *__restrict__ U, int K, int C,
-                                   int flip) {
+__device__ __forceinline__ void wino_filter_body(int64_t idx,
+                                                 const float *__restrict__ w,
+                                                 float *__restrict__ U, int K,
+                                                 int C, int flip) {
   using W = WinoMat<M>;
   constexpr int A = W::A;
   const int KO = flip ? C : K, CI = flip ? K : C;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)KO * CI) return;
   const int ci = (int)(idx % CI), ko = (int)(idx / CI);
   const float *src = flip ? w + ((int64_t)ci * C + ko) * 9
@@ -102,12 +102,13 @@ __global__ void wino_filter_kernel(const float *__restrict__ w,
 // the matrix [(p * S + s)][C][Tp]: the weight gradient sums over the tiles,
 // and the slices are the split of that reduction over more workgroups.
 template <int M>
-__global__ void wino_input_kernel(const float *__restrict__ x,
-                                  float *__restrict__ V, int C, int H, int Wd,
-                                  int th, int tw, int64_t T, int64_t Tp) {
+__device__ __forceinline__ void wino_input_body(int64_t idx,
+                                                const float *__restrict__ x,
+                                                float *__restrict__ V, int C,
+                                                int H, int Wd, int th, int tw,
+                                                int64_t T, int64_t Tp) {
   using W = WinoMat<M>;
   constexpr int A = W::A;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)C * T) return;
   const int64_t t = idx % T;
   const int c = (int)(idx / T);
@@ -156,13 +157,11 @@ __global__ void wino_input_kernel(const float *__restrict__ x,
 // image): the gradient of the loss with respect to the products M.  Same
 // slice layout as wino_input_kernel.
 template <int M>
-__global__ void wino_outgrad_kernel(const float *__restrict__ dy,
-                                    float *__restrict__ dM, int K, int H,
-                                    int Wd, int th, int tw, int64_t T,
-                                    int64_t Tp) {
+__device__ __forceinline__ void wino_outgrad_body(
+    int64_t idx, const float *__restrict__ dy, float *__restrict__ dM, int K,
+    int H, int Wd, int th, int tw, int64_t T, int64_t Tp) {
   using W = WinoMat<M>;
   constexpr int A = W::A;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)K * T) return;
   const int64_t t = idx % T;
   const int k = (int)(idx / T);
@@ -203,6 +202,68 @@ __global__ void wino_outgrad_kernel(const float *__restrict__ dy,
         if (W::AT[b][j] != 0.f) s += u[i][b] * W::AT[b][j];
       dM[(i * A + j) * plane + at] = s;
     }
+}
+
+// What has to happen before the batched product, as ONE launch (the pieces
+// are independent and short; at batch 32 a launch of its own costs each of
+// them more than its work): the first `nb_first` workgroups transform the
+// image, the others the filter (forward / data gradient) or dy (weight
+// gradient).
+template <int M>
+__global__ void wino_prepare_kernel(const float *__restrict__ x,
+                                    float *__restrict__ V, int C, int H,
+                                    int Wd, int th, int tw, int64_t T,
+                                    const float *__restrict__ w,
+                                    float *__restrict__ U, int K, int Cw,
+                                    int flip, int nb_first) {
+  if ((int)blockIdx.x < nb_first)
+    wino_input_body<M>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, x, V,
+                       C, H, Wd, th, tw, T, T);
+  else
+    wino_filter_body<M>(
+        (int64_t)(blockIdx.x - nb_first) * blockDim.x + threadIdx.x, w, U, K,
+        Cw, flip);
+}
+
+template <int M>
+__global__ void wino_prepare_grad_kernel(const float *__restrict__ x,
+                                         float *__restrict__ V, int C,
+                                         const float *__restrict__ dy,
+                                         float *__restrict__ dM, int K, int H,
+                                         int Wd, int th, int tw, int64_t T,
+                                         int64_t Tp, int nb_first) {
+  if ((int)blockIdx.x < nb_first)
+    wino_input_body<M>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, x, V,
+                       C, H, Wd, th, tw, T, Tp);
+  else
+    wino_outgrad_body<M>(
+        (int64_t)(blockIdx.x - nb_first) * blockDim.x + threadIdx.x, dy, dM,
+        K, H, Wd, th, tw, T, Tp);
+}
+
+template <int M>
+__global__ void wino_filter_kernel(const float *__restrict__ w,
+                                   float *__restrict__ U, int K, int C,
+                                   int flip) {
+  wino_filter_body<M>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, w, U, K,
+                      C, flip);
+}
+
+template <int M>
+__global__ void wino_input_kernel(const float *__restrict__ x,
+                                  float *__restrict__ V, int C, int H, int Wd,
+                                  int th, int tw, int64_t T, int64_t Tp) {
+  wino_input_body<M>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, x, V, C,
+                     H, Wd, th, tw, T, Tp);
+}
+
+template <int M>
+__global__ void wino_outgrad_kernel(const float *__restrict__ dy,
+                                    float *__restrict__ dM, int K, int H,
+                                    int Wd, int th, int tw, int64_t T,
+                                    int64_t Tp) {
+  wino_outgrad_body<M>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, dy, dM,
+                       K, H, Wd, th, tw, T, Tp);
 }
 
 // dw[k][c] (3 x 3) = G^T (sum over the S slices of dU[p * S + s][k][c]) G
@@ -384,5 +445,45 @@ int sa_wino_output(int m, const float *M, const float *bias,
   else
     hipLaunchKernelGGL(wino_output_kernel<4>, grid, block, 0, s, M, bias,
                        addend, y, K, H, W, th, tw, T);
+  return 0;
+}
+
+int sa_wino_prepare(int m, const float *x, float *V, int N, int CI, int H,
+                    int W, const float *w, float *U, int K, int C, int flip,
+                    hipStream_t s) {
+  if (m != 2 && m != 4) return -2;
+  if (N <= 0 || CI <= 0 || H <= 0 || W <= 0 || K <= 0 || C <= 0) return -2;
+  if (CI != (flip ? K : C)) return -2;
+  const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
+  const int64_t T = (int64_t)N * th * tw;
+  if ((int64_t)CI * T > ((int64_t)1 << 38)) return -2;
+  const int nb_first = wino_grid((int64_t)CI * T);
+  const dim3 grid(nb_first + wino_grid((int64_t)K * C)), block(256);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_prepare_kernel<2>, grid, block, 0, s, x, V, CI, H,
+                       W, th, tw, T, w, U, K, C, flip, nb_first);
+  else
+    hipLaunchKernelGGL(wino_prepare_kernel<4>, grid, block, 0, s, x, V, CI, H,
+                       W, th, tw, T, w, U, K, C, flip, nb_first);
+  return 0;
+}
+
+int sa_wino_prepare_grad(int m, const float *x, float *V, const float *dy,
+                         float *dM, int N, int C, int K, int H, int W,
+                         int slices, hipStream_t s) {
+  if (m != 2 && m != 4) return -2;
+  if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || slices <= 0) return -2;
+  const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
+  const int64_t T = (int64_t)N * th * tw;
+  if (T % slices || (int64_t)(C > K ? C : K) * T > ((int64_t)1 << 38))
+    return -2;
+  const int nb_first = wino_grid((int64_t)C * T);
+  const dim3 grid(nb_first + wino_grid((int64_t)K * T)), block(256);
+  if (m == 2)
+    hipLaunchKernelGGL(wino_prepare_grad_kernel<2>, grid, block, 0, s, x, V, C,
+                       dy, dM, K, H, W, th, tw, T, T / slices, nb_first);
+  else
+    hipLaunchKernelGGL(wino_prepare_grad_kernel<4>, grid, block, 0, s, x, V, C,
+                       dy, dM, K, H, W, th, tw, T, T / slices, nb_first);
   return 0;
 }

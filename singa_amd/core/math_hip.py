@@ -1108,7 +1108,8 @@ class HipMath(object):
     @staticmethod
     def _winograd_applies(act, w, out, stride, pad, groups):
         return (_CONV_WINOGRAD != "0" and groups == 1 and
-                act.dtype == torch.float32 and w.dtype == torch.float32 and
+                act.dtype in _FLOATS and w.dtype == act.dtype and
+                out.dtype == act.dtype and
                 tuple(w.shape[2:]) == (3, 3) and tuple(stride) == (1, 1) and
                 tuple(pad) == (1, 1) and act.is_contiguous() and
                 out.is_contiguous() and
@@ -1126,14 +1127,15 @@ class HipMath(object):
         assert (KO, CI) == ((K, C) if mode == 0 else (C, K))
         P = (m + 2) * (m + 2)
         T = N * (-(-H // m)) * (-(-W // m))
-        U = self._tmp(P * KO * CI).view(P, KO, CI)
-        V = self._tmp(P * CI * T).view(P, CI, T)
-        M = self._tmp(P * KO * T).view(P, KO, T)
+        dt, code = act.dtype, _code(act)
+        U = self._tmp(P * KO * CI, dt).view(P, KO, CI)
+        V = self._tmp(P * CI * T, dt).view(P, CI, T)
+        M = self._tmp(P * KO * T, dt).view(P, KO, T)
         s = self._s()
-        self.k.wino_prepare(m, act.data_ptr(), V.data_ptr(), N, CI, H, W,
-                            w.data_ptr(), U.data_ptr(), K, C, mode == 1, s)
+        self.k.wino_prepare(code, m, act.data_ptr(), V.data_ptr(), N, CI, H,
+                            W, w.data_ptr(), U.data_ptr(), K, C, mode == 1, s)
         self.gemm(1.0, U, V, 0.0, M)
-        self.k.wino_output(m, M.data_ptr(),
+        self.k.wino_output(code, m, M.data_ptr(),
                            bias.data_ptr() if bias is not None else 0,
                            addend.data_ptr() if addend is not None else 0,
                            out.data_ptr(), N, KO, H, W, s)
@@ -1165,14 +1167,16 @@ class HipMath(object):
         T = N * (-(-H // m)) * (-(-W // m))
         S = self._winograd_slices(P, K, C, T)
         Tp = T // S
+        assert x.dtype == torch.float32     # (16-bit sums would be rounded)
         V = self._tmp(P * C * T).view(P * S, C, Tp)
         dM = self._tmp(P * K * T).view(P * S, K, Tp)
         dU = self._tmp(P * S * K * C).view(P * S, K, C)
         s = self._s()
-        self.k.wino_prepare_grad(m, x.data_ptr(), V.data_ptr(), dy.data_ptr(),
-                                 dM.data_ptr(), N, C, K, H, W, S, s)
+        self.k.wino_prepare_grad(0, m, x.data_ptr(), V.data_ptr(),
+                                 dy.data_ptr(), dM.data_ptr(), N, C, K, H, W,
+                                 S, s)
         self.gemm(1.0, dM, V.transpose(1, 2), 0.0, dU)
-        self.k.wino_filtergrad(m, dU.data_ptr(), dw.data_ptr(), K, C, S, s)
+        self.k.wino_filtergrad(0, m, dU.data_ptr(), dw.data_ptr(), K, C, S, s)
         return True
 
     def _route32(self, mode, act, w, bias, addend, out, direct):
@@ -1181,10 +1185,13 @@ class HipMath(object):
         geometry and kept with the launch plans.  Returns what ``direct``
         returned when it ran, else None."""
         key = ("w32", mode, tuple(act.shape), tuple(w.shape),
-               bias is not None, addend is not None)
+               bias is not None, addend is not None, _code(act))
         plan = self._conv_plans.get(key)
+        # 16-bit operands: m = 2 only (the m = 4 transforms lose bits there)
+        ms = (2, 4) if act.dtype == torch.float32 else (2,)
         if _CONV_WINOGRAD in ("2", "4"):
-            plan = (int(_CONV_WINOGRAD), 0)
+            plan = (int(_CONV_WINOGRAD) if int(_CONV_WINOGRAD) in ms else 2,
+                    0)
         elif plan is None and _CONV_AUTOTUNE and not _DETERMINISTIC and \
                 (_world_size() <= 1 or _rank() == 0):
             name = repr(key)
@@ -1195,12 +1202,11 @@ class HipMath(object):
                 def run_direct():
                     direct()
                     return True
-                plan = self._measure_routes16([
-                    ((0, 0), run_direct),
-                    ((2, 0), lambda: self._winograd_any(2, mode, act, w, bias,
-                                                        addend, out)),
-                    ((4, 0), lambda: self._winograd_any(4, mode, act, w, bias,
-                                                        addend, out))])
+                def route(m):
+                    return lambda: self._winograd_any(m, mode, act, w, bias,
+                                                      addend, out)
+                plan = self._measure_routes16(
+                    [((0, 0), run_direct)] + [((m, 0), route(m)) for m in ms])
                 if plan is not None:
                     self._persist_plan(name, plan)
             if plan is not None:
@@ -1229,18 +1235,23 @@ class HipMath(object):
         if stats is not None:
             assert stats.dtype == torch.float32 and \
                 shift.dtype == torch.float32 and shift.is_contiguous()
+        if stats is None and self._winograd_applies(x, w, y, stride, pad,
+                                                    groups):
+            self._route32(0, x, w, b, None, y,
+                          lambda: self._conv_fwd_main(x, w, b, y, stride,
+                                                      pad, groups, None,
+                                                      None))
+            return
+        self._conv_fwd_main(x, w, b, y, stride, pad, groups, stats, shift)
+
+    def _conv_fwd_main(self, x, w, b, y, stride, pad, groups, stats, shift):
+        """The GEMM-shaped 16-bit kernels where one applies, else the
+        implicit-GEMM kernels."""
         if self._conv_fwd_16bit(x, w, b, y, stride, pad, groups):
             if stats is not None:
                 self.k.chan_sums(_code(y), y.data_ptr(), stats.data_ptr(),
                                  shift.data_ptr(), y.shape[0], y.shape[1],
                                  y.shape[2] * y.shape[3], self._s())
-            return
-        if stats is None and self._winograd_applies(x, w, y, stride, pad,
-                                                    groups):
-            self._route32(0, x, w, b, None, y,
-                          lambda: self._conv_fwd_direct(x, w, b, y, stride,
-                                                        pad, groups, None,
-                                                        None))
             return
         self._conv_fwd_direct(x, w, b, y, stride, pad, groups, stats, shift)
 
@@ -1302,6 +1313,18 @@ class HipMath(object):
         if addend is not None:
             assert addend.shape == dx.shape and addend.dtype == dx.dtype \
                 and addend.data_ptr() != dx.data_ptr()
+        if self._winograd_applies(dy, w, dx, stride, pad, groups):
+            if addend is not None:
+                addend = self._contig(addend)
+            return self._route32(
+                1, dy, w, None, addend, dx,
+                lambda: self._conv_bwd_data_main(dy, w, dx, stride, pad,
+                                                 groups, addend, side_zero))
+        return self._conv_bwd_data_main(dy, w, dx, stride, pad, groups,
+                                        addend, side_zero)
+
+    def _conv_bwd_data_main(self, dy, w, dx, stride, pad, groups, addend,
+                            side_zero):
         if self._strided_pointwise16(dx, w, stride, pad, groups) and \
                 dy.is_contiguous():
             N, C, H, W = dx.shape
@@ -1318,13 +1341,6 @@ class HipMath(object):
                     1, dy, w, None if addend is None else self._contig(addend),
                     dx, stride, pad, groups):
             return
-        if self._winograd_applies(dy, w, dx, stride, pad, groups):
-            if addend is not None:
-                addend = self._contig(addend)
-            return self._route32(
-                1, dy, w, None, addend, dx,
-                lambda: self._conv_bwd_data_direct(dy, w, dx, stride, pad,
-                                                   groups, addend, side_zero))
         return self._conv_bwd_data_direct(dy, w, dx, stride, pad, groups,
                                           addend, side_zero)
 
@@ -1394,8 +1410,8 @@ class HipMath(object):
             return
         if self._wgrad16(dy, x, dw, stride, pad, groups):
             return
-        if self._winograd_applies(dy, dw, x, stride, pad, groups) and \
-                dw.is_contiguous():
+        if x.dtype == torch.float32 and dw.is_contiguous() and \
+                self._winograd_applies(dy, dw, x, stride, pad, groups):
             # route timing runs the direct kernels more than once: only the
             # first of those launches may rely on dw holding zeros
             state = {"zeroed": zeroed}

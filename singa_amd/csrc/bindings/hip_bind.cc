@@ -553,46 +553,44 @@ PYBIND11_MODULE(_hip, m) {
   });
 
   // ---- Winograd transforms -----------------------------------------------------------------------------
-  m.def("wino_filter", [](int mm, uintptr_t w, uintptr_t U, int K, int C,
-                          bool flip, uintptr_t s) {
-    check(sa_wino_filter(mm, (const float *)CP(w), (float *)P(U), K, C,
-                         flip ? 1 : 0, S(s)), "wino_filter");
+  m.def("wino_filter", [](int dt, int mm, uintptr_t w, uintptr_t U, int K,
+                          int C, bool flip, uintptr_t s) {
+    check(sa_wino_filter(dt, mm, CP(w), P(U), K, C, flip ? 1 : 0, S(s)),
+          "wino_filter");
   });
-  m.def("wino_input", [](int mm, uintptr_t x, uintptr_t V, int N, int C, int H,
-                         int W, int slices, uintptr_t s) {
-    check(sa_wino_input(mm, (const float *)CP(x), (float *)P(V), N, C, H, W,
-                        slices, S(s)), "wino_input");
+  m.def("wino_input", [](int dt, int mm, uintptr_t x, uintptr_t V, int N,
+                         int C, int H, int W, int slices, uintptr_t s) {
+    check(sa_wino_input(dt, mm, CP(x), P(V), N, C, H, W, slices, S(s)),
+          "wino_input");
   });
-  m.def("wino_prepare", [](int mm, uintptr_t x, uintptr_t V, int N, int CI,
-                           int H, int W, uintptr_t w, uintptr_t U, int K,
-                           int C, bool flip, uintptr_t s) {
-    check(sa_wino_prepare(mm, (const float *)CP(x), (float *)P(V), N, CI, H, W,
-                          (const float *)CP(w), (float *)P(U), K, C,
+  m.def("wino_prepare", [](int dt, int mm, uintptr_t x, uintptr_t V, int N,
+                           int CI, int H, int W, uintptr_t w, uintptr_t U,
+                           int K, int C, bool flip, uintptr_t s) {
+    check(sa_wino_prepare(dt, mm, CP(x), P(V), N, CI, H, W, CP(w), P(U), K, C,
                           flip ? 1 : 0, S(s)), "wino_prepare");
   });
-  m.def("wino_prepare_grad", [](int mm, uintptr_t x, uintptr_t V, uintptr_t dy,
-                                uintptr_t dM, int N, int C, int K, int H,
-                                int W, int slices, uintptr_t s) {
-    check(sa_wino_prepare_grad(mm, (const float *)CP(x), (float *)P(V),
-                               (const float *)CP(dy), (float *)P(dM), N, C, K,
-                               H, W, slices, S(s)), "wino_prepare_grad");
+  m.def("wino_prepare_grad", [](int dt, int mm, uintptr_t x, uintptr_t V,
+                                uintptr_t dy, uintptr_t dM, int N, int C,
+                                int K, int H, int W, int slices,
+                                uintptr_t s) {
+    check(sa_wino_prepare_grad(dt, mm, CP(x), P(V), CP(dy), P(dM), N, C, K, H,
+                               W, slices, S(s)), "wino_prepare_grad");
   });
-  m.def("wino_outgrad", [](int mm, uintptr_t dy, uintptr_t dM, int N, int K,
-                           int H, int W, int slices, uintptr_t s) {
-    check(sa_wino_outgrad(mm, (const float *)CP(dy), (float *)P(dM), N, K, H,
-                          W, slices, S(s)), "wino_outgrad");
+  m.def("wino_outgrad", [](int dt, int mm, uintptr_t dy, uintptr_t dM, int N,
+                           int K, int H, int W, int slices, uintptr_t s) {
+    check(sa_wino_outgrad(dt, mm, CP(dy), P(dM), N, K, H, W, slices, S(s)),
+          "wino_outgrad");
   });
-  m.def("wino_filtergrad", [](int mm, uintptr_t dU, uintptr_t dw, int K, int C,
-                              int slices, uintptr_t s) {
-    check(sa_wino_filtergrad(mm, (const float *)CP(dU), (float *)P(dw), K, C,
-                             slices, S(s)), "wino_filtergrad");
+  m.def("wino_filtergrad", [](int dt, int mm, uintptr_t dU, uintptr_t dw,
+                              int K, int C, int slices, uintptr_t s) {
+    check(sa_wino_filtergrad(dt, mm, CP(dU), P(dw), K, C, slices, S(s)),
+          "wino_filtergrad");
   });
-  m.def("wino_output", [](int mm, uintptr_t M, uintptr_t bias,
+  m.def("wino_output", [](int dt, int mm, uintptr_t M, uintptr_t bias,
                           uintptr_t addend, uintptr_t y, int N, int K, int H,
                           int W, uintptr_t s) {
-    check(sa_wino_output(mm, (const float *)CP(M), (const float *)CP(bias),
-                         (const float *)CP(addend), (float *)P(y), N, K, H, W,
-                         S(s)), "wino_output");
+    check(sa_wino_output(dt, mm, CP(M), CP(bias), CP(addend), P(y), N, K, H,
+                         W, S(s)), "wino_output");
   });
 
   // ---- xGMI windows: direct collectives between the GPUs of a node ----------------------------------

@@ -449,32 +449,33 @@ struct PackBatch {
   int64_t count[kPackMax];
 };
 }  // namespace sa
-// ---- winograd.hip: transforms of F(m x m, 3 x 3), m = 2 or 4, float32 ---------------------------------------------
+// ---- winograd.hip: transforms of F(m x m, 3 x 3), m = 2 or 4 ----------------------------------------------------
+// All tensors of one call have the element type `dtype`; arithmetic is float.
 // U[(m+2)^2][KO][CI] from w[K][C][3][3]; flip: rotated taps and exchanged
 // channel roles (the data gradient's filter), KO = C, CI = K
-int sa_wino_filter(int m, const float *w, float *U, int K, int C, int flip,
-                   hipStream_t s);
+int sa_wino_filter(int dtype, int m, const void *w, void *U, int K, int C,
+                   int flip, hipStream_t s);
 // V[(m+2)^2][C][T] from x[N][C][H][W], T = N * ceil(H / m) * ceil(W / m); with
 // `slices` > 1 (a divisor of T) the layout is [(m+2)^2 * slices][C][T / slices]
-int sa_wino_input(int m, const float *x, float *V, int N, int C, int H, int W,
-                  int slices, hipStream_t s);
+int sa_wino_input(int dtype, int m, const void *x, void *V, int N, int C,
+                  int H, int W, int slices, hipStream_t s);
 // weight gradient: dM[(m+2)^2 * slices][K][T / slices] from dy[N][K][H][W], and
 // dw[K][C][3][3] from dU[(m+2)^2 * slices][K][C] (summed over the slices)
-int sa_wino_outgrad(int m, const float *dy, float *dM, int N, int K, int H,
-                    int W, int slices, hipStream_t s);
-int sa_wino_filtergrad(int m, const float *dU, float *dw, int K, int C,
-                       int slices, hipStream_t s);
+int sa_wino_outgrad(int dtype, int m, const void *dy, void *dM, int N, int K,
+                    int H, int W, int slices, hipStream_t s);
+int sa_wino_filtergrad(int dtype, int m, const void *dU, void *dw, int K,
+                       int C, int slices, hipStream_t s);
 // sa_wino_input + sa_wino_filter, and sa_wino_input + sa_wino_outgrad, as one
 // launch each (CI = C of w forward, K with flip)
-int sa_wino_prepare(int m, const float *x, float *V, int N, int CI, int H,
-                    int W, const float *w, float *U, int K, int C, int flip,
-                    hipStream_t s);
-int sa_wino_prepare_grad(int m, const float *x, float *V, const float *dy,
-                         float *dM, int N, int C, int K, int H, int W,
-                         int slices, hipStream_t s);
+int sa_wino_prepare(int dtype, int m, const void *x, void *V, int N, int CI,
+                    int H, int W, const void *w, void *U, int K, int C,
+                    int flip, hipStream_t s);
+int sa_wino_prepare_grad(int dtype, int m, const void *x, void *V,
+                         const void *dy, void *dM, int N, int C, int K, int H,
+                         int W, int slices, hipStream_t s);
 // y[N][K][H][W] = inverse transform of M[(m+2)^2][K][T] [+ bias[K]] [+ addend]
-int sa_wino_output(int m, const float *M, const float *bias,
-                   const float *addend, float *y, int N, int K, int H, int W,
+int sa_wino_output(int dtype, int m, const void *M, const void *bias,
+                   const void *addend, void *y, int N, int K, int H, int W,
                    hipStream_t s);
 // ---- xgmi.hip: collectives over IPC-mapped windows of the node's GPUs -------------------------------------------
 namespace sa {

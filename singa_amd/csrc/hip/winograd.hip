@@ -1,4 +1,4 @@
-// Winograd transforms for 3 x 3, stride 1, pad 1 convolutions in float32.
+// Winograd transforms for 3 x 3, stride 1, pad 1 convolutions.
 //
 // F(m x m, 3 x 3) computes an m x m block of outputs from an (m + 2)^2 input
 // patch with (m + 2)^2 multiplications per (input channel, output channel)
@@ -21,9 +21,12 @@
 // transform does both on the fly.  The reference leaves the choice of such
 // algorithms to the vendor library (src/model/operation/convolution.cc:514-640).
 //
-// Everything is plain float32 arithmetic; the transforms add and subtract
-// neighbouring values, so results differ from the direct kernels by rounding
-// only (a few 1e-6 of the output magnitude for m = 2, 1e-5 for m = 4).
+// The transforms compute in float32 whatever the element type; they add and
+// subtract neighbouring values, so float32 results differ from the direct
+// kernels by rounding only (a few 1e-6 of the output magnitude for m = 2,
+// 1e-5 for m = 4).  With 16-bit tensors the transformed operands are rounded
+// to 16 bits before the product, which m = 2 (coefficients 1 and 1/2) takes
+// without visible loss; the caller does not use m = 4 there.
 #include "common.cuh"
 #include "kernels.h"
 
@@ -61,24 +64,24 @@ template <> struct WinoMat<4> {
 // one thread per (output channel, input channel) pair of the product:
 // (ko, ci) = (k, c) of w[K][C][3][3] forward, (c, k) with the taps reversed for
 // the data gradient
-template <int M>
+template <int M, typename T>
 __device__ __forceinline__ void wino_filter_body(int64_t idx,
-                                                 const float *__restrict__ w,
-                                                 float *__restrict__ U, int K,
+                                                 const T *__restrict__ w,
+                                                 T *__restrict__ U, int K,
                                                  int C, int flip) {
   using W = WinoMat<M>;
   constexpr int A = W::A;
   const int KO = flip ? C : K, CI = flip ? K : C;
   if (idx >= (int64_t)KO * CI) return;
   const int ci = (int)(idx % CI), ko = (int)(idx / CI);
-  const float *src = flip ? w + ((int64_t)ci * C + ko) * 9
-                          : w + ((int64_t)ko * C + ci) * 9;
+  const T *src = flip ? w + ((int64_t)ci * C + ko) * 9
+                      : w + ((int64_t)ko * C + ci) * 9;
   float g[3][3];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int s = 0; s < 3; ++s)
-      g[r][s] = flip ? src[(2 - r) * 3 + (2 - s)] : src[r * 3 + s];
+      g[r][s] = to_f<T>(flip ? src[(2 - r) * 3 + (2 - s)] : src[r * 3 + s]);
   float t[A][3];
 #pragma unroll
   for (int i = 0; i < A; ++i)
@@ -91,9 +94,9 @@ __device__ __forceinline__ void wino_filter_body(int64_t idx,
   for (int i = 0; i < A; ++i)
 #pragma unroll
     for (int j = 0; j < A; ++j)
-      U[(i * A + j) * plane + idx] = t[i][0] * W::G[j][0] +
-                                     t[i][1] * W::G[j][1] +
-                                     t[i][2] * W::G[j][2];
+      U[(i * A + j) * plane + idx] = from_f<T>(t[i][0] * W::G[j][0] +
+                                               t[i][1] * W::G[j][1] +
+                                               t[i][2] * W::G[j][2]);
 }
 
 // one thread per (channel, tile); tiles are numbered (n, tile row, tile
@@ -101,10 +104,10 @@ __device__ __forceinline__ void wino_filter_body(int64_t idx,
 // With Tp < T the tiles are cut into T / Tp slices and slice s of plane p is
 // the matrix [(p * S + s)][C][Tp]: the weight gradient sums over the tiles,
 // and the slices are the split of that reduction over more workgroups.
-template <int M>
+template <int M, typename TT>
 __device__ __forceinline__ void wino_input_body(int64_t idx,
-                                                const float *__restrict__ x,
-                                                float *__restrict__ V, int C,
+                                                const TT *__restrict__ x,
+                                                TT *__restrict__ V, int C,
                                                 int H, int Wd, int th, int tw,
                                                 int64_t T, int64_t Tp) {
   using W = WinoMat<M>;
@@ -115,7 +118,7 @@ __device__ __forceinline__ void wino_input_body(int64_t idx,
   const int tc = (int)(t % tw);
   const int tr = (int)((t / tw) % th);
   const int n = (int)(t / ((int64_t)tw * th));
-  const float *img = x + ((int64_t)n * C + c) * H * Wd;
+  const TT *img = x + ((int64_t)n * C + c) * H * Wd;
   const int h0 = tr * M - 1, w0 = tc * M - 1;
   float d[A][A];
 #pragma unroll
@@ -125,7 +128,8 @@ __device__ __forceinline__ void wino_input_body(int64_t idx,
 #pragma unroll
     for (int b = 0; b < A; ++b) {
       const int ww = w0 + b;
-      d[a][b] = (hin && ww >= 0 && ww < Wd) ? img[(int64_t)h * Wd + ww] : 0.f;
+      d[a][b] = (hin && ww >= 0 && ww < Wd)
+                    ? to_f<TT>(img[(int64_t)h * Wd + ww]) : 0.f;
     }
   }
   float u[A][A];  // B^T d
@@ -149,16 +153,16 @@ __device__ __forceinline__ void wino_input_body(int64_t idx,
 #pragma unroll
       for (int b = 0; b < A; ++b)
         if (W::BT[j][b] != 0.f) s += u[i][b] * W::BT[j][b];
-      V[(i * A + j) * plane + at] = s;
+      V[(i * A + j) * plane + at] = from_f<TT>(s);
     }
 }
 
 // dM[p][k][t] = (A dY A^T)[p] of the m x m tile t of dy (zero outside the
 // image): the gradient of the loss with respect to the products M.  Same
 // slice layout as wino_input_kernel.
-template <int M>
+template <int M, typename TT>
 __device__ __forceinline__ void wino_outgrad_body(
-    int64_t idx, const float *__restrict__ dy, float *__restrict__ dM, int K,
+    int64_t idx, const TT *__restrict__ dy, TT *__restrict__ dM, int K,
     int H, int Wd, int th, int tw, int64_t T, int64_t Tp) {
   using W = WinoMat<M>;
   constexpr int A = W::A;
@@ -168,7 +172,7 @@ __device__ __forceinline__ void wino_outgrad_body(
   const int tc = (int)(t % tw);
   const int tr = (int)((t / tw) % th);
   const int n = (int)(t / ((int64_t)tw * th));
-  const float *img = dy + ((int64_t)n * K + k) * H * Wd;
+  const TT *img = dy + ((int64_t)n * K + k) * H * Wd;
   float d[M][M];
 #pragma unroll
   for (int a = 0; a < M; ++a) {
@@ -176,7 +180,7 @@ __device__ __forceinline__ void wino_outgrad_body(
 #pragma unroll
     for (int b = 0; b < M; ++b) {
       const int ww = tc * M + b;
-      d[a][b] = (h < H && ww < Wd) ? img[(int64_t)h * Wd + ww] : 0.f;
+      d[a][b] = (h < H && ww < Wd) ? to_f<TT>(img[(int64_t)h * Wd + ww]) : 0.f;
     }
   }
   float u[A][M];  // A dY
@@ -200,7 +204,7 @@ __device__ __forceinline__ void wino_outgrad_body(
 #pragma unroll
       for (int b = 0; b < M; ++b)
         if (W::AT[b][j] != 0.f) s += u[i][b] * W::AT[b][j];
-      dM[(i * A + j) * plane + at] = s;
+      dM[(i * A + j) * plane + at] = from_f<TT>(s);
     }
 }
 
@@ -209,67 +213,67 @@ __device__ __forceinline__ void wino_outgrad_body(
 // them more than its work): the first `nb_first` workgroups transform the
 // image, the others the filter (forward / data gradient) or dy (weight
 // gradient).
-template <int M>
-__global__ void wino_prepare_kernel(const float *__restrict__ x,
-                                    float *__restrict__ V, int C, int H,
+template <int M, typename TT>
+__global__ void wino_prepare_kernel(const TT *__restrict__ x,
+                                    TT *__restrict__ V, int C, int H,
                                     int Wd, int th, int tw, int64_t T,
-                                    const float *__restrict__ w,
-                                    float *__restrict__ U, int K, int Cw,
+                                    const TT *__restrict__ w,
+                                    TT *__restrict__ U, int K, int Cw,
                                     int flip, int nb_first) {
   if ((int)blockIdx.x < nb_first)
-    wino_input_body<M>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, x, V,
+    wino_input_body<M, TT>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, x, V,
                        C, H, Wd, th, tw, T, T);
   else
-    wino_filter_body<M>(
+    wino_filter_body<M, TT>(
         (int64_t)(blockIdx.x - nb_first) * blockDim.x + threadIdx.x, w, U, K,
         Cw, flip);
 }
 
-template <int M>
-__global__ void wino_prepare_grad_kernel(const float *__restrict__ x,
-                                         float *__restrict__ V, int C,
-                                         const float *__restrict__ dy,
-                                         float *__restrict__ dM, int K, int H,
+template <int M, typename TT>
+__global__ void wino_prepare_grad_kernel(const TT *__restrict__ x,
+                                         TT *__restrict__ V, int C,
+                                         const TT *__restrict__ dy,
+                                         TT *__restrict__ dM, int K, int H,
                                          int Wd, int th, int tw, int64_t T,
                                          int64_t Tp, int nb_first) {
   if ((int)blockIdx.x < nb_first)
-    wino_input_body<M>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, x, V,
+    wino_input_body<M, TT>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, x, V,
                        C, H, Wd, th, tw, T, Tp);
   else
-    wino_outgrad_body<M>(
+    wino_outgrad_body<M, TT>(
         (int64_t)(blockIdx.x - nb_first) * blockDim.x + threadIdx.x, dy, dM,
         K, H, Wd, th, tw, T, Tp);
 }
 
-template <int M>
-__global__ void wino_filter_kernel(const float *__restrict__ w,
-                                   float *__restrict__ U, int K, int C,
+template <int M, typename TT>
+__global__ void wino_filter_kernel(const TT *__restrict__ w,
+                                   TT *__restrict__ U, int K, int C,
                                    int flip) {
-  wino_filter_body<M>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, w, U, K,
+  wino_filter_body<M, TT>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, w, U, K,
                       C, flip);
 }
 
-template <int M>
-__global__ void wino_input_kernel(const float *__restrict__ x,
-                                  float *__restrict__ V, int C, int H, int Wd,
+template <int M, typename TT>
+__global__ void wino_input_kernel(const TT *__restrict__ x,
+                                  TT *__restrict__ V, int C, int H, int Wd,
                                   int th, int tw, int64_t T, int64_t Tp) {
-  wino_input_body<M>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, x, V, C,
+  wino_input_body<M, TT>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, x, V, C,
                      H, Wd, th, tw, T, Tp);
 }
 
-template <int M>
-__global__ void wino_outgrad_kernel(const float *__restrict__ dy,
-                                    float *__restrict__ dM, int K, int H,
+template <int M, typename TT>
+__global__ void wino_outgrad_kernel(const TT *__restrict__ dy,
+                                    TT *__restrict__ dM, int K, int H,
                                     int Wd, int th, int tw, int64_t T,
                                     int64_t Tp) {
-  wino_outgrad_body<M>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, dy, dM,
+  wino_outgrad_body<M, TT>((int64_t)blockIdx.x * blockDim.x + threadIdx.x, dy, dM,
                        K, H, Wd, th, tw, T, Tp);
 }
 
 // dw[k][c] (3 x 3) = G^T (sum over the S slices of dU[p * S + s][k][c]) G
-template <int M>
-__global__ void wino_filtergrad_kernel(const float *__restrict__ dU,
-                                       float *__restrict__ dw, int K, int C,
+template <int M, typename TT>
+__global__ void wino_filtergrad_kernel(const TT *__restrict__ dU,
+                                       TT *__restrict__ dw, int K, int C,
                                        int S) {
   using W = WinoMat<M>;
   constexpr int A = W::A;
@@ -285,9 +289,9 @@ __global__ void wino_filtergrad_kernel(const float *__restrict__ dU,
   for (int i = 0; i < A; ++i)
 #pragma unroll
     for (int j = 0; j < A; ++j) {
-      const float *src = dU + (int64_t)(i * A + j) * S * plane + idx;
+      const TT *src = dU + (int64_t)(i * A + j) * S * plane + idx;
       float v = 0.f;
-      for (int s = 0; s < S; ++s) v += src[s * plane];
+      for (int s = 0; s < S; ++s) v += to_f<TT>(src[s * plane]);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
         if (W::G[i][r] != 0.f) t[r][j] += W::G[i][r] * v;
@@ -300,16 +304,16 @@ __global__ void wino_filtergrad_kernel(const float *__restrict__ dU,
 #pragma unroll
       for (int j = 0; j < A; ++j)
         if (W::G[j][q] != 0.f) v += t[r][j] * W::G[j][q];
-      dw[idx * 9 + r * 3 + q] = v;
+      dw[idx * 9 + r * 3 + q] = from_f<TT>(v);
     }
 }
 
 // one thread per (output channel, tile): y tile = A^T m A [+ bias] [+ addend]
-template <int M>
-__global__ void wino_output_kernel(const float *__restrict__ Mm,
-                                   const float *__restrict__ bias,
-                                   const float *__restrict__ addend,
-                                   float *__restrict__ y, int K, int H, int Wd,
+template <int M, typename TT>
+__global__ void wino_output_kernel(const TT *__restrict__ Mm,
+                                   const TT *__restrict__ bias,
+                                   const TT *__restrict__ addend,
+                                   TT *__restrict__ y, int K, int H, int Wd,
                                    int th, int tw, int64_t T) {
   using W = WinoMat<M>;
   constexpr int A = W::A;
@@ -325,7 +329,8 @@ __global__ void wino_output_kernel(const float *__restrict__ Mm,
 #pragma unroll
   for (int i = 0; i < A; ++i)
 #pragma unroll
-    for (int j = 0; j < A; ++j) m[i][j] = Mm[(i * A + j) * plane + idx];
+    for (int j = 0; j < A; ++j)
+      m[i][j] = to_f<TT>(Mm[(i * A + j) * plane + idx]);
   float u[M][A];  // A^T m
 #pragma unroll
   for (int a = 0; a < M; ++a)
@@ -337,7 +342,7 @@ __global__ void wino_output_kernel(const float *__restrict__ Mm,
         if (W::AT[a][i] != 0.f) s += W::AT[a][i] * m[i][j];
       u[a][j] = s;
     }
-  const float bk = bias ? bias[k] : 0.f;
+  const float bk = bias ? to_f<TT>(bias[k]) : 0.f;
   const int64_t base = ((int64_t)n * K + k) * H * Wd;
 #pragma unroll
   for (int a = 0; a < M; ++a) {
@@ -352,7 +357,7 @@ __global__ void wino_output_kernel(const float *__restrict__ Mm,
       for (int j = 0; j < A; ++j)
         if (W::AT[b][j] != 0.f) s += u[a][j] * W::AT[b][j];
       const int64_t o = base + (int64_t)h * Wd + ww;
-      y[o] = addend ? s + addend[o] : s;
+      y[o] = from_f<TT>(addend ? s + to_f<TT>(addend[o]) : s);
     }
   }
 }
@@ -363,23 +368,27 @@ using namespace sa;
 
 static int wino_grid(int64_t n) { return (int)((n + 255) / 256); }
 
-int sa_wino_filter(int m, const float *w, float *U, int K, int C, int flip,
-                   hipStream_t s) {
+// m = 2 or 4 and the element type become template arguments
+#define WINO_DISPATCH(m, dtype, KERNEL, ...)                               \
+  SA_DISPATCH_FLOAT(dtype, TT, {                                           \
+    if (m == 2)                                                            \
+      hipLaunchKernelGGL((KERNEL<2, TT>), __VA_ARGS__);                    \
+    else                                                                   \
+      hipLaunchKernelGGL((KERNEL<4, TT>), __VA_ARGS__);                    \
+  })
+
+int sa_wino_filter(int dtype, int m, const void *w, void *U, int K, int C,
+                   int flip, hipStream_t s) {
+  if (m != 2 && m != 4) return -2;
   if (K <= 0 || C <= 0 || (int64_t)K * C > ((int64_t)1 << 38)) return -2;
   const dim3 grid(wino_grid((int64_t)K * C)), block(256);
-  if (m == 2)
-    hipLaunchKernelGGL(wino_filter_kernel<2>, grid, block, 0, s, w, U, K, C,
-                       flip);
-  else if (m == 4)
-    hipLaunchKernelGGL(wino_filter_kernel<4>, grid, block, 0, s, w, U, K, C,
-                       flip);
-  else
-    return -2;
+  WINO_DISPATCH(m, dtype, wino_filter_kernel, grid, block, 0, s,
+                (const TT *)w, (TT *)U, K, C, flip)
   return 0;
 }
 
-int sa_wino_input(int m, const float *x, float *V, int N, int C, int H, int W,
-                  int slices, hipStream_t s) {
+int sa_wino_input(int dtype, int m, const void *x, void *V, int N, int C,
+                  int H, int W, int slices, hipStream_t s) {
   if (m != 2 && m != 4) return -2;
   if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || slices <= 0) return -2;
   const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
@@ -388,17 +397,13 @@ int sa_wino_input(int m, const float *x, float *V, int N, int C, int H, int W,
   const int64_t Tp = T / slices;
   if ((int64_t)C * T > ((int64_t)1 << 38)) return -2;
   const dim3 grid(wino_grid((int64_t)C * T)), block(256);
-  if (m == 2)
-    hipLaunchKernelGGL(wino_input_kernel<2>, grid, block, 0, s, x, V, C, H, W,
-                       th, tw, T, Tp);
-  else
-    hipLaunchKernelGGL(wino_input_kernel<4>, grid, block, 0, s, x, V, C, H, W,
-                       th, tw, T, Tp);
+  WINO_DISPATCH(m, dtype, wino_input_kernel, grid, block, 0, s,
+                (const TT *)x, (TT *)V, C, H, W, th, tw, T, Tp)
   return 0;
 }
 
-int sa_wino_outgrad(int m, const float *dy, float *dM, int N, int K, int H,
-                    int W, int slices, hipStream_t s) {
+int sa_wino_outgrad(int dtype, int m, const void *dy, void *dM, int N, int K,
+                    int H, int W, int slices, hipStream_t s) {
   if (m != 2 && m != 4) return -2;
   if (N <= 0 || K <= 0 || H <= 0 || W <= 0 || slices <= 0) return -2;
   const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
@@ -406,32 +411,23 @@ int sa_wino_outgrad(int m, const float *dy, float *dM, int N, int K, int H,
   if (T % slices || (int64_t)K * T > ((int64_t)1 << 38)) return -2;
   const int64_t Tp = T / slices;
   const dim3 grid(wino_grid((int64_t)K * T)), block(256);
-  if (m == 2)
-    hipLaunchKernelGGL(wino_outgrad_kernel<2>, grid, block, 0, s, dy, dM, K, H,
-                       W, th, tw, T, Tp);
-  else
-    hipLaunchKernelGGL(wino_outgrad_kernel<4>, grid, block, 0, s, dy, dM, K, H,
-                       W, th, tw, T, Tp);
+  WINO_DISPATCH(m, dtype, wino_outgrad_kernel, grid, block, 0, s,
+                (const TT *)dy, (TT *)dM, K, H, W, th, tw, T, Tp)
   return 0;
 }
 
-int sa_wino_filtergrad(int m, const float *dU, float *dw, int K, int C,
-                       int slices, hipStream_t s) {
+int sa_wino_filtergrad(int dtype, int m, const void *dU, void *dw, int K,
+                       int C, int slices, hipStream_t s) {
+  if (m != 2 && m != 4) return -2;
   if (K <= 0 || C <= 0 || slices <= 0) return -2;
   const dim3 grid(wino_grid((int64_t)K * C)), block(256);
-  if (m == 2)
-    hipLaunchKernelGGL(wino_filtergrad_kernel<2>, grid, block, 0, s, dU, dw, K,
-                       C, slices);
-  else if (m == 4)
-    hipLaunchKernelGGL(wino_filtergrad_kernel<4>, grid, block, 0, s, dU, dw, K,
-                       C, slices);
-  else
-    return -2;
+  WINO_DISPATCH(m, dtype, wino_filtergrad_kernel, grid, block, 0, s,
+                (const TT *)dU, (TT *)dw, K, C, slices)
   return 0;
 }
 
-int sa_wino_output(int m, const float *M, const float *bias,
-                   const float *addend, float *y, int N, int K, int H, int W,
+int sa_wino_output(int dtype, int m, const void *M, const void *bias,
+                   const void *addend, void *y, int N, int K, int H, int W,
                    hipStream_t s) {
   if (m != 2 && m != 4) return -2;
   if (N <= 0 || K <= 0 || H <= 0 || W <= 0) return -2;
@@ -439,18 +435,15 @@ int sa_wino_output(int m, const float *M, const float *bias,
   const int64_t T = (int64_t)N * th * tw;
   if ((int64_t)K * T > ((int64_t)1 << 38)) return -2;
   const dim3 grid(wino_grid((int64_t)K * T)), block(256);
-  if (m == 2)
-    hipLaunchKernelGGL(wino_output_kernel<2>, grid, block, 0, s, M, bias,
-                       addend, y, K, H, W, th, tw, T);
-  else
-    hipLaunchKernelGGL(wino_output_kernel<4>, grid, block, 0, s, M, bias,
-                       addend, y, K, H, W, th, tw, T);
+  WINO_DISPATCH(m, dtype, wino_output_kernel, grid, block, 0, s,
+                (const TT *)M, (const TT *)bias, (const TT *)addend, (TT *)y,
+                K, H, W, th, tw, T)
   return 0;
 }
 
-int sa_wino_prepare(int m, const float *x, float *V, int N, int CI, int H,
-                    int W, const float *w, float *U, int K, int C, int flip,
-                    hipStream_t s) {
+int sa_wino_prepare(int dtype, int m, const void *x, void *V, int N, int CI,
+                    int H, int W, const void *w, void *U, int K, int C,
+                    int flip, hipStream_t s) {
   if (m != 2 && m != 4) return -2;
   if (N <= 0 || CI <= 0 || H <= 0 || W <= 0 || K <= 0 || C <= 0) return -2;
   if (CI != (flip ? K : C)) return -2;
@@ -459,18 +452,15 @@ int sa_wino_prepare(int m, const float *x, float *V, int N, int CI, int H,
   if ((int64_t)CI * T > ((int64_t)1 << 38)) return -2;
   const int nb_first = wino_grid((int64_t)CI * T);
   const dim3 grid(nb_first + wino_grid((int64_t)K * C)), block(256);
-  if (m == 2)
-    hipLaunchKernelGGL(wino_prepare_kernel<2>, grid, block, 0, s, x, V, CI, H,
-                       W, th, tw, T, w, U, K, C, flip, nb_first);
-  else
-    hipLaunchKernelGGL(wino_prepare_kernel<4>, grid, block, 0, s, x, V, CI, H,
-                       W, th, tw, T, w, U, K, C, flip, nb_first);
+  WINO_DISPATCH(m, dtype, wino_prepare_kernel, grid, block, 0, s,
+                (const TT *)x, (TT *)V, CI, H, W, th, tw, T, (const TT *)w,
+                (TT *)U, K, C, flip, nb_first)
   return 0;
 }
 
-int sa_wino_prepare_grad(int m, const float *x, float *V, const float *dy,
-                         float *dM, int N, int C, int K, int H, int W,
-                         int slices, hipStream_t s) {
+int sa_wino_prepare_grad(int dtype, int m, const void *x, void *V,
+                         const void *dy, void *dM, int N, int C, int K, int H,
+                         int W, int slices, hipStream_t s) {
   if (m != 2 && m != 4) return -2;
   if (N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0 || slices <= 0) return -2;
   const int th = (H + m - 1) / m, tw = (W + m - 1) / m;
@@ -479,11 +469,8 @@ int sa_wino_prepare_grad(int m, const float *x, float *V, const float *dy,
     return -2;
   const int nb_first = wino_grid((int64_t)C * T);
   const dim3 grid(nb_first + wino_grid((int64_t)K * T)), block(256);
-  if (m == 2)
-    hipLaunchKernelGGL(wino_prepare_grad_kernel<2>, grid, block, 0, s, x, V, C,
-                       dy, dM, K, H, W, th, tw, T, T / slices, nb_first);
-  else
-    hipLaunchKernelGGL(wino_prepare_grad_kernel<4>, grid, block, 0, s, x, V, C,
-                       dy, dM, K, H, W, th, tw, T, T / slices, nb_first);
+  WINO_DISPATCH(m, dtype, wino_prepare_grad_kernel, grid, block, 0, s,
+                (const TT *)x, (TT *)V, C, (const TT *)dy, (TT *)dM, K, H, W,
+                th, tw, T, T / slices, nb_first)
   return 0;
 }

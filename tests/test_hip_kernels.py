@@ -1547,3 +1547,31 @@ def test_winograd_route_is_chosen_by_measurement(maths, monkeypatch):
     keys = [k for k in type(hm)._conv_plans if k[0] == "w32"]
     assert any(k[2] == (N, C, H, H) for k in keys), keys
     monkeypatch.setattr(type(hm), "_plan_file", None)
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("N,C,K,H,W", [(2, 64, 32, 14, 14), (3, 16, 16, 7, 7),
+                                       (1, 8, 8, 9, 13)])
+def test_winograd_16bit_forward_and_data_gradient(maths, dt, N, C, K, H, W):
+    """F(2x2, 3x3) on 16-bit tensors (float32 transform arithmetic, operands
+    of the product rounded to 16 bits) against the float32 host convolution
+    of the same 16-bit inputs."""
+    hm, cm, dev = maths
+    x = rnd(N, C, H, W, seed=1).to(dt)
+    w = rnd(K, C, 3, 3, seed=2, lo=-0.3, hi=0.3).to(dt)
+    b = rnd(K, seed=3).to(dt)
+    dy = rnd(N, K, H, W, seed=4).to(dt)
+    ad = rnd(N, C, H, W, seed=5).to(dt)
+    y_ref = torch.nn.functional.conv2d(x.float(), w.float(), b.float(),
+                                       stride=1, padding=1)
+    dx_ref = torch.nn.functional.conv_transpose2d(
+        dy.float(), w.float(), stride=1, padding=1) + ad.float()
+    y = torch.empty(N, K, H, W, dtype=dt, device=dev.torch_device)
+    assert hm._winograd(2, 0, g(x, dev), g(w, dev), g(b, dev), None, y)
+    dx = torch.empty(N, C, H, W, dtype=dt, device=dev.torch_device)
+    assert hm._winograd(2, 1, g(dy, dev), g(w, dev), None, g(ad, dev), dx)
+    tol = 4e-3 if dt == torch.float16 else 3e-2
+    assert float((y.cpu().float() - y_ref).abs().max()) <= \
+        tol * float(y_ref.abs().max())
+    assert float((dx.cpu().float() - dx_ref).abs().max()) <= \
+        tol * float(dx_ref.abs().max())

@@ -383,6 +383,7 @@ def test_two_ranks_share_one_gpu(graph, option):
 @pytest.mark.gpu
 @pytest.mark.parametrize("case,ranks", [("collectives", "4"),
                                         ("collectives", "2"),
+                                        ("collectives", "8"),
                                         ("timeout", "3")])
 def test_xgmi_direct_collectives(case, ranks):
     """All-reduce (one- and two-shot, three element types) and all-gather

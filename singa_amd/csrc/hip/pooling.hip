@@ -80,11 +80,19 @@ __global__ void pool_bwd_kernel(PoolGeom g, const T *__restrict__ dy,
 // consecutive columns per thread (W a multiple of 4): 32-bit index arithmetic,
 // 8- / 16-byte loads of x and stores of dx, the few rows of dy / y a thread
 // needs stay in L1 across its four columns.
-template <typename T>
+// KS = window edge and stride as compile-time constants (KS = 32 for the
+// 3 x 3 / stride 2 windows of the residual networks: the window bounds then
+// need shifts instead of integer divisions); 0 = taken from g.
+template <typename T, int KS>
 __global__ void __launch_bounds__(256)
-maxpool_bwd_plane_kernel(PoolGeom g, const T *__restrict__ dy,
+maxpool_bwd_plane_kernel(PoolGeom gg, const T *__restrict__ dy,
                          const T *__restrict__ x, const T *__restrict__ y,
                          T *__restrict__ dx, int planes) {
+  struct Win {
+    int kh, kw, sh, sw;
+  };
+  const PoolGeom &g = gg;
+  const Win win = KS == 32 ? Win{3, 3, 2, 2} : Win{g.kh, g.kw, g.sh, g.sw};
   const int quads = g.W >> 2, per_plane = g.H * quads;
   for (int nc = blockIdx.y; nc < planes; nc += gridDim.y) {
     const T *dyp = dy + (int64_t)nc * g.P * g.Q;
@@ -103,13 +111,13 @@ maxpool_bwd_plane_kernel(PoolGeom g, const T *__restrict__ dy,
         __builtin_memcpy(xe, &v, 8);
       }
       const int hp = h + g.ph;
-      const int p_lo = hp < g.kh ? 0 : (hp - g.kh) / g.sh + 1;
-      const int p_hi = min(hp / g.sh, g.P - 1);
+      const int p_lo = hp < win.kh ? 0 : (hp - win.kh) / win.sh + 1;
+      const int p_hi = min(hp / win.sh, g.P - 1);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int wp = w0 + k + g.pw;
-        const int q_lo = wp < g.kw ? 0 : (wp - g.kw) / g.sw + 1;
-        const int q_hi = min(wp / g.sw, g.Q - 1);
+        const int q_lo = wp < win.kw ? 0 : (wp - win.kw) / win.sw + 1;
+        const int q_hi = min(wp / win.sw, g.Q - 1);
         const float xv = to_f<T>(xe[k]);
         float acc = 0.f;
         for (int p = p_lo; p <= p_hi; ++p)
@@ -159,10 +167,16 @@ int sa_pool_bwd(int dtype, const PoolGeom *g, const void *dy, const void *x,
     const int per_plane = g->H * (g->W / 4);
     const dim3 grid((unsigned)((per_plane + 255) / 256),
                     (unsigned)i64min(planes, 32768));
+    const bool k3s2 = g->kh == 3 && g->kw == 3 && g->sh == 2 && g->sw == 2;
     SA_DISPATCH_FLOAT(dtype, T, {
-      hipLaunchKernelGGL((maxpool_bwd_plane_kernel<T>), grid, dim3(256), 0, s,
-                         *g, (const T *)dy, (const T *)x, (const T *)y,
-                         (T *)dx, (int)planes);
+      if (k3s2)
+        hipLaunchKernelGGL((maxpool_bwd_plane_kernel<T, 32>), grid, dim3(256),
+                           0, s, *g, (const T *)dy, (const T *)x,
+                           (const T *)y, (T *)dx, (int)planes);
+      else
+        hipLaunchKernelGGL((maxpool_bwd_plane_kernel<T, 0>), grid, dim3(256),
+                           0, s, *g, (const T *)dy, (const T *)x,
+                           (const T *)y, (T *)dx, (int)planes);
     });
     return 0;
   }

@@ -583,6 +583,12 @@ static std::vector<LayerCase> LayerCases() {
   c.convolution_conf.set_kernel(1);
   c.convolution_conf.group = 2;
   cases.push_back({"singacpp_convolution", c, {4, 5, 5}, 2});
+  // enough channels and positions for the HIP device's Winograd route
+  c = LayerConf();
+  c.convolution_conf.num_output = 32;
+  c.convolution_conf.set_kernel(3);
+  c.convolution_conf.set_pad(1);
+  cases.push_back({"singacpp_convolution", c, {32, 12, 11}, 4});
   c = LayerConf();
   c.pooling_conf.set_kernel(2);
   c.pooling_conf.set_stride(2);

@@ -477,6 +477,15 @@ int sa_wino_prepare_grad(int dtype, int m, const void *x, void *V,
 int sa_wino_output(int dtype, int m, const void *M, const void *bias,
                    const void *addend, void *y, int N, int K, int H, int W,
                    hipStream_t s);
+// the whole route in one call: transforms + batched product + inverse
+// transform; mode 0 forward (out = y, N x K), mode 1 data gradient (act = dy,
+// out = dx, N x C); workspace: sa_conv3x3_winograd_workspace() elements
+int64_t sa_conv3x3_winograd_workspace(int m, int N, int C, int K, int H,
+                                      int W);
+int sa_conv3x3_winograd(int dtype, int m, int mode, const void *act,
+                        const void *w, const void *bias, const void *addend,
+                        void *out, int N, int C, int K, int H, int W,
+                        void *workspace, hipStream_t s);
 // ---- xgmi.hip: collectives over IPC-mapped windows of the node's GPUs -------------------------------------------
 namespace sa {
 constexpr int kXgmiMaxRanks = 8;    // GPUs of one node

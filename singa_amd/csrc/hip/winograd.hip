@@ -474,3 +474,41 @@ int sa_wino_prepare_grad(int dtype, int m, const void *x, void *V,
                 th, tw, T, T / slices, nb_first)
   return 0;
 }
+
+// ---- the whole route behind one call (the C++ API's convolution uses it) --------
+int64_t sa_conv3x3_winograd_workspace(int m, int N, int C, int K, int H,
+                                      int W) {
+  if ((m != 2 && m != 4) || N <= 0 || C <= 0 || K <= 0 || H <= 0 || W <= 0)
+    return -1;
+  const int64_t P = (int64_t)(m + 2) * (m + 2);
+  const int64_t T = (int64_t)N * ((H + m - 1) / m) * ((W + m - 1) / m);
+  return P * ((int64_t)K * C + (int64_t)C * T + (int64_t)K * T);
+}
+
+// mode 0: out[N][K][H][W] = conv3x3(act[N][C][H][W], w[K][C][3][3]) + bias;
+// mode 1: out[N][C][H][W] = data gradient of act[N][K][H][W] (+ addend).
+// `workspace` holds sa_conv3x3_winograd_workspace() elements of `dtype`.
+int sa_conv3x3_winograd(int dtype, int m, int mode, const void *act,
+                        const void *w, const void *bias, const void *addend,
+                        void *out, int N, int C, int K, int H, int W,
+                        void *workspace, hipStream_t s) {
+  if (mode != 0 && mode != 1) return -2;
+  if (sa_conv3x3_winograd_workspace(m, N, C, K, H, W) < 0 || !workspace)
+    return -2;
+  const int CI = mode == 0 ? C : K, KO = mode == 0 ? K : C;
+  const int64_t P = (int64_t)(m + 2) * (m + 2);
+  const int64_t T = (int64_t)N * ((H + m - 1) / m) * ((W + m - 1) / m);
+  const int64_t esize = dtype == kF32 ? 4 : 2;
+  char *base = static_cast<char *>(workspace);
+  void *U = base;
+  void *V = base + P * KO * CI * esize;
+  void *M = base + P * (KO * (int64_t)CI + CI * T) * esize;
+  int rc = sa_wino_prepare(dtype, m, act, V, N, CI, H, W, w, U, K, C,
+                           mode == 1, s);
+  if (rc != 0) return rc;
+  // M[p] (KO x T) = U[p] (KO x CI) * V[p] (CI x T), P products in one launch
+  rc = sa_gemm(dtype, KO, T, CI, 1.f, U, CI, 1, (int64_t)KO * CI, V, T, 1,
+               CI * T, 0.f, M, T, KO * T, P, nullptr, 0, s);
+  if (rc != 0) return rc;
+  return sa_wino_output(dtype, m, M, bias, addend, out, N, KO, H, W, s);
+}

@@ -1,6 +1,8 @@
 """Model zoo: every network builds, trains one step in graph mode and the
 loss is finite; small ones are trained until the loss drops (reference
 examples/cnn/train_cnn.py, examples/mlp/model.py)."""
+import os
+import sys
 import numpy as np
 import pytest
 
@@ -127,3 +129,18 @@ def test_bfloat16_training_step():
     dev.ResetGraph()
     assert np.all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_training_with_winograd_routes_follows_direct_kernels():
+    """ResNet-18, 300 replayed float32 steps on the same data and seed, once
+    on the direct convolution kernels and once with the measured Winograd
+    routes: some layers take a transform, the loss curves stay together."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(
+        [sys.executable, "-u",
+         os.path.join(root, "tools", "check_winograd_training.py")],
+        capture_output=True, text=True, timeout=280)
+    assert out.returncode == 0 and "WINOGRAD-TRAINING-OK" in out.stdout, (
+        out.stdout[-3000:] + out.stderr[-2000:])

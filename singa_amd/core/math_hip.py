@@ -1167,16 +1167,22 @@ class HipMath(object):
         T = N * (-(-H // m)) * (-(-W // m))
         S = self._winograd_slices(P, K, C, T)
         Tp = T // S
-        assert x.dtype == torch.float32     # (16-bit sums would be rounded)
-        V = self._tmp(P * C * T).view(P * S, C, Tp)
-        dM = self._tmp(P * K * T).view(P * S, K, Tp)
-        dU = self._tmp(P * S * K * C).view(P * S, K, C)
+        dt, code = x.dtype, _code(x)
+        V = self._tmp(P * C * T, dt).view(P * S, C, Tp)
+        dM = self._tmp(P * K * T, dt).view(P * S, K, Tp)
+        dU = self._tmp(P * S * K * C).view(P * S, K, C)     # float sums
         s = self._s()
-        self.k.wino_prepare_grad(0, m, x.data_ptr(), V.data_ptr(),
+        self.k.wino_prepare_grad(code, m, x.data_ptr(), V.data_ptr(),
                                  dy.data_ptr(), dM.data_ptr(), N, C, K, H, W,
                                  S, s)
-        self.gemm(1.0, dM, V.transpose(1, 2), 0.0, dU)
-        self.k.wino_filtergrad(0, m, dU.data_ptr(), dw.data_ptr(), K, C, S, s)
+        if dt == torch.float32:
+            self.gemm(1.0, dM, V.transpose(1, 2), 0.0, dU)
+        elif Tp % 8 or self.k.gemm_h16_partial(
+                code, K, C, Tp, dM.data_ptr(), Tp, 1, K * Tp, V.data_ptr(), 1,
+                Tp, C * Tp, dU.data_ptr(), P * S, s, 0) != 0:
+            return False    # the tiled 16-bit kernel refuses the layout
+        self.k.wino_filtergrad(code, m, dU.data_ptr(), True, dw.data_ptr(), K,
+                               C, S, s)
         return True
 
     def _route32(self, mode, act, w, bias, addend, out, direct):
@@ -1211,8 +1217,8 @@ class HipMath(object):
                     self._persist_plan(name, plan)
             if plan is not None:
                 self._conv_plans[key] = plan
-        if plan is not None and plan[0] in (2, 4):
-            self._winograd_any(plan[0], mode, act, w, bias, addend, out)
+        if plan is not None and plan[0] in (2, 4) and \
+                self._winograd_any(plan[0], mode, act, w, bias, addend, out):
             return None
         return direct()
 
@@ -1408,19 +1414,21 @@ class HipMath(object):
                 self._wgrad16(dy, self._even_positions(x), dw, (1, 1), (0, 0),
                               1):
             return
-        if self._wgrad16(dy, x, dw, stride, pad, groups):
-            return
-        if x.dtype == torch.float32 and dw.is_contiguous() and \
+        if dw.is_contiguous() and \
                 self._winograd_applies(dy, dw, x, stride, pad, groups):
             # route timing runs the direct kernels more than once: only the
             # first of those launches may rely on dw holding zeros
             state = {"zeroed": zeroed}
 
             def direct():
+                if self._wgrad16(dy, x, dw, stride, pad, groups):
+                    return
                 self._conv_bwd_weight_direct(dy, x, dw, stride, pad, groups,
                                              state["zeroed"])
                 state["zeroed"] = False
             self._route32(2, dy, x, None, None, dw, direct)
+            return
+        if self._wgrad16(dy, x, dw, stride, pad, groups):
             return
         self._conv_bwd_weight_direct(dy, x, dw, stride, pad, groups, zeroed)
 

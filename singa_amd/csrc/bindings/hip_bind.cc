@@ -581,10 +581,11 @@ PYBIND11_MODULE(_hip, m) {
     check(sa_wino_outgrad(dt, mm, CP(dy), P(dM), N, K, H, W, slices, S(s)),
           "wino_outgrad");
   });
-  m.def("wino_filtergrad", [](int dt, int mm, uintptr_t dU, uintptr_t dw,
-                              int K, int C, int slices, uintptr_t s) {
-    check(sa_wino_filtergrad(dt, mm, CP(dU), P(dw), K, C, slices, S(s)),
-          "wino_filtergrad");
+  m.def("wino_filtergrad", [](int dt, int mm, uintptr_t dU, bool du_float,
+                              uintptr_t dw, int K, int C, int slices,
+                              uintptr_t s) {
+    check(sa_wino_filtergrad(dt, mm, CP(dU), du_float ? 1 : 0, P(dw), K, C,
+                             slices, S(s)), "wino_filtergrad");
   });
   m.def("wino_output", [](int dt, int mm, uintptr_t M, uintptr_t bias,
                           uintptr_t addend, uintptr_t y, int N, int K, int H,

@@ -463,8 +463,9 @@ int sa_wino_input(int dtype, int m, const void *x, void *V, int N, int C,
 // dw[K][C][3][3] from dU[(m+2)^2 * slices][K][C] (summed over the slices)
 int sa_wino_outgrad(int dtype, int m, const void *dy, void *dM, int N, int K,
                     int H, int W, int slices, hipStream_t s);
-int sa_wino_filtergrad(int dtype, int m, const void *dU, void *dw, int K,
-                       int C, int slices, hipStream_t s);
+// (du_float: dU holds floats although dw is a 16-bit tensor)
+int sa_wino_filtergrad(int dtype, int m, const void *dU, int du_float,
+                       void *dw, int K, int C, int slices, hipStream_t s);
 // sa_wino_input + sa_wino_filter, and sa_wino_input + sa_wino_outgrad, as one
 // launch each (CI = C of w forward, K with flip)
 int sa_wino_prepare(int dtype, int m, const void *x, void *V, int N, int CI,

@@ -271,8 +271,8 @@ __global__ void wino_outgrad_kernel(const TT *__restrict__ dy,
 }
 
 // dw[k][c] (3 x 3) = G^T (sum over the S slices of dU[p * S + s][k][c]) G
-template <int M, typename TT>
-__global__ void wino_filtergrad_kernel(const TT *__restrict__ dU,
+template <int M, typename TT, typename TI = TT>
+__global__ void wino_filtergrad_kernel(const TI *__restrict__ dU,
                                        TT *__restrict__ dw, int K, int C,
                                        int S) {
   using W = WinoMat<M>;
@@ -289,9 +289,9 @@ __global__ void wino_filtergrad_kernel(const TT *__restrict__ dU,
   for (int i = 0; i < A; ++i)
 #pragma unroll
     for (int j = 0; j < A; ++j) {
-      const TT *src = dU + (int64_t)(i * A + j) * S * plane + idx;
+      const TI *src = dU + (int64_t)(i * A + j) * S * plane + idx;
       float v = 0.f;
-      for (int s = 0; s < S; ++s) v += to_f<TT>(src[s * plane]);
+      for (int s = 0; s < S; ++s) v += to_f<TI>(src[s * plane]);
 #pragma unroll
       for (int r = 0; r < 3; ++r)
         if (W::G[i][r] != 0.f) t[r][j] += W::G[i][r] * v;
@@ -416,11 +416,25 @@ int sa_wino_outgrad(int dtype, int m, const void *dy, void *dM, int N, int K,
   return 0;
 }
 
-int sa_wino_filtergrad(int dtype, int m, const void *dU, void *dw, int K,
-                       int C, int slices, hipStream_t s) {
+int sa_wino_filtergrad(int dtype, int m, const void *dU, int du_float,
+                       void *dw, int K, int C, int slices, hipStream_t s) {
   if (m != 2 && m != 4) return -2;
   if (K <= 0 || C <= 0 || slices <= 0) return -2;
   const dim3 grid(wino_grid((int64_t)K * C)), block(256);
+  if (du_float && dtype != kF32) {
+    // float products of 16-bit operands, gradient in the 16-bit type
+    SA_DISPATCH_FLOAT(dtype, TT, {
+      if (m == 2)
+        hipLaunchKernelGGL((wino_filtergrad_kernel<2, TT, float>), grid,
+                           block, 0, s, (const float *)dU, (TT *)dw, K, C,
+                           slices);
+      else
+        hipLaunchKernelGGL((wino_filtergrad_kernel<4, TT, float>), grid,
+                           block, 0, s, (const float *)dU, (TT *)dw, K, C,
+                           slices);
+    })
+    return 0;
+  }
   WINO_DISPATCH(m, dtype, wino_filtergrad_kernel, grid, block, 0, s,
                 (const TT *)dU, (TT *)dw, K, C, slices)
   return 0;

@@ -1575,3 +1575,13 @@ def test_winograd_16bit_forward_and_data_gradient(maths, dt, N, C, K, H, W):
         tol * float(y_ref.abs().max())
     assert float((dx.cpu().float() - dx_ref).abs().max()) <= \
         tol * float(dx_ref.abs().max())
+    # weight gradient: float products of the 16-bit transformed operands
+    wd = w.double().requires_grad_(True)
+    torch.nn.functional.conv2d(x.double(), wd, None, stride=1,
+                               padding=1).backward(dy.double())
+    dw = torch.empty(K, C, 3, 3, dtype=dt, device=dev.torch_device)
+    if hm._winograd_wgrad(2, g(dy, dev), g(x, dev), dw):
+        assert float((dw.cpu().double() - wd.grad).abs().max()) <= \
+            tol * float(wd.grad.abs().max())
+    else:       # tile counts the 16-bit product kernel does not take
+        assert (N * (-(-H // 2)) * (-(-W // 2))) % 64 != 0

@@ -38,7 +38,7 @@ def main():
     dt = {"fp32": torch.float32, "fp16": torch.float16,
           "bf16": torch.bfloat16}[os.environ.get("DTYPE", "fp32")]
     ms = (2, 4) if dt == torch.float32 else (2,)
-    modes = 3 if dt == torch.float32 else 2
+    modes = 3
     dev = device.create_cuda_gpu_on(0)
     hm = dev.math
     td = dev.torch_device
@@ -51,19 +51,24 @@ def main():
         y = torch.empty(batch, K, HW, HW, device=td, dtype=dt)
         dx = torch.empty(batch, C, HW, HW, device=td, dtype=dt)
         row, devs = [], []
-        dw = torch.empty(K, C, 3, 3, device=td)
+        dw = torch.empty(K, C, 3, 3, device=td, dtype=dt)
         for mode, act, out in ((0, x, y), (1, dy, dx), (2, dy, dw))[:modes]:
             if mode == 0:
                 d = lambda: hm._conv_fwd_main(x, w, None, y, (1, 1), (1, 1), 1, None, None)
             elif mode == 1:
                 d = lambda: hm._conv_bwd_data_main(dy, w, dx, (1, 1), (1, 1), 1, None, None)
             else:
-                d = lambda: hm._conv_bwd_weight_direct(dy, x, dw, (1, 1), (1, 1), 1, False)
+                d = lambda: (hm._wgrad16(dy, x, dw, (1, 1), (1, 1), 1) or
+                             hm._conv_bwd_weight_direct(dy, x, dw, (1, 1), (1, 1), 1, False))
             t0 = timed(d, dev)
             ref = out.clone()
             ts = [t0]
             for m in ms:
                 f = lambda: hm._winograd_any(m, mode, act, x if mode == 2 else w, None, None, out)
+                if not f():
+                    ts.append(float("nan"))
+                    devs.append(float("nan"))
+                    continue
                 ts.append(timed(f, dev))
                 devs.append(float((out.float() - ref.float()).abs().max() / ref.float().abs().max()))
             row.append(ts)

@@ -21,17 +21,21 @@ from bench_conv import resnet50_layers  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--dtype", default="fp32",
+                    choices=["fp32", "fp16", "bf16"])
     args = ap.parse_args()
+    dt = {"fp32": torch.float32, "fp16": torch.float16,
+          "bf16": torch.bfloat16}[args.dtype]
     sdev = sdevice.create_cuda_gpu()
     dev, m = sdev.torch_device, sdev.math
     N = args.batch
     layers = []
     for (C, K, R, st, pd, H, cnt) in resnet50_layers()[1:]:
         P = (H + 2 * pd - R) // st + 1
-        x = torch.randn(N, C, H, H, device=dev)
-        w = torch.randn(K, C, R, R, device=dev) * 0.05
-        y = torch.randn(N, K, P, P, device=dev)      # conv output = BN input
-        dz = torch.randn(N, K, P, P, device=dev)     # gradient after the BN
+        x = torch.randn(N, C, H, H, device=dev).to(dt)
+        w = (torch.randn(K, C, R, R, device=dev) * 0.05).to(dt)
+        y = torch.randn(N, K, P, P, device=dev).to(dt)   # conv output = BN input
+        dz = torch.randn(N, K, P, P, device=dev).to(dt)  # gradient after the BN
         dy = torch.empty_like(dz)
         dx = torch.empty_like(x)
         dw = torch.empty_like(w)
@@ -80,6 +84,7 @@ def main():
 
     t_s = timeit(lambda: chain(False))
     t_f = timeit(lambda: chain(True))
+    print(args.dtype, end=" ")
     print("backward chain of %d layers: in line %.3f ms, weight gradients on "
           "a second stream %.3f ms (%.2fx)" % (len(layers), t_s, t_f,
                                               t_s / t_f))

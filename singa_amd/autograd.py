@@ -971,12 +971,11 @@ class LinearBias(Operator):
         K, N = w.shape()
         M = int(np.prod(x.shape())) // K
         dy2 = singa.Reshape(dy, [M, N])
-        dx = dw = None
-        if self.x_needs_grad[0]:
-            dx = singa.Reshape(singa.Mult(dy2, _t_last2(w)), list(x.shape()))
-        if self.x_needs_grad[1]:
-            dw = singa.Mult(_t_last2(singa.Reshape(x, [M, K])), dy2)
-        db = singa.Sum(dy2, 0)
+        dx, dw, db = singa.LinearBackward(
+            dy2, singa.Reshape(x, [M, K]), w, bool(self.x_needs_grad[0]),
+            bool(self.x_needs_grad[1]))
+        if dx is not None:
+            dx = singa.Reshape(dx, list(x.shape()))
         return dx, dw, db
 
 

@@ -343,8 +343,14 @@ def test_conv_hands_batchnorm_statistics_cpu(monkeypatch):
                                             ("float16", 2e-2),
                                             ("bfloat16", 1e-1)])
 @pytest.mark.parametrize("shape", [(6, 5, 24), (33, 40), (2, 3, 4, 8)])
-def test_linear_bias_forward_backward(dev, dtype_name, tol, shape):
+@pytest.mark.parametrize("streams", [False, True])
+def test_linear_bias_forward_backward(dev, dtype_name, tol, shape, streams,
+                                      monkeypatch):
+    """``streams``: the three gradient kernels on streams of their own (GPU
+    only; one stream on the host either way)."""
     from singa_amd import autograd, tensor
+    from singa_amd.core import tensor_core
+    monkeypatch.setattr(tensor_core, "_LINEAR_BWD_STREAMS", streams)
     dt = getattr(tensor, dtype_name)
     rs = np.random.RandomState(0)
     K, N = shape[-1], 16

@@ -80,6 +80,8 @@ _CONV16_AUTOTUNE = os.environ.get("SINGA_CONV16_AUTOTUNE", "1") != "0"
 # against the direct kernels per geometry; 0 keeps the direct kernels, 2 / 4
 # force a transform where it applies (tests)
 _CONV_WINOGRAD = os.environ.get("SINGA_CONV_WINOGRAD", "1")
+_CONV_WINOGRAD_MAX_BYTES = int(os.environ.get("SINGA_CONV_WINOGRAD_MAX_MB",
+                                              "4096")) << 20
 # SINGA_DETERMINISTIC=1: bitwise reproducible training steps.  Reductions that
 # are split over workgroups (convolution passes, column sums, whole-tensor
 # sums, the soft-max loss) add their partial results in a fixed order instead
@@ -1107,6 +1109,16 @@ class HipMath(object):
     # ---- float32 Winograd routes ------------------------------------------------
     @staticmethod
     def _winograd_applies(act, w, out, stride, pad, groups):
+        # the transformed image and the products are (m+2)^2 / m^2 times the
+        # activation each: no route for layers whose two scratch tensors
+        # would exceed SINGA_CONV_WINOGRAD_MAX_MB (4 GiB)
+        if act.dim() == 4:
+            tiles = act.shape[0] * (-(-act.shape[2] // 4)) * \
+                (-(-act.shape[3] // 4))
+            scratch = 36 * tiles * (act.shape[1] + out.shape[1]) * \
+                act.element_size()
+            if scratch > _CONV_WINOGRAD_MAX_BYTES:
+                return False
         return (_CONV_WINOGRAD != "0" and groups == 1 and
                 act.dtype in _FLOATS and w.dtype == act.dtype and
                 out.dtype == act.dtype and

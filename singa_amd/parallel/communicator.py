@@ -433,6 +433,14 @@ class Communicator(object):
                 torch.cuda.synchronize()
             if getattr(self, "_xgmi", None) is not None:
                 self._buffers = {}
+                if self.world_size > 1 and dist.is_initialized():
+                    # a peer's last kernel may still read this rank's window:
+                    # every rank drains its device (above) before any unmaps
+                    try:
+                        dist.monitored_barrier(
+                            timeout=datetime.timedelta(seconds=20))
+                    except Exception:   # noqa: BLE001 (a rank is gone)
+                        pass
                 self._xgmi.close()
                 self._xgmi = None
             if self._rccl is not None:

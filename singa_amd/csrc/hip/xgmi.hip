@@ -57,7 +57,8 @@ __device__ __forceinline__ void st_flag(unsigned *p, unsigned v) {
 // no-ops once a wait has timed out.
 __device__ __forceinline__ void peer_barrier(const XgmiPeers &pr, int rank,
                                              int world, unsigned epoch,
-                                             long long limit, int *dead) {
+                                             long long limit,
+                                             volatile int *dead) {
   // this thread's stores (to its own or a peer's memory) are performed
   // before any flag goes out
   __threadfence_system();

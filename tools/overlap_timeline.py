@@ -15,7 +15,7 @@ import glob
 import re
 import sys
 
-COMM = re.compile(r"nccl|rccl|pack_kernel|unpack_kernel|sparse|scatter_add",
+COMM = re.compile(r"nccl|rccl|xgmi|pack_kernel|unpack_kernel|sparse|scatter_add",
                   re.I)
 
 

@@ -121,9 +121,48 @@ __device__ __forceinline__ uint4 sum_peers(const XgmiPeers &pr, int64_t off,
   return out.raw;
 }
 
+// Vectors i, i + step, ... (kXgmiUnroll of them) at once: world x kXgmiUnroll
+// loads are in flight per thread before the first sum is formed.  Window
+// memory is uncached and a peer's sits behind a link, so the latency of one
+// access is long; the bytes in flight are what sets the rate.  Two, not more:
+// with eight peers that is 64 registers of loads per thread, and the kernels
+// keep to 128 registers (four waves per SIMD) so that the ranks of a
+// rehearsal that share one GPU are all resident at once -- a barrier between
+// workgroups that cannot all be scheduled would only end by its time limit.
+constexpr int kXgmiUnroll = 2;
+
+template <typename T, int W>
+__device__ __forceinline__ void sum_peers_many(const XgmiPeers &pr, int64_t off,
+                                               int64_t i, int64_t step,
+                                               int64_t hi, int world,
+                                               uint4 *__restrict__ dst) {
+  constexpr int kN = Vec16<T>::kN;
+  Vec16<T> in[kXgmiUnroll][W];
+#pragma unroll
+  for (int u = 0; u < kXgmiUnroll; ++u)
+#pragma unroll
+    for (int p = 0; p < W; ++p)
+      if (p < world && i + u * step < hi)
+        in[u][p].raw =
+            reinterpret_cast<const uint4 *>(pr.data[p] + off)[i + u * step];
+#pragma unroll
+  for (int u = 0; u < kXgmiUnroll; ++u) {
+    if (i + u * step >= hi) break;
+    float acc[kN];
+#pragma unroll
+    for (int k = 0; k < kN; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int p = 0; p < W; ++p)
+      if (p < world) in[u][p].add_to(acc);
+    Vec16<T> out;
+    out.from(acc);
+    dst[i + u * step] = out.raw;
+  }
+}
+
 // nvec 16-byte vectors at byte offset `off` of every window
 template <typename T>
-__global__ void __launch_bounds__(kXgmiThreads)
+__global__ void __launch_bounds__(kXgmiThreads, 4)
 xgmi_allreduce_two_shot_kernel(XgmiPeers pr, int rank, int world, int64_t off,
                                int64_t nvec, long long limit) {
   __shared__ int dead;
@@ -141,8 +180,8 @@ xgmi_allreduce_two_shot_kernel(XgmiPeers pr, int rank, int world, int64_t off,
   {
     const int64_t lo = rank * per, hi = i64min_d(lo + per, nvec);
     uint4 *mine = reinterpret_cast<uint4 *>(pr.data[rank] + off);
-    for (int64_t i = lo + first; i < hi; i += step)
-      mine[i] = sum_peers<T, kXgmiMaxRanks>(pr, off, i, world);
+    for (int64_t i = lo + first; i < hi; i += kXgmiUnroll * step)
+      sum_peers_many<T, kXgmiMaxRanks>(pr, off, i, step, hi, world, mine);
   }
   peer_barrier(pr, rank, world, e + 2, limit, &dead);
   {
@@ -153,7 +192,15 @@ xgmi_allreduce_two_shot_kernel(XgmiPeers pr, int rank, int world, int64_t off,
       const int p = (rank + d) % world;
       const int64_t lo = p * per, hi = i64min_d(lo + per, nvec);
       const uint4 *src = reinterpret_cast<const uint4 *>(pr.data[p] + off);
-      for (int64_t i = lo + first; i < hi; i += step) mine[i] = src[i];
+      for (int64_t i = lo + first; i < hi; i += kXgmiUnroll * step) {
+        uint4 v[kXgmiUnroll];
+#pragma unroll
+        for (int u = 0; u < kXgmiUnroll; ++u)
+          if (i + u * step < hi) v[u] = src[i + u * step];
+#pragma unroll
+        for (int u = 0; u < kXgmiUnroll; ++u)
+          if (i + u * step < hi) mine[i + u * step] = v[u];
+      }
     }
   }
   peer_barrier(pr, rank, world, e + 3, limit, &dead);
@@ -205,7 +252,15 @@ xgmi_allgather_kernel(XgmiPeers pr, int rank, int world, int64_t off,
   for (int d = 0; d < world; ++d) {
     const int p = (rank + d) % world;
     const V *src = reinterpret_cast<const V *>(pr.data[p] + off);
-    for (int64_t i = first; i < nvec; i += step) out[p * nvec + i] = src[i];
+    for (int64_t i = first; i < nvec; i += kXgmiUnroll * step) {
+      V v[kXgmiUnroll];
+#pragma unroll
+      for (int u = 0; u < kXgmiUnroll; ++u)
+        if (i + u * step < nvec) v[u] = src[i + u * step];
+#pragma unroll
+      for (int u = 0; u < kXgmiUnroll; ++u)
+        if (i + u * step < nvec) out[p * nvec + i + u * step] = v[u];
+    }
   }
   peer_barrier(pr, rank, world, e + 2, limit, &dead);
   if (threadIdx.x == 0) pr.epoch[blockIdx.x] = e + 2;

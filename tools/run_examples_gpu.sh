@@ -31,6 +31,8 @@ run onnx_train python examples/onnx/training/train.py --self-export -m 1 -b 8 --
 run onnx_selftest python examples/onnx/text_models.py self-test
 run largedata python examples/largedataset_cnn/train_largedata.py cnn --synthetic -m 1 -b 16
 run hfl python examples/hfl/run_local.py --num_clients 2 -m 2 --port 15411
+run caffe_lenet python examples/caffe/train.py --iters 100 --save /tmp/singa_caffe_lenet.caffemodel
+run caffe_lenet_restore python examples/caffe/train.py --iters 10 --weights /tmp/singa_caffe_lenet.caffemodel
 run cpp_cnn singa_amd/bin/singa_cnn -epoch 1
 run cpp_cnn_opencl singa_amd/bin/singa_cnn -epoch 1 -opencl
 run cpp_cnn_parallel singa_amd/bin/singa_cnn_parallel -epoch 1 -replicas 1

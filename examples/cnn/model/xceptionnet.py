@@ -1,0 +1,4 @@
+"""The library's model zoo network under the module name scripts of the
+reference import (examples/cnn/model/xceptionnet.py there)."""
+from singa_amd.models.xceptionnet import *          # noqa: F401,F403
+from singa_amd.models.xceptionnet import create_model  # noqa: F401

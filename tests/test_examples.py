@@ -305,3 +305,48 @@ def test_distributed_example_launchers(script, args, tmp_path):
     assert out.returncode == 0, tail
     assert "terminate called" not in tail and "Traceback" not in tail, tail
     assert "Throughput" in out.stdout or "accuracy" in out.stdout, tail
+
+
+def test_caffe_lenet_example_trains_and_restores(tmp_path):
+    import subprocess
+    script = os.path.join(ROOT, "caffe", "train.py")
+    saved = str(tmp_path / "lenet.caffemodel")
+    out = subprocess.run(
+        [sys.executable, script, "--cpu", "--iters", "40", "--batch", "16",
+         "--save", saved], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    losses = [float(line.split("loss")[1].split()[0])
+              for line in out.stdout.splitlines() if "loss" in line]
+    assert losses[-1] < 0.5 * losses[0]
+    again = subprocess.run(
+        [sys.executable, script, "--cpu", "--iters", "1", "--batch", "16",
+         "--weights", saved], capture_output=True, text=True, timeout=300)
+    assert again.returncode == 0, again.stderr[-2000:]
+    assert "restored ['conv1', 'conv2', 'ip1', 'ip2']" in again.stdout
+    first = float(again.stdout.split("loss")[1].split()[0])
+    assert first < 0.5 * losses[0]      # starts where the first run ended
+
+
+@pytest.mark.parametrize("subdir", ["cnn", "cifar_distributed_cnn",
+                                    "largedataset_cnn"])
+def test_model_modules_under_the_reference_layout(subdir):
+    """``from model import resnet`` inside an example directory gives the
+    library's model zoo."""
+    import importlib
+    from singa_amd import models
+    path = os.path.join(ROOT, subdir)
+    sys.path.insert(0, path)
+    stale = {k: sys.modules.pop(k) for k in list(sys.modules)
+             if k == "model" or k.startswith("model.")}
+    try:
+        for name in ("cnn", "alexnet", "resnet", "xceptionnet"):
+            mod = importlib.import_module("model." + name)
+            zoo = getattr(models, name)
+            for public in zoo.__all__:
+                assert getattr(mod, public) is getattr(zoo, public)
+    finally:
+        sys.path.remove(path)
+        for k in list(sys.modules):
+            if k == "model" or k.startswith("model."):
+                del sys.modules[k]
+        sys.modules.update(stale)

@@ -350,3 +350,92 @@ def test_model_modules_under_the_reference_layout(subdir):
             if k == "model" or k.startswith("model."):
                 del sys.modules[k]
         sys.modules.update(stale)
+
+
+def test_prediction_service_batches_concurrent_requests():
+    """examples/singa_easy/serve.py: concurrent requests share forward passes
+    and every caller gets the rows of its own samples."""
+    from starlette.testclient import TestClient
+    serve = _import("singa_easy", "serve")
+    from singa_amd import models, tensor
+
+    built = []
+
+    def build():
+        built.append(models.cnn.create_model(num_channels=1, num_classes=10))
+        return built[0]
+
+    predictor = serve.BatchingPredictor(build, (1, 28, 28), max_batch=4,
+                                        max_wait=0.05, graph=False)
+    try:
+        assert predictor.ready.wait(60) and predictor.failed is None
+        rng = np.random.RandomState(0)
+        samples = rng.randn(6, 1, 28, 28).astype(np.float32)
+        # reference: the model applied to each sample on its own
+        want = np.concatenate([predictor.predict(s) for s in samples], 0)
+        before = predictor.stats["batches"]
+        pending = [predictor.submit(s) for s in samples]
+        got = np.concatenate([p.result(30) for p in pending], 0)
+        np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)
+        assert predictor.stats["batches"] - before < 6      # they were stacked
+        big = predictor.predict(samples)        # more samples than one batch
+        np.testing.assert_allclose(big, want, rtol=1e-5, atol=1e-6)
+        with pytest.raises(ValueError):
+            predictor.submit(np.zeros((3, 3, 3), np.float32))
+
+        client = TestClient(serve.create_app(predictor, explain_samples=24))
+        assert client.get("/healthz").json() == {"status": "ok"}
+        r = client.post("/predict", json={"inputs": samples[:2].tolist()})
+        assert r.status_code == 200
+        np.testing.assert_allclose(np.array(r.json()["outputs"]), want[:2],
+                                   rtol=1e-4, atol=1e-5)
+        assert r.json()["classes"] == np.argmax(want[:2], 1).tolist()
+        buf = __import__("io").BytesIO()
+        np.save(buf, samples[2])
+        r = client.post("/predict", content=buf.getvalue(),
+                        headers={"content-type": "application/x-npy"})
+        np.testing.assert_allclose(np.array(r.json()["outputs"]), want[2:3],
+                                   rtol=1e-4, atol=1e-5)
+        assert client.post("/predict", json={"inputs": [1, 2]}
+                           ).status_code == 400
+        r = client.post("/explain", json={"inputs": samples[0].tolist()})
+        assert r.status_code == 200 and \
+            len(r.json()["segment_weights"]) == 16
+        text = client.get("/metrics").text
+        assert "singa_serve_samples" in text and "# TYPE" in text
+    finally:
+        predictor.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float16"])
+def test_prediction_service_replays_a_hipgraph_from_its_worker_thread(dtype):
+    serve = _import("singa_easy", "serve")
+    from singa_amd import device, models, tensor
+    dev = device.create_cuda_gpu()
+    dt = getattr(tensor, dtype)
+    holder = []
+
+    def build():
+        holder.append(models.resnet.resnet18(num_channels=3, num_classes=10))
+        return holder[0]
+
+    predictor = serve.BatchingPredictor(build, (3, 32, 32), max_batch=4,
+                                        max_wait=0.02, dev=dev, dtype=dt,
+                                        graph=True)
+    try:
+        assert predictor.ready.wait(120)
+        assert predictor.failed is None, predictor.failed
+        rng = np.random.RandomState(0)
+        samples = rng.randn(7, 3, 32, 32).astype(np.float32)
+        single = np.concatenate([predictor.predict(s) for s in samples], 0)
+        pending = [predictor.submit(s) for s in samples]
+        stacked = np.concatenate([p.result(60) for p in pending], 0)
+        tol = 1e-4 if dtype == "float32" else 3e-2
+        np.testing.assert_allclose(stacked, single, rtol=tol, atol=tol)
+        np.testing.assert_allclose(predictor.predict(samples), single,
+                                   rtol=tol, atol=tol)
+        assert np.isfinite(single).all() and np.abs(single).max() > 0
+        assert len(holder[0]._inference.plans) == 1     # one recorded pass
+    finally:
+        predictor.close()

@@ -4,7 +4,7 @@ runs as one replayed hipGraph on the MI355X (``Model.graph_inference``), and
 every caller gets its own rows back.  The role of the application that the
 reference's examples/singa_easy/scripts/start.sh brings up.
 
-    python serve.py --model resnet18 --classes 10 --size 32 --port 8000
+    python serve.py --model resnet18 --classes 10 --port 8000
     python serve.py --onnx model.onnx --shape 3 224 224 --dtype fp16
     curl -X POST localhost:8000/predict -H 'content-type: application/json' \\
          -d '{"inputs": [[[[0.1, ...]]]]}'
@@ -37,8 +37,8 @@ class BatchingPredictor(object):
     ``submit(samples)`` (an array of shape (n,) + sample_shape) returns an
     object with ``result(timeout)``.  The worker takes what is queued, up to
     ``max_batch`` samples or until ``max_wait`` seconds have passed since the
-    first one, copies it into the input tensor the forward pass was recorded
-    with (unused rows keep zeros) and replays the pass."""
+    first one, copies it into the input tensor of the smallest recorded batch
+    size that holds it and replays that pass."""
 
     def __init__(self, build_model, sample_shape, max_batch=8,
                  max_wait=0.002, dev=None, dtype=tensor.float32, graph=True):
@@ -90,24 +90,33 @@ class BatchingPredictor(object):
 
     # ---- device side -------------------------------------------------
     def _compile(self):
-        shape = (self.max_batch,) + self.sample_shape
-        self.host = np.zeros(shape, np.float32)
-        self.staging = tensor.Tensor(shape, self.dev, tensor.float32)
-        self.staging.copy_from_numpy(self.host)
+        """One input tensor and one recorded pass per batch size 1, 2, 4, ...
+        max_batch: a lone request neither uploads nor computes a full batch
+        (``Model`` keeps a recorded pass per input shape)."""
+        self.buckets = sorted({min(1 << k, self.max_batch)
+                               for k in range(self.max_batch.bit_length() + 1)})
+        self.slots = {}
+        for rows in self.buckets:
+            host = np.zeros((rows,) + self.sample_shape, np.float32)
+            staging = tensor.Tensor(host.shape, self.dev, tensor.float32)
+            staging.copy_from_numpy(host)
+            self.slots[rows] = (host, staging)
         self.model = self.build_model()
-        self.model.compile([self._input()], is_train=False,
+        self.model.compile([self._input(self.buckets[-1])], is_train=False,
                            use_graph=self.graph, sequential=False)
         self.model.eval()
         self.model.graph_inference = self.graph
-        self._forward()                     # records the pass
+        for rows in self.buckets:
+            self._forward(rows)             # records the pass of this size
 
-    def _input(self):
+    def _input(self, rows):
+        staging = self.slots[rows][1]
         if self.dtype == tensor.float32:
-            return self.staging
-        return self.staging.as_type(self.dtype)
+            return staging
+        return staging.as_type(self.dtype)
 
-    def _forward(self):
-        out = self.model(self._input())
+    def _forward(self, rows):
+        out = self.model(self._input(rows))
         return tensor.to_numpy(out.as_type(tensor.float32)
                                if self.dtype != tensor.float32 else out)
 
@@ -161,11 +170,14 @@ class BatchingPredictor(object):
             outs = []
             for lo in range(0, stacked.shape[0], self.max_batch):
                 part = stacked[lo:lo + self.max_batch]
-                self.host[:part.shape[0]] = part
-                self.host[part.shape[0]:] = 0
+                rows = next(b for b in self.buckets if b >= part.shape[0])
+                host, staging = self.slots[rows]
+                # rows beyond the request keep what an earlier batch left:
+                # every row of the output depends on its own sample only
+                host[:part.shape[0]] = part
                 t0 = time.perf_counter()
-                self.staging.copy_from_numpy(self.host)
-                y = self._forward()
+                staging.copy_from_numpy(host)
+                y = self._forward(rows)
                 self.stats["device_seconds"] += time.perf_counter() - t0
                 self.stats["batches"] += 1
                 outs.append(np.array(y[:part.shape[0]]))

@@ -420,14 +420,14 @@ def test_prediction_service_replays_a_hipgraph_from_its_worker_thread(dtype):
         holder.append(models.resnet.resnet18(num_channels=3, num_classes=10))
         return holder[0]
 
-    predictor = serve.BatchingPredictor(build, (3, 32, 32), max_batch=4,
+    predictor = serve.BatchingPredictor(build, (3, 224, 224), max_batch=4,
                                         max_wait=0.02, dev=dev, dtype=dt,
                                         graph=True)
     try:
         assert predictor.ready.wait(120)
         assert predictor.failed is None, predictor.failed
         rng = np.random.RandomState(0)
-        samples = rng.randn(7, 3, 32, 32).astype(np.float32)
+        samples = rng.randn(7, 3, 224, 224).astype(np.float32)
         single = np.concatenate([predictor.predict(s) for s in samples], 0)
         pending = [predictor.submit(s) for s in samples]
         stacked = np.concatenate([p.result(60) for p in pending], 0)
@@ -436,6 +436,7 @@ def test_prediction_service_replays_a_hipgraph_from_its_worker_thread(dtype):
         np.testing.assert_allclose(predictor.predict(samples), single,
                                    rtol=tol, atol=tol)
         assert np.isfinite(single).all() and np.abs(single).max() > 0
-        assert len(holder[0]._inference.plans) == 1     # one recorded pass
+        # one recorded pass per batch size 1, 2, 4
+        assert len(holder[0]._inference.plans) == 3
     finally:
         predictor.close()

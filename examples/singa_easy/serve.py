@@ -97,7 +97,7 @@ class BatchingPredictor(object):
                                for k in range(self.max_batch.bit_length() + 1)})
         self.slots = {}
         for rows in self.buckets:
-            host = np.zeros((rows,) + self.sample_shape, np.float32)
+            host = self._host_buffer((rows,) + self.sample_shape)
             staging = tensor.Tensor(host.shape, self.dev, tensor.float32)
             staging.copy_from_numpy(host)
             self.slots[rows] = (host, staging)
@@ -108,6 +108,16 @@ class BatchingPredictor(object):
         self.model.graph_inference = self.graph
         for rows in self.buckets:
             self._forward(rows)             # records the pass of this size
+
+    def _host_buffer(self, shape):
+        """Zeroed float32 staging array; page-locked when the model runs on a
+        GPU, so that the upload is one DMA transfer from this buffer."""
+        import torch
+        if self.graph and torch.cuda.is_available():
+            pinned = torch.zeros(shape, dtype=torch.float32).pin_memory()
+            self._pinned = getattr(self, "_pinned", []) + [pinned]
+            return pinned.numpy()
+        return np.zeros(shape, np.float32)
 
     def _input(self, rows):
         staging = self.slots[rows][1]
@@ -165,27 +175,38 @@ class BatchingPredictor(object):
                 p.done.set()
 
     def _serve(self, group):
+        """Run the samples of ``group`` in passes of at most ``max_batch``
+        rows; each sample is copied once, from the request straight into the
+        staging buffer of the pass it belongs to."""
         try:
-            stacked = np.concatenate([p.samples for p in group], 0)
+            total = sum(p.samples.shape[0] for p in group)
             outs = []
-            for lo in range(0, stacked.shape[0], self.max_batch):
-                part = stacked[lo:lo + self.max_batch]
-                rows = next(b for b in self.buckets if b >= part.shape[0])
+            flat = [(p, i) for p in group for i in range(p.samples.shape[0])]
+            for lo in range(0, total, self.max_batch):
+                part = flat[lo:lo + self.max_batch]
+                rows = next(b for b in self.buckets if b >= len(part))
                 host, staging = self.slots[rows]
                 # rows beyond the request keep what an earlier batch left:
                 # every row of the output depends on its own sample only
-                host[:part.shape[0]] = part
+                at = 0
+                while at < len(part):       # runs of rows of one request
+                    p, i = part[at]
+                    run = 1
+                    while at + run < len(part) and part[at + run][0] is p:
+                        run += 1
+                    host[at:at + run] = p.samples[i:i + run]
+                    at += run
                 t0 = time.perf_counter()
                 staging.copy_from_numpy(host)
                 y = self._forward(rows)
                 self.stats["device_seconds"] += time.perf_counter() - t0
                 self.stats["batches"] += 1
-                outs.append(np.array(y[:part.shape[0]]))
-            y = np.concatenate(outs, 0)
+                outs.append(y[:len(part)])
+            y = outs[0] if len(outs) == 1 else np.concatenate(outs, 0)
             at = 0
             for p in group:
                 n = p.samples.shape[0]
-                p.value = y[at:at + n]
+                p.value = np.array(y[at:at + n])
                 at += n
                 self.stats["requests"] += 1
                 self.stats["samples"] += n

@@ -669,6 +669,28 @@ PYBIND11_MODULE(_hip, m) {
           "xgmi_allgather");
   });
 
+  m.def("xgmi_alltoall", [make_peers](std::vector<uintptr_t> data,
+                                      std::vector<uintptr_t> flags, int rank,
+                                      uintptr_t error, int64_t off,
+                                      int64_t gathered_off,
+                                      int64_t chunk_bytes, double timeout_s,
+                                      uintptr_t s) {
+    sa::XgmiPeers pr = make_peers(data, flags, rank, error);
+    check(sa_xgmi_alltoall(&pr, rank, (int)data.size(), off, gathered_off,
+                           chunk_bytes, timeout_s, S(s)),
+          "xgmi_alltoall");
+  });
+  m.def("xgmi_reduce_scatter", [make_peers](int dt, std::vector<uintptr_t> data,
+                                            std::vector<uintptr_t> flags,
+                                            int rank, uintptr_t error,
+                                            int64_t off, int64_t bytes,
+                                            double timeout_s, uintptr_t s) {
+    sa::XgmiPeers pr = make_peers(data, flags, rank, error);
+    check(sa_xgmi_reduce_scatter(dt, &pr, rank, (int)data.size(), off, bytes,
+                                 timeout_s, S(s)),
+          "xgmi_reduce_scatter");
+  });
+
   // ---- communication helpers ----------------------------------------------------------------------------
   m.def("pack", [](int src_dt, int dst_dt, std::vector<uintptr_t> ptrs,
                    std::vector<int64_t> counts, uintptr_t bucket, uintptr_t s) {

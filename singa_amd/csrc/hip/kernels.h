@@ -516,6 +516,12 @@ int sa_xgmi_allreduce(int dtype, const sa::XgmiPeers *peers, int rank,
 int sa_xgmi_allgather(const sa::XgmiPeers *peers, int rank, int world,
                       int64_t off, int64_t gathered_off, int64_t bytes,
                       double timeout_s, hipStream_t s);
+int sa_xgmi_alltoall(const sa::XgmiPeers *peers, int rank, int world,
+                     int64_t off, int64_t gathered_off, int64_t chunk_bytes,
+                     double timeout_s, hipStream_t s);
+int sa_xgmi_reduce_scatter(int dtype, const sa::XgmiPeers *peers, int rank,
+                           int world, int64_t off, int64_t bytes,
+                           double timeout_s, hipStream_t s);
 int sa_pack(int src_dtype, int dst_dtype, int n_tensors, void *const *ptrs,
             const int64_t *counts, void *bucket, hipStream_t s);
 int sa_unpack(int src_dtype, int dst_dtype, int n_tensors, void *const *ptrs,

@@ -161,7 +161,7 @@ __device__ __forceinline__ void sum_peers_many(const XgmiPeers &pr, int64_t off,
 }
 
 // nvec 16-byte vectors at byte offset `off` of every window
-template <typename T>
+template <typename T, bool kGather>
 __global__ void __launch_bounds__(kXgmiThreads, 4)
 xgmi_allreduce_two_shot_kernel(XgmiPeers pr, int rank, int world, int64_t off,
                                int64_t nvec, long long limit) {
@@ -183,7 +183,12 @@ xgmi_allreduce_two_shot_kernel(XgmiPeers pr, int rank, int world, int64_t off,
     for (int64_t i = lo + first; i < hi; i += kXgmiUnroll * step)
       sum_peers_many<T, kXgmiMaxRanks>(pr, off, i, step, hi, world, mine);
   }
+  // no peer reads this rank's input any more once all have passed here
   peer_barrier(pr, rank, world, e + 2, limit, &dead);
+  if (!kGather) {     // reduce-scatter: this rank's slice is the result
+    if (threadIdx.x == 0) pr.epoch[blockIdx.x] = e + 2;
+    return;
+  }
   {
     uint4 *mine = reinterpret_cast<uint4 *>(pr.data[rank] + off);
     // start with the next rank so that at any moment the W ranks read from W
@@ -236,7 +241,8 @@ xgmi_allreduce_one_shot_kernel(XgmiPeers pr, int rank, int world, int64_t off,
 template <typename V>
 __global__ void __launch_bounds__(kXgmiThreads)
 xgmi_allgather_kernel(XgmiPeers pr, int rank, int world, int64_t off,
-                      int64_t goff, int64_t nvec, long long limit) {
+                      int64_t goff, int64_t nvec, int64_t sstride,
+                      long long limit) {
   __shared__ int dead;
   __shared__ unsigned epoch0;
   if (threadIdx.x == 0) {
@@ -251,7 +257,10 @@ xgmi_allgather_kernel(XgmiPeers pr, int rank, int world, int64_t off,
   V *out = reinterpret_cast<V *>(pr.data[rank] + goff);
   for (int d = 0; d < world; ++d) {
     const int p = (rank + d) % world;
-    const V *src = reinterpret_cast<const V *>(pr.data[p] + off);
+    // sstride 0: every reader takes the same nvec vectors of peer p
+    // (all-gather); nvec: reader r takes the r-th chunk (all-to-all)
+    const V *src = reinterpret_cast<const V *>(pr.data[p] + off) +
+                   (int64_t)rank * sstride;
     for (int64_t i = first; i < nvec; i += kXgmiUnroll * step) {
       V v[kXgmiUnroll];
 #pragma unroll
@@ -383,7 +392,7 @@ int sa_xgmi_allreduce(int dtype, const sa::XgmiPeers *peers, int rank,
                          dim3(kXgmiThreads), 0, s, *peers, rank, world, off,
                          nvec, limit);
     else
-      hipLaunchKernelGGL((xgmi_allreduce_two_shot_kernel<T>),
+      hipLaunchKernelGGL((xgmi_allreduce_two_shot_kernel<T, true>),
                          dim3(xgmi_blocks((nvec + world - 1) / world)),
                          dim3(kXgmiThreads), 0, s, *peers, rank, world, off,
                          nvec, limit);
@@ -391,22 +400,61 @@ int sa_xgmi_allreduce(int dtype, const sa::XgmiPeers *peers, int rank,
   return 0;
 }
 
-int sa_xgmi_allgather(const sa::XgmiPeers *peers, int rank, int world,
-                      int64_t off, int64_t gathered_off, int64_t bytes,
-                      double timeout_s, hipStream_t s) {
+static int xgmi_gather_launch(const sa::XgmiPeers *peers, int rank, int world,
+                              int64_t off, int64_t gathered_off,
+                              int64_t bytes, bool chunked, double timeout_s,
+                              hipStream_t s) {
   if ((bytes & 3) != 0 || (gathered_off & 15) != 0 || gathered_off < 0)
     return -2;
+  // chunks of an all-to-all start at multiples of the chunk size: 16-byte
+  // vectors need 16-byte chunks
   const bool wide = (bytes & 15) == 0;
   const int64_t nvec = wide ? bytes >> 4 : bytes >> 2;
   if (!xgmi_args_ok(*peers, rank, world, off, nvec)) return -2;
+  const int64_t sstride = chunked ? nvec : 0;
   if (wide)
     hipLaunchKernelGGL(xgmi_allgather_kernel<uint4>, dim3(xgmi_blocks(nvec)),
                        dim3(kXgmiThreads), 0, s, *peers, rank, world, off,
-                       gathered_off, nvec, xgmi_ticks(timeout_s));
+                       gathered_off, nvec, sstride, xgmi_ticks(timeout_s));
   else
     hipLaunchKernelGGL(xgmi_allgather_kernel<uint32_t>,
                        dim3(xgmi_blocks(nvec)), dim3(kXgmiThreads), 0, s,
-                       *peers, rank, world, off, gathered_off, nvec,
+                       *peers, rank, world, off, gathered_off, nvec, sstride,
                        xgmi_ticks(timeout_s));
+  return 0;
+}
+
+int sa_xgmi_allgather(const sa::XgmiPeers *peers, int rank, int world,
+                      int64_t off, int64_t gathered_off, int64_t bytes,
+                      double timeout_s, hipStream_t s) {
+  return xgmi_gather_launch(peers, rank, world, off, gathered_off, bytes,
+                            false, timeout_s, s);
+}
+
+// Every rank holds world chunks of chunk_bytes at off; afterwards the p-th
+// chunk at gathered_off is the chunk that rank p held for this rank.
+int sa_xgmi_alltoall(const sa::XgmiPeers *peers, int rank, int world,
+                     int64_t off, int64_t gathered_off, int64_t chunk_bytes,
+                     double timeout_s, hipStream_t s) {
+  return xgmi_gather_launch(peers, rank, world, off, gathered_off,
+                            chunk_bytes, true, timeout_s, s);
+}
+
+// Sum over the ranks of the bytes at off, cut into world slices of equal
+// size: afterwards slice `rank` of this rank's buffer holds the sum (the
+// other slices keep this rank's input).
+int sa_xgmi_reduce_scatter(int dtype, const sa::XgmiPeers *peers, int rank,
+                           int world, int64_t off, int64_t bytes,
+                           double timeout_s, hipStream_t s) {
+  if ((bytes & 15) != 0 || world < 1 || ((bytes >> 4) % world) != 0)
+    return -2;
+  const int64_t nvec = bytes >> 4;
+  if (!xgmi_args_ok(*peers, rank, world, off, nvec)) return -2;
+  const long long limit = xgmi_ticks(timeout_s);
+  SA_DISPATCH_FLOAT(dtype, T, {
+    hipLaunchKernelGGL((xgmi_allreduce_two_shot_kernel<T, false>),
+                       dim3(xgmi_blocks(nvec / world)), dim3(kXgmiThreads), 0,
+                       s, *peers, rank, world, off, nvec, limit);
+  })
   return 0;
 }

@@ -149,6 +149,37 @@ class XgmiWindow(object):
                               out.data_ptr() - self.data, nbytes,
                               self.timeout, s)
 
+    def all_to_all(self, out, t):
+        """``t`` holds one chunk per rank, in rank order; afterwards chunk p
+        of ``out`` is the chunk rank p held for this rank.  Both from
+        ``tensor``, not overlapping, chunks of whole 32-bit words."""
+        assert self.owns(t) and self.owns(out)
+        nbytes = t.numel() * t.element_size()
+        assert out.numel() * out.element_size() == nbytes
+        assert nbytes % (4 * self.world) == 0, \
+            "every chunk must be whole 32-bit words"
+        lo, hi = t.data_ptr(), out.data_ptr()
+        assert lo + nbytes <= hi or hi + nbytes <= lo, "operands overlap"
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.k.xgmi_alltoall(self.peer_data, self.peer_flags, self.rank,
+                             self._err_dev, lo - self.data, hi - self.data,
+                             nbytes // self.world, self.timeout, s)
+
+    def reduce_scatter(self, t):
+        """Sum ``t`` (from ``tensor``; a multiple of 16 * world bytes) over
+        the ranks and return the view of this rank's slice of it, which holds
+        the sum; the other slices keep this rank's input."""
+        assert self.owns(t) and t.is_contiguous()
+        off, nbytes = t.data_ptr() - self.data, t.numel() * t.element_size()
+        assert off % 16 == 0 and nbytes % (16 * self.world) == 0, \
+            "every slice must be whole 16-byte vectors"
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        self.k.xgmi_reduce_scatter(_CODE[t.dtype], self.peer_data,
+                                   self.peer_flags, self.rank, self._err_dev,
+                                   off, nbytes, self.timeout, s)
+        n = t.numel() // self.world
+        return t.view(-1)[self.rank * n:(self.rank + 1) * n]
+
     def check(self):
         """Raise when a barrier of one of this rank's kernels has timed out
         (the word is in host memory: reading it waits for nothing)."""

@@ -108,6 +108,41 @@ def rank_main():
             assert np.array_equal(
                 got[r], np.arange(words, dtype=np.int32) * (r + 1) + seed), (
                     words, r)
+    # all-to-all: chunk p of the result came from rank p, which held it as its
+    # chunk number `rank`
+    for words in (4, 3, 1024, 50001):
+        seed += 1
+        src = win.tensor(world * words, torch.int32)
+        out = win.tensor(world * words, torch.int32)
+        base = torch.arange(world * words, dtype=torch.int32)
+        for rep in range(2):
+            src.copy_(base + 1000003 * rank + seed + rep)
+            win.all_to_all(out, src)
+            torch.cuda.synchronize()
+            got = out.cpu().numpy().reshape(world, words)
+            for r in range(world):
+                want = np.arange(rank * words, (rank + 1) * words,
+                                 dtype=np.int32) + 1000003 * r + seed + rep
+                assert np.array_equal(got[r], want), (words, r, rep)
+    # reduce-scatter: this rank's slice holds the sum, the others the input
+    for tdt, tol in ((torch.float32, 0.0), (torch.float16, 0.0)):
+        for per in (8, 4096, 262144 + 8):
+            seed += 1
+            n = per * world
+            t = win.tensor(n, tdt)
+            want = sum(_input(r, n, seed) for r in range(world))
+            mine = torch.from_numpy(_input(rank, n, seed)).to(tdt).to(dev)
+            for rep in range(2):
+                t.copy_(mine)
+                part = win.reduce_scatter(t)
+                torch.cuda.synchronize()
+                got = part.double().cpu().numpy()
+                ref = want[rank * per:(rank + 1) * per]
+                assert np.abs(got - ref).max() <= tol, (str(tdt), per, rep)
+                other = (rank + 1) % world
+                if other != rank:
+                    assert torch.equal(t[other * per:(other + 1) * per],
+                                       mine[other * per:(other + 1) * per])
     # captured into a hipGraph and replayed
     big = win.tensor(3 * (1 << 20) + 8, torch.float32)
     small = win.tensor(2048, torch.float32)

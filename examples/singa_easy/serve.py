@@ -77,6 +77,9 @@ class BatchingPredictor(object):
         if samples.shape[1:] != self.sample_shape or samples.shape[0] == 0:
             raise ValueError("expected samples of shape %s, got %s" % (
                 self.sample_shape, samples.shape))
+        if self.failed is not None:
+            raise RuntimeError("the model could not be set up: %s" %
+                               (self.failed,))
         pending = self._Pending(samples)
         self.requests.put(pending)
         return pending

@@ -254,3 +254,26 @@ def test_caffe_network_trains_as_a_replayed_graph_on_the_gpu(files):
     losses = [float(tensor.to_numpy(net(x, y)[1]).ravel()[0])
               for _ in range(12)]
     assert losses[-1] < losses[0]
+
+
+def test_imported_network_exports_to_onnx(tmp_path):
+    """A Caffe description becomes an ONNX file through the model it was
+    turned into; the ONNX backend gives the same outputs."""
+    from singa_amd import sonnx
+    here = os.path.dirname(os.path.abspath(__file__))
+    conv = converter.CaffeConverter(
+        os.path.join(here, "..", "examples", "caffe", "lenet.prototxt"))
+    net = conv.create_net("test")
+    x = tensor.from_numpy(
+        np.random.RandomState(0).randn(2, 1, 28, 28).astype(np.float32))
+    net.compile([x], is_train=False, use_graph=False, sequential=False)
+    net.eval()
+    y = net(x)
+    proto = sonnx.to_onnx([x], [y], "lenet")
+    assert [n.op_type for n in proto.graph.node].count("Conv") == 2
+    path = tmp_path / "lenet.onnx"
+    path.write_bytes(proto.SerializeToString())
+    rep = sonnx.prepare(sonnx.onnx.load(str(path)), device="CPU")
+    got = rep.run([x])[0]
+    got = got if isinstance(got, np.ndarray) else tensor.to_numpy(got)
+    np.testing.assert_allclose(got, tensor.to_numpy(y), rtol=1e-6, atol=1e-6)
